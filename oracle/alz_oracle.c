@@ -1,0 +1,235 @@
+/*
+ * alz_oracle.c -- CPU restatement of AudioLazy's linear-filter hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under audiolazy_amd/ may include, link or
+ * call this file; it is the checker for tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py, never the thing shipped or measured as product.
+ *
+ * Parity status: PINNED.  oracle/gen_golden.py runs the reference itself
+ * (imported from /root/reference) and commits its outputs under tests/golden/;
+ * tests/test_oracle_golden.py checks every function below bit-for-bit against
+ * those vectors and against the reference's own doctest / test known answers.
+ *
+ * Compile with -ffp-contract=off: CPython floats are IEEE binary64 with a
+ * separately rounded multiply and add, and so is every expression here.
+ *
+ * Reference lines restated (paths relative to /root/reference/):
+ *   audiolazy/lazy_filters.py:197-257  generated difference-equation body
+ *   audiolazy/lazy_filters.py:233-237  gain handling (a0 == -1, a0 != 1)
+ *   audiolazy/lazy_filters.py:185-195  memory -> m1..m_{la-1}
+ *   audiolazy/lazy_filters.py:988-990  CascadeFilter = nested filters
+ *   audiolazy/lazy_analysis.py:311-312 acorr sum order
+ *   audiolazy/lazy_lpc.py:115-136      levinson_durbin (dense inner products)
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define ALZO_MAX_TAPS 4096
+
+/*
+ * One channel, one section, Direct Form I in the reference's term order
+ * (lazy_filters.py:198-224): numerator terms by ascending delay, then
+ * denominator terms by ascending delay; coefficients equal to zero are not
+ * part of the expression at all (:209, :223); the sum is left-to-right.
+ * "coeff == 1 -> d", "coeff == -1 -> -d" (:205-208, :219-222) are the same
+ * doubles as 1*d and -1*d, so they need no special case here.
+ *
+ *   xh[k] = x[-1-k]  (the reference's d1..d_{nb-1}, all `zero` at start, :247-250)
+ *   yh[k] = y[-1-k]  (the reference's m1..m_{na-1}, from `memory`, :243-246)
+ * Both histories are updated in place so a second call continues the stream.
+ *
+ * Returns 0, or -1 when a[0] == 0 (ZeroDivisionError, :177-178), or -2 when
+ * every term vanished (the reference then yields `zero`, :227-231 -- the
+ * caller handles that, there is no arithmetic to restate).
+ */
+int alzo_df1(const double *b, int nb, const double *a, int na,
+             const double *x, int64_t sx, double *y, int64_t sy, int64_t n,
+             double *xh, double *yh)
+{
+  if (na < 1 || a[0] == 0.0) return -1;
+  if (nb > ALZO_MAX_TAPS || na > ALZO_MAX_TAPS) return -3;
+  int nterms = 0;
+  for (int k = 0; k < nb; ++k) nterms += (b[k] != 0.0);
+  for (int k = 1; k < na; ++k) nterms += (a[k] != 0.0);
+  if (nterms == 0) return -2;
+
+  const double gain = a[0];
+  /* "-{value} * m{idx}" (:224): unary minus binds to the literal, so the
+   * product is (-a_k) * m_k. */
+  double *na_ = (double *)malloc(sizeof(double) * (size_t)(na > 0 ? na : 1));
+  for (int k = 1; k < na; ++k) na_[k] = -a[k];
+
+  for (int64_t i = 0; i < n; ++i) {
+    const double d0 = x[i * sx];
+    double acc = 0.0;
+    int first = 1;
+    for (int k = 0; k < nb; ++k) {
+      if (b[k] == 0.0) continue;
+      const double d = (k == 0) ? d0 : xh[k - 1];
+      const double t = b[k] * d;
+      if (first) { acc = t; first = 0; } else acc = acc + t;
+    }
+    for (int k = 1; k < na; ++k) {
+      if (a[k] == 0.0) continue;
+      const double t = na_[k] * yh[k - 1];
+      if (first) { acc = t; first = 0; } else acc = acc + t;
+    }
+    double m0;
+    if (gain == 1.0) m0 = acc;            /* :233-237 */
+    else if (gain == -1.0) m0 = -acc;
+    else m0 = acc / gain;
+    y[i * sy] = m0;
+    /* shifts, :254-257 */
+    for (int k = na - 2; k > 0; --k) yh[k] = yh[k - 1];
+    if (na > 1) yh[0] = m0;
+    for (int k = nb - 2; k > 0; --k) xh[k] = xh[k - 1];
+    if (nb > 1) xh[0] = d0;
+  }
+  free(na_);
+  return 0;
+}
+
+/*
+ * Bank: C independent channels, each a cascade of S sections
+ * (CascadeFilter.__call__, lazy_filters.py:988-990: stage s+1 consumes the
+ * output stream of stage s).  Layouts:
+ *   x, y    : element (n, c) at  n*sn + c*sc   (time-major: sn=C, sc=1;
+ *             channel-major: sn=1, sc=N)
+ *   coefs   : per channel (per_channel=1) or shared (0).  For channel c,
+ *             section s: b at bcoef[c*tb + boff[s] .. +nb[s]],
+ *             a at acoef[c*ta + aoff[s] .. +na[s]]   (tb = sum nb, ta = sum na)
+ *   xh / yh : histories, per channel, sections concatenated:
+ *             xh[c*thx + hxoff[s] + k], thx = sum (nb[s]-1), likewise yh.
+ * `y` may alias `x`.  Returns 0 or the first non-zero alzo_df1 status
+ * (status -2, the all-zero section, is handled by writing `zero`).
+ */
+int alzo_bank(int64_t C, int S, const int *nb, const int *na,
+              const double *bcoef, const double *acoef, int per_channel,
+              const double *x, int64_t sxn, int64_t sxc,
+              double *y, int64_t syn, int64_t syc, int64_t n,
+              double *xh, double *yh, double zero)
+{
+  int tb = 0, ta = 0, thx = 0, thy = 0;
+  for (int s = 0; s < S; ++s) {
+    tb += nb[s]; ta += na[s];
+    thx += nb[s] > 0 ? nb[s] - 1 : 0;
+    thy += na[s] - 1;
+  }
+  int rc = 0;
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  for (int64_t c = 0; c < C; ++c) {
+    const double *bc = bcoef + (per_channel ? c * tb : 0);
+    const double *ac = acoef + (per_channel ? c * ta : 0);
+    double *xhc = xh + c * thx, *yhc = yh + c * thy;
+    for (int s = 0; s < S; ++s) {
+      const double *src = (s == 0) ? x + c * sxc : tmp;
+      const int64_t ss = (s == 0) ? sxn : 1;
+      double *dst = (s == S - 1) ? y + c * syc : tmp;
+      const int64_t ds = (s == S - 1) ? syn : 1;
+      int r = alzo_df1(bc, nb[s], ac, na[s], src, ss, dst, ds, n, xhc, yhc);
+      if (r == -2) {
+        /* the reference's all-zero generator yields `zero` per input item and
+         * keeps no state (:227-231) */
+        for (int64_t i = 0; i < n; ++i) dst[i * ds] = zero;
+        r = 0;
+      }
+      if (r != 0 && rc == 0) rc = r;
+      bc += nb[s]; ac += na[s];
+      xhc += nb[s] > 0 ? nb[s] - 1 : 0; yhc += na[s] - 1;
+    }
+  }
+  free(tmp);
+  return rc;
+}
+
+/*
+ * acorr (lazy_analysis.py:311-312):
+ *   [sum(blk[n] * blk[n + tau] for n in range(len(blk) - tau)) for tau in 0..max_lag]
+ * Python's sum starts from int 0 and adds left to right.
+ */
+void alzo_acorr(const double *blk, int64_t len, int max_lag, double *r)
+{
+  for (int tau = 0; tau <= max_lag; ++tau) {
+    double acc = 0.0;
+    for (int64_t n = 0; n + tau < len; ++n) acc = acc + blk[n] * blk[n + tau];
+    r[tau] = acc;
+  }
+}
+
+/*
+ * levinson_durbin (lazy_lpc.py:115-136), restated with the reference's dense
+ * inner products (O(order^3) overall):
+ *   inner(a, b) = sum(acdata[|i-j|] * a_i * b_j  for i.. for j..)   (:121-125)
+ *   A = 1;  for m in 1..order:  B = A(1/z) * z**-m;
+ *                               A -= inner(A, z**-m) / inner(B, B) * B   (:128-131)
+ *   error = inner(A, A)                                               (:135)
+ * acdata shorter than order+1 is zero-extended (:117-118).
+ * Returns 0, or -4 on a zero inner(B,B) (ParCorError, :132-133).
+ * coefs must hold order+1 doubles.
+ */
+static double alzo_inner(const double *ac, const double *a, int la,
+                         const double *b, int lb)
+{
+  double acc = 0.0;
+  for (int i = 0; i < la; ++i)
+    for (int j = 0; j < lb; ++j) {
+      int d = i - j; if (d < 0) d = -d;
+      acc = acc + (ac[d] * a[i]) * b[j];
+    }
+  return acc;
+}
+
+int alzo_levinson(const double *acdata, int nac, int order, double *coefs, double *err)
+{
+  double *ac = (double *)calloc((size_t)order + 2, sizeof(double));
+  double *A = (double *)calloc((size_t)order + 2, sizeof(double));
+  double *B = (double *)calloc((size_t)order + 2, sizeof(double));
+  double *Z = (double *)calloc((size_t)order + 2, sizeof(double));
+  for (int i = 0; i <= order && i < nac; ++i) ac[i] = acdata[i];
+  int la = 1, rc = 0;
+  A[0] = 1.0;
+  for (int m = 1; m <= order; ++m) {
+    /* B = A(1/z) * z**-m : powers m-i for i in 0..la-1; numlist is dense 0..m */
+    memset(B, 0, sizeof(double) * ((size_t)order + 2));
+    for (int i = 0; i < la; ++i) B[m - i] = A[i];
+    memset(Z, 0, sizeof(double) * ((size_t)order + 2));
+    Z[m] = 1.0;
+    const double num = alzo_inner(ac, A, la, Z, m + 1);
+    const double den = alzo_inner(ac, B, m + 1, B, m + 1);
+    if (den == 0.0) { rc = -4; break; }
+    const double k = num / den;
+    /* A -= k * B : Poly scalar product then subtraction, per coefficient */
+    for (int i = 0; i <= m; ++i) A[i] = A[i] - k * B[i];
+    /* Poly drops exact-zero terms, so the dense numlist can shrink when the
+     * top coefficient cancels to zero. */
+    la = m + 1;
+    while (la > 1 && A[la - 1] == 0.0) --la;
+  }
+  if (rc == 0) {
+    for (int i = 0; i <= order; ++i) coefs[i] = (i < la) ? A[i] : 0.0;
+    *err = alzo_inner(ac, A, la, A, la);
+  }
+  free(ac); free(A); free(B); free(Z);
+  return rc;
+}
+
+/* lpc.kautocor (lazy_lpc.py:229-272): acorr(blk, order) then levinson_durbin. */
+int alzo_kautocor(const double *blk, int64_t len, int order, double *coefs, double *err)
+{
+  double *r = (double *)calloc((size_t)order + 1, sizeof(double));
+  alzo_acorr(blk, len, order, r);
+  int rc = alzo_levinson(r, order + 1, order, coefs, err);
+  free(r);
+  return rc;
+}
+
+/* Frames of a batch: frames[f*hop .. f*hop+len), results [F, order+1], [F], [F]. */
+void alzo_kautocor_frames(const double *sig, int64_t F, int64_t len, int64_t hop,
+                          int order, double *coefs, double *err, int *status)
+{
+  for (int64_t f = 0; f < F; ++f)
+    status[f] = alzo_kautocor(sig + f * hop, len, order,
+                              coefs + f * (order + 1), err + f);
+}

@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by RUNNING THE REFERENCE (AudioLazy 0.6.1dev).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Every vector committed under tests/golden/ comes out of the unmodified
+reference imported from /root/reference; this script is the provenance.
+Floats are stored as ``float.hex()`` strings so the fixtures are bit-exact.
+
+Reference entry points exercised (paths relative to /root/reference/):
+  audiolazy/lazy_filters.py:141-264   LinearFilter.__call__ (DF-I generator)
+  audiolazy/lazy_filters.py:988-990   CascadeFilter.__call__
+  audiolazy/lazy_filters.py:1048-1054 ParallelFilter.__call__
+  audiolazy/lazy_filters.py:1087-1495 comb / resonator / lowpass / highpass
+  audiolazy/lazy_auditory.py:55-218   erb, gammatone_erb_constants, gammatone
+  audiolazy/lazy_analysis.py:277-312  acorr
+  audiolazy/lazy_lpc.py:52-136,229-272 levinson_durbin, lpc.kautocor
+  audiolazy/lazy_misc.py:74-129       blocks
+"""
+import json
+import os
+import random
+import sys
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import audiolazy as al  # noqa: E402
+from audiolazy import (z, ZFilter, CascadeFilter, ParallelFilter, Stream,  # noqa: E402
+                       resonator, comb, lowpass, highpass, sHz, gammatone, erb,
+                       gammatone_erb_constants, acorr, levinson_durbin, lpc,
+                       white_noise, repeat)
+import numpy as np  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+s, Hz = sHz(48000)
+
+
+def hx(v):
+  if isinstance(v, (list, tuple)):
+    return [hx(i) for i in v]
+  return float(v).hex()
+
+
+def noise(n, seed):
+  random.seed(seed)
+  return [random.uniform(-1.0, 1.0) for _ in range(n)]
+
+
+def dump(name, obj):
+  path = os.path.join(OUT, name)
+  with open(path, "w") as f:
+    json.dump(obj, f, indent=0, separators=(",", ":"))
+  print("%-28s %8d bytes" % (name, os.path.getsize(path)))
+
+
+# --------------------------------------------------------------------------
+# 1. DF-I execution: single filters, seeded inputs, memory / zero variants
+# --------------------------------------------------------------------------
+def filt_cases():
+  cases = []
+
+  def add(tag, filt, x, **kw):
+    y = list(filt(list(x), **kw))
+    mem = kw.get("memory")
+    if callable(mem):
+      raise ValueError
+    case = dict(tag=tag, b=hx(filt.numlist), a=hx(filt.denlist),
+                memory=None if mem is None else hx(list(mem)),
+                zero=hx(kw.get("zero", 0.0)), y=hx(y))
+    if list(x) == base[:len(x)]:
+      case["x_len"] = len(x)  # prefix of the shared input
+    else:
+      case["x"] = hx(x)
+    cases.append(case)
+
+  x = base = noise(400, 1234)
+  add("lowpass.pole**2@1k", lowpass.pole(1000 * Hz) ** 2, x)
+  add("lowpass.pole@1k", lowpass.pole(1000 * Hz), x)
+  add("lowpass.z@3k", lowpass.z(3000 * Hz), x)
+  add("lowpass.pole_exp@500", lowpass.pole_exp(500 * Hz), x)
+  add("lowpass.z_exp@500", lowpass.z_exp(500 * Hz), x)
+  add("highpass.z@1k", highpass.z(1000 * Hz), x)
+  add("highpass.pole@2k", highpass.pole(2000 * Hz), x)
+  add("highpass.pole_exp@2k", highpass.pole_exp(2000 * Hz), x)
+  add("highpass.z_exp@2k", highpass.z_exp(2000 * Hz), x)
+  add("resonator.z_exp@1k/100", resonator.z_exp(1000 * Hz, 100 * Hz), x)
+  add("resonator.poles_exp@1k/100", resonator.poles_exp(1000 * Hz, 100 * Hz), x)
+  add("resonator.freq_z_exp@440/30", resonator.freq_z_exp(440 * Hz, 30 * Hz), x)
+  add("resonator.freq_poles_exp@440/30", resonator.freq_poles_exp(440 * Hz, 30 * Hz), x)
+  add("resonator.z_exp@50/1 highQ", resonator.z_exp(50 * Hz, 1 * Hz), x)
+  add("comb.fb(5,.5)", comb.fb(5, .5), x)
+  add("comb.ff(7,-.25)", comb.ff(7, -.25), x)
+  add("comb.tau(20,100)", comb.tau(20, 100), x)
+  add("gain a0=2", ZFilter([.2, .3, .4], [2., -.5, .25]), x)
+  add("gain a0=-1", ZFilter([.2, .3, .4], [-1., -.5, .25]), x)
+  add("gain a0=-18 sparse", ZFilter([1., 0., -1.], [-18., 9.8, 0., 14.3]), x)
+  add("fir4", ZFilter([.1, .2, .3, .4]), x)
+  add("fir unit taps", ZFilter([1., -1., 0., 1.]), x)
+  add("pure delay 3", z ** -3 + 0., x)
+  add("b0==0 leading", ZFilter([0., 0.5, 0.25], [1., -0.3]), x)
+  add("a1==0", ZFilter([0.5], [1., 0., 0.81]), x)
+  add("unit feedback", 1 / (1 - z ** -1), x[:64])
+  add("x[n-1]-y[n-2]", z ** -1 / (1 + z ** -2), x[:64])
+  # memory / zero semantics (lazy_filters.py:185-195, 243-250)
+  f2 = resonator.z_exp(1000 * Hz, 100 * Hz)
+  add("mem full", f2, x[:100], memory=[0.25, -0.5])
+  add("mem short -> left pad", f2, x[:100], memory=[0.7])
+  add("mem long -> truncated", f2, x[:100], memory=[0.1, 0.2, 0.3, 0.4])
+  add("zero=0.5", f2, x[:100], zero=0.5)
+  add("mem short + zero", f2, x[:100], memory=[0.7], zero=-0.25)
+  add("fir zero=1.5", ZFilter([.1, .2, .3, .4]), x[:50], zero=1.5)
+  add("gain + mem + zero", ZFilter([.2, .3, .4], [2., -.5, .25]), x[:100],
+      memory=[1.0, -1.0], zero=0.125)
+  # an 8-tap-numerator section of gammatone.sampled (ill-conditioned numerator)
+  g = gammatone.sampled(100 * Hz, gammatone_erb_constants(4)[0] * erb(100 * Hz, Hz))
+  add("gammatone.sampled[0]@100", g[0], x)
+  # non-finite input: zero-coefficient terms are absent from the expression
+  xin = list(x[:40]); xin[7] = float("inf")
+  add("inf with zero tap", ZFilter([0.5, 0.0, 0.25]), xin)
+  return dict(x=hx(base), cases=cases)
+
+
+# --------------------------------------------------------------------------
+# 2. scipy.signal.lfilter grid re-stated from tests/test_filters_extdep.py:41-47
+#    (that file cannot be collected on NumPy 2; run its cases on the reference)
+# --------------------------------------------------------------------------
+def lfilter_grid():
+  out = []
+  for a in ([1.], [3.], [1., 3.], [15., -17.2], [-18., 9.8, 0., 14.3]):
+    for b in ([1.], [-1.], [1., 0., -1.], [1., 3.]):
+      for data in (list(range(5)), list(range(5, 0, -1)), [7, 22, -5], [8., 3., 15.]):
+        y = list(ZFilter(b, a)([float(v) for v in data]))
+        out.append(dict(b=hx(b), a=hx(a), x=hx(data), y=hx(y)))
+  return out
+
+
+# --------------------------------------------------------------------------
+# 3. containers
+# --------------------------------------------------------------------------
+def container_cases():
+  x = noise(400, 99)
+  out = []
+  fs = [lowpass.pole(800 * Hz), highpass.z(200 * Hz), resonator.z_exp(1500 * Hz, 80 * Hz)]
+  casc = CascadeFilter(fs)
+  out.append(dict(kind="cascade", sections=[dict(b=hx(f.numlist), a=hx(f.denlist)) for f in fs],
+                  x=hx(x), memory=None, zero=hx(0.0), y=hx(list(casc(list(x))))))
+  # same memory / zero forwarded to every stage (lazy_filters.py:989)
+  fs2 = [resonator.poles_exp(700 * Hz, 50 * Hz), resonator.z_exp(900 * Hz, 60 * Hz)]
+  out.append(dict(kind="cascade", sections=[dict(b=hx(f.numlist), a=hx(f.denlist)) for f in fs2],
+                  x=hx(x[:120]), memory=hx([0.3, -0.2]), zero=hx(0.1),
+                  y=hx(list(CascadeFilter(fs2)(list(x[:120]), memory=[0.3, -0.2], zero=0.1)))))
+  par = ParallelFilter(fs)
+  out.append(dict(kind="parallel", sections=[dict(b=hx(f.numlist), a=hx(f.denlist)) for f in fs],
+                  x=hx(x), memory=None, zero=hx(0.0), y=hx(list(par(list(x))))))
+  return out
+
+
+# --------------------------------------------------------------------------
+# 4. design functions: coefficients only
+# --------------------------------------------------------------------------
+def design_cases():
+  out = []
+  freqs = [50., 440., 1000., 3000., 12000., 20000.]
+  for name, sd in (("lowpass", lowpass), ("highpass", highpass)):
+    for strat in ("pole", "z", "pole_exp", "z_exp"):
+      for f in freqs:
+        filt = getattr(sd, strat)(f * Hz)
+        out.append(dict(fn=name, strategy=strat, args=hx([f * Hz]),
+                        b=hx(filt.numlist), a=hx(filt.denlist)))
+  for strat in ("poles_exp", "freq_poles_exp", "z_exp", "freq_z_exp"):
+    for f in freqs:
+      for q in (2., 10., 50.):
+        filt = getattr(resonator, strat)(f * Hz, f / q * Hz)
+        out.append(dict(fn="resonator", strategy=strat, args=hx([f * Hz, f / q * Hz]),
+                        b=hx(filt.numlist), a=hx(filt.denlist)))
+  for d, al_ in ((1, .5), (5, .5), (100, -.9), (441, .99)):
+    for strat in ("fb", "ff"):
+      filt = getattr(comb, strat)(d, al_)
+      out.append(dict(fn="comb", strategy=strat, args=hx([d, al_]),
+                      b=hx(filt.numlist), a=hx(filt.denlist)))
+  for d, tau in ((20, 100), (109, 48000)):
+    filt = comb.tau(d, tau)
+    out.append(dict(fn="comb", strategy="tau", args=hx([d, tau]),
+                    b=hx(filt.numlist), a=hx(filt.denlist)))
+  return out
+
+
+def auditory_cases():
+  out = dict(erb=[], consts=[], gammatone=[])
+  for strat in ("gm90", "mg83"):
+    for f in (50., 100., 1000., 3000., 8000., 20000.):
+      out["erb"].append(dict(strategy=strat, freq=hx(f), value=hx(getattr(erb, strat)(f))))
+      out["erb"].append(dict(strategy=strat, freq=hx(f * Hz), Hz=hx(Hz),
+                             value=hx(getattr(erb, strat)(f * Hz, Hz))))
+  for n in (1, 2, 3, 4, 5, 8):
+    out["consts"].append(dict(n=n, value=hx(gammatone_erb_constants(n))))
+  x = noise(500, 777)
+  for strat in ("sampled", "slaney", "klapuri"):
+    for fc in (50., 100., 1000., 8000., 20000.):
+      bw = gammatone_erb_constants(4)[0] * erb(fc * Hz, Hz)
+      g = getattr(gammatone, strat)(fc * Hz, bw)
+      y = list(g(list(x)))
+      out["gammatone"].append(dict(strategy=strat, freq=hx(fc * Hz), bw=hx(bw),
+                                   sections=[dict(b=hx(f.numlist), a=hx(f.denlist)) for f in g],
+                                   y=hx(y)))
+  out["x"] = hx(x)
+  return out
+
+
+# --------------------------------------------------------------------------
+# 5. multichannel: the reference's vector-valued-sample idiom
+#    (tests/test_filters_extdep.py:49-89; per-channel coefs via repeat(ndarray))
+# --------------------------------------------------------------------------
+def multichannel_case():
+  rng = np.random.default_rng(20260924)
+  C, N = 8, 256
+  x = rng.uniform(-1, 1, (N, C))
+  fcs = np.geomspace(50., 20000., C)
+  filts = [resonator.z_exp(fc * Hz, fc / 10 * Hz) for fc in fcs]
+  b = np.array([f.numlist for f in filts])
+  a = np.array([f.denlist for f in filts])
+  num = sum(repeat(b[:, k].copy()) * z ** -k for k in range(3) if np.any(b[:, k] != 0))
+  den = 1 + sum(repeat(a[:, k].copy()) * z ** -k for k in (1, 2))
+  filt = num / den
+  y = np.array(list(filt(iter(x), zero=np.zeros(C))))
+  # each channel also through the scalar path: must be identical
+  for c in range(C):
+    ys = list(filts[c](list(x[:, c])))
+    assert ys == list(y[:, c]), "vector-valued idiom differs from scalar path"
+  return dict(C=C, N=N, b=[hx(r) for r in b.tolist()], a=[hx(r) for r in a.tolist()],
+              x=[hx(r) for r in x.tolist()], y=[hx(r) for r in y.tolist()])
+
+
+# --------------------------------------------------------------------------
+# 6. LPC
+# --------------------------------------------------------------------------
+def lpc_cases():
+  out = dict(acorr=[], levinson=[], kautocor=[])
+  for seq, lag in (([1, 2, 3, 4, 3, 4, 2], None), ([1, 2, 3, 4, 3, 4, 2], 9),
+                   ([2, 2, 0, 0, -1, -1, 0, 0, 1, 1], None)):
+    out["acorr"].append(dict(x=hx(seq), max_lag=lag, r=hx(acorr(seq, lag) if lag else acorr(seq))))
+  fr = noise(480, 4242)
+  out["acorr"].append(dict(x=hx(fr), max_lag=16, r=hx(acorr(fr, 16))))
+  for ac, order in (([12, 6, 0, -3, -6, -3, 0, 2, 4, 2], 3), ([1, 5, 3], None),
+                    ([1., .5, .25, .125], 5), (acorr(fr, 16), 16)):
+    f = levinson_durbin(ac, order) if order else levinson_durbin(ac)
+    out["levinson"].append(dict(ac=hx(ac), order=order, coefs=hx(f.numlist), error=hx(f.error)))
+  random.seed(31337)
+  res = resonator.z_exp(700 * Hz, 40 * Hz)
+  ar = list(res(noise(480 + 200, 5))) [200:]
+  frames = [fr, ar, [-1., 0., 1., 0.] * 4, noise(480, 6), [float(i % 7) - 3. for i in range(480)]]
+  for blk in frames:
+    for order in ((2, 16) if len(blk) > 16 else (2,)):
+      f = lpc.kautocor(blk, order)
+      out["kautocor"].append(dict(x=hx(blk), order=order, coefs=hx(f.numlist), error=hx(f.error)))
+  return out
+
+
+# --------------------------------------------------------------------------
+# 7. Stream.blocks
+# --------------------------------------------------------------------------
+def blocks_cases():
+  out = []
+  for n, size, hop, pad in ((10, 4, None, 0.), (10, 4, 2, 0.), (10, 4, 6, 0.), (7, 3, 3, -1.),
+                            (12, 4, 4, 0.), (5, 8, None, 9.), (9, 4, 1, 0.), (11, 5, 7, 0.5)):
+    data = [float(i) for i in range(n)]
+    kw = dict(size=size, padval=pad)
+    if hop is not None:
+      kw["hop"] = hop
+    blks = [list(b) for b in Stream(data).blocks(**kw)]
+    out.append(dict(n=n, size=size, hop=hop, padval=pad, blocks=blks))
+  return out
+
+
+if __name__ == "__main__":
+  print("audiolazy", al.__version__, "numpy", np.__version__)
+  dump("filters.json", filt_cases())
+  dump("lfilter_grid.json", lfilter_grid())
+  dump("containers.json", container_cases())
+  dump("designs.json", design_cases())
+  dump("auditory.json", auditory_cases())
+  dump("multichannel.json", multichannel_case())
+  dump("lpc.json", lpc_cases())
+  dump("blocks.json", blocks_cases())
