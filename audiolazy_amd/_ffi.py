@@ -1,0 +1,114 @@
+"""ctypes binding of libalzhip.so (C ABI declared in include/alz.h).
+
+There is no CPU execution path behind this module: if the HIP library is
+missing or fails to load, importing a compute entry point raises ImportError
+loudly instead of falling back to anything else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalzhip.so")
+
+# status codes (include/alz.h)
+OK = 0
+E_ARG, E_NONCAUSAL, E_ZERO_GAIN, E_PARCOR, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
+TIME_MAJOR, CHAN_MAJOR = 0, 1
+BANK_DIAGONAL, BANK_OUTER = 0, 1
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+
+# every symbol include/alz.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+  "alz_version": (_int, []),
+  "alz_last_error": (ctypes.c_char_p, []),
+  "alz_device_count": (_int, [_ip]),
+  "alz_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
+  "alz_free": (_int, [_int, _vp]),
+  "alz_memcpy_h2d": (_int, [_int, _vp, _vp, _u64]),
+  "alz_memcpy_d2h": (_int, [_int, _vp, _vp, _u64]),
+  "alz_device_sync": (_int, [_int]),
+  "alz_bank_create": (_int, [_i64, _i64, _int, _int, _ip, _ip, _dp, _dp, _int, ctypes.POINTER(_vp)]),
+  "alz_bank_destroy": (_int, [_vp]),
+  "alz_bank_channels": (_int, [_vp, ctypes.POINTER(_i64)]),
+  "alz_bank_reset": (_int, [_vp, ctypes.c_double]),
+  "alz_bank_set_state": (_int, [_vp, _dp, _dp]),
+  "alz_bank_get_state": (_int, [_vp, _dp, _dp]),
+  "alz_bank_process_dev": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _i64, _vp]),
+  "alz_bank_process_host": (_int, [_vp, _dp, _dp, _i64, _int, _i64, _i64]),
+  "alz_bank_sync": (_int, [_vp]),
+  "alz_bank_last_kernel": (ctypes.c_char_p, [_vp]),
+  "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
+  "alz_acorr_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
+}
+
+
+class ParCorError(ZeroDivisionError):
+  """Error when trying to find the partial correlation coefficients
+  (reference audiolazy/lazy_lpc.py:37-41)."""
+
+
+_lib = None
+
+
+def load():
+  """Load libalzhip.so and bind every declared symbol (no GPU needed for this)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+      "audiolazy_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+      "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+  try:
+    L = ctypes.CDLL(LIB_PATH)
+  except OSError as exc:  # e.g. no ROCm runtime on this machine
+    raise ImportError("audiolazy_amd: cannot load %s: %s" % (LIB_PATH, exc))
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(L, name)  # AttributeError here == header/library mismatch
+    fn.restype = res
+    fn.argtypes = args
+  _lib = L
+  return L
+
+
+def last_error():
+  msg = load().alz_last_error()
+  return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+  """Map a C status to the exception type the reference raises."""
+  if rc == OK:
+    return
+  msg = last_error()
+  if rc == E_ZERO_GAIN:
+    raise ZeroDivisionError(msg or "Invalid filter gain")   # lazy_filters.py:177-178
+  if rc == E_NONCAUSAL:
+    raise ValueError(msg or "Non-causal filter")             # lazy_filters.py:165-168
+  if rc == E_PARCOR:
+    raise ParCorError(msg or "Can't find next PARCOR coefficient")  # lazy_lpc.py:132-133
+  if rc == E_ARG:
+    raise ValueError(msg)
+  if rc == E_NOMEM:
+    raise MemoryError(msg)
+  if rc == E_UNSUPPORTED:
+    raise NotImplementedError(msg)
+  raise RuntimeError("libalzhip: %s (status %d)" % (msg, rc))
+
+
+def device_count():
+  n = _int(0)
+  rc = load().alz_device_count(ctypes.byref(n))
+  return n.value if rc == OK else 0
+
+
+def require_gpu():
+  if device_count() < 1:
+    raise RuntimeError("audiolazy_amd: no HIP device visible; this engine has no CPU path (%s)"
+                       % last_error())

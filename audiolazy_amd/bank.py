@@ -1,0 +1,302 @@
+"""FilterBank: the host side of the blocked stream-filter engine.
+
+Mirrors the reference's callable protocol -- "a filter is any callable that
+receives an iterable as input and returns a Stream" with the signature
+``__call__(seq, memory=None, zero=0.)`` (reference audiolazy/lazy_filters.py
+:141, :840, :975-978) -- for a whole bank of independent channels, and adds an
+array-in / array-out ``process`` for blocks already held as arrays.
+
+Design stays on the host in float64 (coefficients come from any object with
+``numlist`` / ``denlist``, reference lazy_filters.py:55-67, or from raw arrays);
+execution is always libalzhip.so (HIP, gfx950).  No CPU execution path exists
+here: without the library or a GPU the calls raise.
+"""
+import ctypes
+import itertools
+
+import numpy as np
+
+from . import _ffi
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+LAYOUTS = {"time": _ffi.TIME_MAJOR, "chan": _ffi.CHAN_MAJOR,
+           _ffi.TIME_MAJOR: _ffi.TIME_MAJOR, _ffi.CHAN_MAJOR: _ffi.CHAN_MAJOR}
+
+
+def _is_torch(x):
+  return type(x).__module__.startswith("torch")
+
+
+def _coef_lists(filt):
+  """(numlist, denlist) of one section as float lists.
+
+  Raises what the reference raises: ValueError("Non-causal filter") comes out
+  of the filter's own numlist/denlist properties (lazy_filters.py:55-67);
+  Stream-valued (time-varying) coefficients are outside the engine's gate.
+  """
+  if isinstance(filt, (tuple, list)) and len(filt) == 2 and not hasattr(filt, "numlist"):
+    b, a = filt
+  else:
+    b, a = filt.numlist, filt.denlist
+  b, a = list(b), list(a)
+  for v in itertools.chain(b, a):
+    if hasattr(v, "__iter__") and not isinstance(v, np.ndarray):
+      raise NotImplementedError("time-varying (Stream) coefficients are outside the engine's gate")
+  return b, a
+
+
+def sections_of(filt):
+  """Flatten a filter object into its cascade sections [(b, a), ...].
+
+  A CascadeFilter-like object (a list of filters, reference lazy_filters.py
+  :970-1021) contributes one section per item, in call order (:988-990).
+  """
+  if hasattr(filt, "numlist") or (isinstance(filt, tuple) and len(filt) == 2):
+    return [_coef_lists(filt)]
+  if isinstance(filt, (list, tuple)):
+    out = []
+    for f in filt:
+      out.extend(sections_of(f))
+    return out
+  raise TypeError("cannot read filter coefficients from %r" % (type(filt),))
+
+
+def memory_to_hist(memory, lm, zero=0.0):
+  """memory -> [m1 .. m_lm], the reference's rule (lazy_filters.py:185-195).
+
+  None -> [zero]*lm; callable -> memory(lm); iterable -> its first lm items,
+  LEFT-padded with ``zero`` when short (zero_pad's second positional argument
+  is ``left``, lazy_misc.py:132 -- a quirk reproduced on purpose).
+  """
+  if memory is None:
+    return [zero] * lm
+  if not hasattr(memory, "__iter__"):
+    memory = memory(lm)
+  out = list(itertools.islice(iter(memory), lm)) if lm > 0 else []
+  if len(out) < lm:
+    out = [zero] * (lm - len(out)) + out
+  return out
+
+
+class FilterBank(object):
+  """``channels`` independent streams through per-channel cascades.
+
+  Parameters
+  ----------
+  sections :
+    list of (b, a) per cascade section; ``b`` is [nb] (shared) or
+    [n_sets, nb], ``a`` likewise -- the reference's numlist / denlist.
+  n_inputs :
+    number of input channels.  ``mode="diagonal"``: channel c filters input c
+    with coefficient set c (or the single shared set).  ``mode="outer"``:
+    every coefficient set runs on every input, channel = set * n_inputs +
+    input (a filterbank such as the gammatone bank).
+  """
+
+  def __init__(self, sections, n_inputs=None, mode="diagonal", device=0):
+    L = _ffi.load()
+    secs = []
+    n_sets = 1
+    for b, a in sections:
+      b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+      a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+      if b.shape[-1] == 0:
+        b = np.zeros(b.shape[:-1] + (1,))
+      if a.shape[-1] == 0:
+        raise ZeroDivisionError("Invalid filter gain")  # empty denominator == 0
+      for arr in (b, a):
+        if arr.ndim == 2 and arr.shape[0] != 1:
+          if n_sets not in (1, arr.shape[0]):
+            raise ValueError("sections disagree on the number of coefficient sets")
+          n_sets = arr.shape[0]
+      secs.append((b, a))
+    if mode not in ("diagonal", "outer"):
+      raise ValueError("mode must be 'diagonal' or 'outer'")
+    if n_inputs is None:
+      n_inputs = n_sets if mode == "diagonal" else 1
+    if mode == "diagonal" and n_sets not in (1, n_inputs):
+      raise ValueError("diagonal bank: %d coefficient sets for %d inputs" % (n_sets, n_inputs))
+    self.n_sets, self.n_inputs, self.mode, self.device = int(n_sets), int(n_inputs), mode, int(device)
+    self.channels = self.n_inputs if mode == "diagonal" else self.n_sets * self.n_inputs
+    self.nb = [s[0].shape[-1] for s in secs]
+    self.na = [s[1].shape[-1] for s in secs]
+    self.thx = sum(n - 1 for n in self.nb)
+    self.thy = sum(n - 1 for n in self.na)
+
+    def rows(arr):
+      arr = arr.reshape(1, -1) if arr.ndim == 1 else arr
+      return np.broadcast_to(arr, (self.n_sets, arr.shape[1]))
+
+    self.b = np.ascontiguousarray(np.concatenate([rows(s[0]) for s in secs], axis=1))
+    self.a = np.ascontiguousarray(np.concatenate([rows(s[1]) for s in secs], axis=1))
+    nb = (ctypes.c_int * len(secs))(*self.nb)
+    na = (ctypes.c_int * len(secs))(*self.na)
+    handle = ctypes.c_void_p()
+    _ffi.check(L.alz_bank_create(self.n_sets, self.n_inputs,
+                                 _ffi.BANK_DIAGONAL if mode == "diagonal" else _ffi.BANK_OUTER,
+                                 len(secs), nb, na, self.b.ctypes.data_as(_dp),
+                                 self.a.ctypes.data_as(_dp), self.device, ctypes.byref(handle)))
+    self._h = handle
+    self._L = L
+
+  # -- construction helpers ------------------------------------------------
+  @classmethod
+  def from_filters(cls, filters, **kwargs):
+    """One channel per filter object (ZFilter / CascadeFilter duck-typed):
+    all must share the section shapes; coefficients become per-channel sets."""
+    per = [sections_of(f) for f in filters]
+    shapes = [[(len(b), len(a)) for b, a in p] for p in per]
+    n_sec = len(per[0])
+    if any(len(p) != n_sec for p in per):
+      raise ValueError("filters disagree on the number of cascade sections")
+    secs = []
+    for s in range(n_sec):
+      nb = max(sh[s][0] for sh in shapes)
+      na = max(sh[s][1] for sh in shapes)
+      # trailing zero taps are absent from the reference's expression anyway
+      b = np.zeros((len(per), max(nb, 1)))
+      a = np.zeros((len(per), na))
+      for i, p in enumerate(per):
+        b[i, :len(p[s][0])] = p[s][0]
+        a[i, :len(p[s][1])] = p[s][1]
+      secs.append((b, a))
+    return cls(secs, **kwargs)
+
+  def __del__(self):
+    h, self._h = getattr(self, "_h", None), None
+    if h:
+      try:
+        self._L.alz_bank_destroy(h)
+      except Exception:
+        pass
+
+  # -- state ---------------------------------------------------------------
+  def reset(self, memory=None, zero=0.0):
+    """Start a new stream: the reference's ``memory`` / ``zero`` call arguments
+    (lazy_filters.py:149-157, 185-195, 243-250), forwarded unchanged to every
+    cascade stage like CascadeFilter does (:989)."""
+    zero_arr = np.asarray(zero, dtype=np.float64)
+    if memory is None and zero_arr.ndim == 0:
+      _ffi.check(self._L.alz_bank_reset(self._h, float(zero)))
+      return
+    _ffi.check(self._L.alz_bank_reset(self._h, float(zero_arr.ravel()[0]) if zero_arr.size else 0.0))
+    C = self.channels
+    zc = np.broadcast_to(zero_arr, (C,)) if zero_arr.ndim else np.full(C, float(zero_arr))
+    xh = np.repeat(zc[:, None], max(self.thx, 1), axis=1).copy()
+    yh = np.empty((C, max(self.thy, 1)))
+    off = 0
+    if callable(memory) and not hasattr(memory, "__iter__"):
+      mem_items = None
+    else:
+      mem_items = None if memory is None else list(itertools.islice(iter(memory), max(self.na) - 1))
+    for na in self.na:
+      lm = na - 1
+      if memory is not None and mem_items is None:
+        hist = memory_to_hist(memory, lm, zero)   # callable: called once per stage
+      else:
+        hist = memory_to_hist(mem_items, lm, zero)
+      for k, item in enumerate(hist):
+        yh[:, off + k] = np.broadcast_to(np.asarray(item, dtype=np.float64), (C,))
+      off += lm
+    self.set_state(xh, yh)
+
+  def set_state(self, xh, yh):
+    xh = np.ascontiguousarray(xh, dtype=np.float64)
+    yh = np.ascontiguousarray(yh, dtype=np.float64)
+    if xh.shape != (self.channels, max(self.thx, 1)) and xh.shape != (self.channels, self.thx):
+      raise ValueError("xh must be [channels, sum(nb-1)]")
+    if yh.shape != (self.channels, max(self.thy, 1)) and yh.shape != (self.channels, self.thy):
+      raise ValueError("yh must be [channels, sum(na-1)]")
+    _ffi.check(self._L.alz_bank_set_state(self._h, xh.ctypes.data_as(_dp), yh.ctypes.data_as(_dp)))
+
+  def get_state(self):
+    xh = np.zeros((self.channels, max(self.thx, 1)))
+    yh = np.zeros((self.channels, max(self.thy, 1)))
+    _ffi.check(self._L.alz_bank_get_state(self._h, xh.ctypes.data_as(_dp), yh.ctypes.data_as(_dp)))
+    return xh[:, :self.thx], yh[:, :self.thy]
+
+  @property
+  def last_kernel(self):
+    return self._L.alz_bank_last_kernel(self._h).decode()
+
+  # -- execution -----------------------------------------------------------
+  def process(self, x, layout="time", out=None):
+    """Filter one block, continuing from the current state.
+
+    x : [N, n_inputs] (layout="time") or [n_inputs, N] (layout="chan"), float64;
+        a NumPy array (staged through the device) or a torch CUDA tensor
+        (processed in place in HBM on the current torch stream).
+    Returns an array / tensor of [N, channels] or [channels, N].
+    """
+    lay = LAYOUTS[layout]
+    if _is_torch(x):
+      return self._process_torch(x, lay, out)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.ndim == 1:
+      x = x.reshape(-1, 1) if lay == _ffi.TIME_MAJOR else x.reshape(1, -1)
+    n, cin = (x.shape if lay == _ffi.TIME_MAJOR else x.shape[::-1])
+    if cin != self.n_inputs:
+      raise ValueError("block has %d input channels, bank expects %d" % (cin, self.n_inputs))
+    shape = (n, self.channels) if lay == _ffi.TIME_MAJOR else (self.channels, n)
+    y = np.empty(shape) if out is None else out
+    if n == 0:
+      return y
+    ldx = self.n_inputs if lay == _ffi.TIME_MAJOR else n
+    ldy = self.channels if lay == _ffi.TIME_MAJOR else n
+    _ffi.check(self._L.alz_bank_process_host(self._h, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp),
+                                             n, lay, ldx, ldy))
+    return y
+
+  def _process_torch(self, x, lay, out):
+    import torch
+    if not x.is_cuda or x.dtype != torch.float64 or not x.is_contiguous():
+      raise ValueError("torch input must be a contiguous float64 CUDA tensor")
+    if x.dim() != 2:
+      raise ValueError("torch input must be 2-D")
+    n, cin = (tuple(x.shape) if lay == _ffi.TIME_MAJOR else tuple(x.shape)[::-1])
+    if cin != self.n_inputs:
+      raise ValueError("block has %d input channels, bank expects %d" % (cin, self.n_inputs))
+    shape = (n, self.channels) if lay == _ffi.TIME_MAJOR else (self.channels, n)
+    y = torch.empty(shape, dtype=torch.float64, device=x.device) if out is None else out
+    if n == 0:
+      return y
+    ldx = self.n_inputs if lay == _ffi.TIME_MAJOR else n
+    ldy = self.channels if lay == _ffi.TIME_MAJOR else n
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _ffi.check(self._L.alz_bank_process_dev(self._h, x.data_ptr(), y.data_ptr(), n, lay, ldx, ldy,
+                                            ctypes.c_void_p(stream)))
+    return y
+
+  def sync(self):
+    _ffi.check(self._L.alz_bank_sync(self._h))
+
+  def __call__(self, seq, memory=None, zero=0., block=4096):
+    """The reference's filter call: any iterable in, a Stream out.
+
+    Items of ``seq`` are scalars (one input channel) or rows of ``n_inputs``
+    values (the reference's vector-valued-sample idiom); output items are
+    scalars when the bank has one channel, rows of ``channels`` otherwise.
+    The input is pulled ``block`` items at a time (lazy per block, not per
+    sample).
+    """
+    from .stream import Stream
+    self.reset(memory=memory, zero=zero)
+    scalar_out = self.channels == 1
+
+    def gen():
+      it = iter(seq)
+      while True:
+        chunk = list(itertools.islice(it, block))
+        if not chunk:
+          return
+        x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), self.n_inputs)
+        y = self.process(x, layout="time")
+        if scalar_out:
+          for v in y[:, 0].tolist():
+            yield v
+        else:
+          for row in y:
+            yield row
+    return Stream(gen())

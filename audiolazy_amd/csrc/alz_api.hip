@@ -1,0 +1,419 @@
+// alz_api.hip -- the C ABI of libalzhip.so (see include/alz.h): handles, state,
+// host/device block entry points.  No CPU compute path exists in this library:
+// every process call launches HIP kernels or fails.
+#include <string.h>
+
+#include <new>
+
+#include "alz_common.h"
+
+namespace alz {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+}  // namespace alz
+
+using alz::fail;
+
+struct alz_bank {
+  int device = 0;
+  int64_t n_sets = 0, n_inputs = 0, channels = 0;
+  int mode = 0;
+  int n_sections = 0;
+  std::vector<int> nb, na;
+  std::vector<int64_t> hx_off, hy_off;  // per-section offsets into the host state rows
+  int64_t thx = 0, thy = 0;             // sum(nb-1), sum(na-1)
+  // device arrays, one allocation each
+  double *b_dev = nullptr, *a_dev = nullptr;
+  double *xh_dev = nullptr, *yh_dev = nullptr;  // 2x capacity (k_generic's new-state copy)
+  std::vector<alz::SectionDev> sec;
+  double zero = 0.0;
+  // staging for process_host and for out-of-place generic sections
+  double *stage_x = nullptr, *stage_y = nullptr, *scratch = nullptr;
+  uint64_t stage_x_bytes = 0, stage_y_bytes = 0, scratch_bytes = 0;
+  const char *last_kernel = "";
+  std::string last_kernels;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int grow(double **ptr, uint64_t *have, uint64_t need) {
+  if (*have >= need) return ALZ_OK;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr;
+  *have = 0;
+  if (hipMalloc((void **)ptr, need) != hipSuccess)
+    return fail(ALZ_E_NOMEM, "hipMalloc failed for " + std::to_string(need) + " bytes");
+  *have = need;
+  return ALZ_OK;
+}
+
+// host [rows = channels][cols] (row-major)  <->  device [cols][channels]
+void transpose_to_dev_order(const double *src, std::vector<double> &dst, int64_t rows, int64_t cols) {
+  dst.resize((size_t)(rows * cols));
+  for (int64_t r = 0; r < rows; ++r)
+    for (int64_t k = 0; k < cols; ++k) dst[(size_t)(k * rows + r)] = src[r * cols + k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int alz_version(void) { return ALZ_VERSION; }
+
+const char *alz_last_error(void) { return alz::g_err.c_str(); }
+
+int alz_device_count(int *count) {
+  if (!count) return fail(ALZ_E_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(ALZ_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return ALZ_OK;
+}
+
+int alz_malloc(int device, uint64_t bytes, void **dev_ptr) {
+  if (!dev_ptr) return fail(ALZ_E_ARG, "dev_ptr is NULL");
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  if (hipMalloc(dev_ptr, bytes ? bytes : 8) != hipSuccess) return fail(ALZ_E_NOMEM, "hipMalloc failed");
+  return ALZ_OK;
+}
+
+int alz_free(int device, void *dev_ptr) {
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  ALZ_HIP_CHECK(hipFree(dev_ptr));
+  return ALZ_OK;
+}
+
+int alz_memcpy_h2d(int device, void *dst_dev, const void *src_host, uint64_t bytes) {
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  ALZ_HIP_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return ALZ_OK;
+}
+
+int alz_memcpy_d2h(int device, void *dst_host, const void *src_dev, uint64_t bytes) {
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  ALZ_HIP_CHECK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return ALZ_OK;
+}
+
+int alz_device_sync(int device) {
+  DeviceGuard g(device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  ALZ_HIP_CHECK(hipDeviceSynchronize());
+  return ALZ_OK;
+}
+
+int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, const int *nb,
+                    const int *na, const double *b_host, const double *a_host, int device,
+                    alz_bank_t **out) {
+  if (!out) return fail(ALZ_E_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_sets < 1 || n_inputs < 1 || n_sections < 1 || !nb || !na || !b_host || !a_host)
+    return fail(ALZ_E_ARG, "alz_bank_create: bad sizes or NULL arrays");
+  if (mode != ALZ_BANK_DIAGONAL && mode != ALZ_BANK_OUTER) return fail(ALZ_E_ARG, "bad bank mode");
+  if (mode == ALZ_BANK_DIAGONAL && n_sets != n_inputs && n_sets != 1)
+    return fail(ALZ_E_ARG, "DIAGONAL bank needs n_sets == n_inputs (or 1 shared set)");
+  int64_t tb = 0, ta = 0;
+  for (int s = 0; s < n_sections; ++s) {
+    if (nb[s] < 1 || na[s] < 1) return fail(ALZ_E_ARG, "every section needs nb >= 1 and na >= 1");
+    tb += nb[s];
+    ta += na[s];
+  }
+  // a0 == 0 -> ZeroDivisionError("Invalid filter gain"), lazy_filters.py:177-178
+  {
+    int64_t off = 0;
+    for (int s = 0; s < n_sections; ++s) {
+      for (int64_t q = 0; q < n_sets; ++q)
+        if (a_host[q * ta + off] == 0.0) return fail(ALZ_E_ZERO_GAIN, "Invalid filter gain");
+      off += na[s];
+    }
+  }
+
+  alz_bank *h = new (std::nothrow) alz_bank();
+  if (!h) return fail(ALZ_E_NOMEM, "out of host memory");
+  h->device = device;
+  h->n_sets = n_sets;
+  h->n_inputs = n_inputs;
+  h->mode = mode;
+  h->channels = (mode == ALZ_BANK_OUTER) ? n_sets * n_inputs : n_inputs;
+  h->n_sections = n_sections;
+  h->nb.assign(nb, nb + n_sections);
+  h->na.assign(na, na + n_sections);
+  for (int s = 0; s < n_sections; ++s) {
+    h->hx_off.push_back(h->thx);
+    h->hy_off.push_back(h->thy);
+    h->thx += nb[s] - 1;
+    h->thy += na[s] - 1;
+  }
+
+  DeviceGuard g(device);
+  if (!g.ok) {
+    delete h;
+    return fail(ALZ_E_HIP, "hipSetDevice failed");
+  }
+  // coefficients, tap-major on the device: section s, tap k, set q at
+  //   b_dev[(boff(s) + k) * n_sets + q]
+  std::vector<double> bt, at;
+  transpose_to_dev_order(b_host, bt, n_sets, tb);
+  transpose_to_dev_order(a_host, at, n_sets, ta);
+  const uint64_t xs = (uint64_t)(h->thx > 0 ? h->thx : 1) * h->channels * 8 * 2;
+  const uint64_t ys = (uint64_t)(h->thy > 0 ? h->thy : 1) * h->channels * 8 * 2;
+  if (hipMalloc((void **)&h->b_dev, bt.size() * 8) != hipSuccess ||
+      hipMalloc((void **)&h->a_dev, at.size() * 8) != hipSuccess ||
+      hipMalloc((void **)&h->xh_dev, xs) != hipSuccess ||
+      hipMalloc((void **)&h->yh_dev, ys) != hipSuccess) {
+    alz_bank_destroy(h);
+    return fail(ALZ_E_NOMEM, "hipMalloc failed while creating the bank");
+  }
+  if (hipMemcpy(h->b_dev, bt.data(), bt.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->a_dev, at.data(), at.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(h->xh_dev, 0, xs) != hipSuccess || hipMemset(h->yh_dev, 0, ys) != hipSuccess) {
+    alz_bank_destroy(h);
+    return fail(ALZ_E_HIP, "coefficient upload failed");
+  }
+
+  // Section descriptors.  Each section's state occupies a [taps-1][channels]
+  // slab (x2 for k_generic's new-state copy), slabs laid out back to back.
+  int64_t boff = 0, aoff = 0;
+  for (int s = 0; s < n_sections; ++s) {
+    alz::SectionDev d;
+    d.nb = nb[s];
+    d.na = na[s];
+    d.b = h->b_dev + boff * n_sets;
+    d.a = h->a_dev + aoff * n_sets;
+    d.xh = h->xh_dev + 2 * h->hx_off[s] * h->channels;
+    d.yh = h->yh_dev + 2 * h->hy_off[s] * h->channels;
+    d.present_b = d.present_a = 0;
+    d.uniform = true;
+    d.any_div = false;
+    d.shared_sets = n_sets == 1;
+    for (int k = 0; k < nb[s]; ++k) {
+      int64_t nz = 0;
+      for (int64_t q = 0; q < n_sets; ++q) nz += b_host[q * tb + boff + k] != 0.0;
+      if (nz && k < 32) d.present_b |= 1u << k;
+      if (nz && nz != n_sets) d.uniform = false;
+      if (nz && k >= 32) d.present_b |= 0x80000000u;
+    }
+    for (int k = 1; k < na[s]; ++k) {
+      int64_t nz = 0;
+      for (int64_t q = 0; q < n_sets; ++q) nz += a_host[q * ta + aoff + k] != 0.0;
+      if (nz && k <= 32) d.present_a |= 1u << (k - 1);
+      if (nz && nz != n_sets) d.uniform = false;
+      if (nz && k > 32) d.present_a |= 0x80000000u;
+    }
+    for (int64_t q = 0; q < n_sets; ++q) d.any_div |= a_host[q * ta + aoff] != 1.0;
+    h->sec.push_back(d);
+    boff += nb[s];
+    aoff += na[s];
+  }
+  *out = h;
+  return ALZ_OK;
+}
+
+int alz_bank_destroy(alz_bank_t *h) {
+  if (!h) return ALZ_OK;
+  DeviceGuard g(h->device);
+  if (h->b_dev) (void)hipFree(h->b_dev);
+  if (h->a_dev) (void)hipFree(h->a_dev);
+  if (h->xh_dev) (void)hipFree(h->xh_dev);
+  if (h->yh_dev) (void)hipFree(h->yh_dev);
+  if (h->stage_x) (void)hipFree(h->stage_x);
+  if (h->stage_y) (void)hipFree(h->stage_y);
+  if (h->scratch) (void)hipFree(h->scratch);
+  delete h;
+  return ALZ_OK;
+}
+
+int alz_bank_channels(const alz_bank_t *h, int64_t *channels) {
+  if (!h || !channels) return fail(ALZ_E_ARG, "NULL argument");
+  *channels = h->channels;
+  return ALZ_OK;
+}
+
+static int put_state(alz_bank *h, const double *xh_host, const double *yh_host) {
+  // host rows [channels][thx] -> per-section device slabs [nb-1][channels]
+  const int64_t C = h->channels;
+  std::vector<double> tmp;
+  for (int s = 0; s < h->n_sections; ++s) {
+    const int64_t kx = h->nb[s] - 1, ky = h->na[s] - 1;
+    if (kx > 0 && xh_host) {
+      tmp.resize((size_t)(kx * C));
+      for (int64_t c = 0; c < C; ++c)
+        for (int64_t k = 0; k < kx; ++k) tmp[(size_t)(k * C + c)] = xh_host[c * h->thx + h->hx_off[s] + k];
+      ALZ_HIP_CHECK(hipMemcpy(h->sec[s].xh, tmp.data(), tmp.size() * 8, hipMemcpyHostToDevice));
+    }
+    if (ky > 0 && yh_host) {
+      tmp.resize((size_t)(ky * C));
+      for (int64_t c = 0; c < C; ++c)
+        for (int64_t k = 0; k < ky; ++k) tmp[(size_t)(k * C + c)] = yh_host[c * h->thy + h->hy_off[s] + k];
+      ALZ_HIP_CHECK(hipMemcpy(h->sec[s].yh, tmp.data(), tmp.size() * 8, hipMemcpyHostToDevice));
+    }
+  }
+  return ALZ_OK;
+}
+
+int alz_bank_reset(alz_bank_t *h, double zero) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  DeviceGuard g(h->device);
+  ALZ_HIP_CHECK(hipDeviceSynchronize());
+  h->zero = zero;
+  std::vector<double> xh((size_t)(h->channels * (h->thx > 0 ? h->thx : 1)), zero);
+  std::vector<double> yh((size_t)(h->channels * (h->thy > 0 ? h->thy : 1)), zero);
+  return put_state(h, xh.data(), yh.data());
+}
+
+int alz_bank_set_state(alz_bank_t *h, const double *xh_host, const double *yh_host) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  DeviceGuard g(h->device);
+  ALZ_HIP_CHECK(hipDeviceSynchronize());
+  return put_state(h, xh_host, yh_host);
+}
+
+int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  DeviceGuard g(h->device);
+  ALZ_HIP_CHECK(hipDeviceSynchronize());
+  const int64_t C = h->channels;
+  std::vector<double> tmp;
+  for (int s = 0; s < h->n_sections; ++s) {
+    const int64_t kx = h->nb[s] - 1, ky = h->na[s] - 1;
+    if (kx > 0 && xh_host) {
+      tmp.resize((size_t)(kx * C));
+      ALZ_HIP_CHECK(hipMemcpy(tmp.data(), h->sec[s].xh, tmp.size() * 8, hipMemcpyDeviceToHost));
+      for (int64_t c = 0; c < C; ++c)
+        for (int64_t k = 0; k < kx; ++k) xh_host[c * h->thx + h->hx_off[s] + k] = tmp[(size_t)(k * C + c)];
+    }
+    if (ky > 0 && yh_host) {
+      tmp.resize((size_t)(ky * C));
+      ALZ_HIP_CHECK(hipMemcpy(tmp.data(), h->sec[s].yh, tmp.size() * 8, hipMemcpyDeviceToHost));
+      for (int64_t c = 0; c < C; ++c)
+        for (int64_t k = 0; k < ky; ++k) yh_host[c * h->thy + h->hy_off[s] + k] = tmp[(size_t)(k * C + c)];
+    }
+  }
+  return ALZ_OK;
+}
+
+int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int64_t n, int layout,
+                         int64_t ldx, int64_t ldy, void *stream) {
+  if (!h || !x_dev || !y_dev) return fail(ALZ_E_ARG, "NULL argument");
+  if (n < 0) return fail(ALZ_E_ARG, "negative block length");
+  if (layout != ALZ_TIME_MAJOR && layout != ALZ_CHAN_MAJOR) return fail(ALZ_E_ARG, "bad layout");
+  if (layout == ALZ_TIME_MAJOR && (ldx < h->n_inputs || ldy < h->channels))
+    return fail(ALZ_E_ARG, "TIME_MAJOR leading dimension smaller than the channel count");
+  if (layout == ALZ_CHAN_MAJOR && (ldx < n || ldy < n))
+    return fail(ALZ_E_ARG, "CHAN_MAJOR leading dimension smaller than the block length");
+  if (x_dev == y_dev && (h->mode != ALZ_BANK_DIAGONAL || ldx != ldy))
+    return fail(ALZ_E_ARG, "in-place processing needs DIAGONAL mode and ldx == ldy");
+  h->last_kernels.clear();
+  h->last_kernel = "";
+  if (n == 0) return ALZ_OK;
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+
+  alz::BlockIO io;
+  io.n = n;
+  io.channels = h->channels;
+  io.n_inputs = h->n_inputs;
+  io.n_sets = h->n_sets;
+  io.mode = h->mode;
+  io.zero = h->zero;
+  const int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
+  const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
+  // extent of y in elements, for the out-of-place copy some sections need
+  const uint64_t y_extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
+                                                      : (uint64_t)((h->channels - 1) * ldy + n);
+
+  for (int s = 0; s < h->n_sections; ++s) {
+    const alz::SectionDev &sec = h->sec[s];
+    const bool generic = !(sec.nb <= 16 && sec.na <= 9);
+    io.y = y_dev;
+    io.syn = syn;
+    io.syc = syc;
+    if (s == 0) {
+      io.x = x_dev;
+      io.sxn = sxn;
+      io.sxc = sxc;
+      io.map_input = h->mode == ALZ_BANK_OUTER;
+    } else {
+      io.x = y_dev;
+      io.sxn = syn;
+      io.sxc = syc;
+      io.map_input = 0;
+    }
+    if (generic && io.x == io.y) {
+      // k_generic reads its history from the block, so it cannot overwrite it
+      int rc = grow(&h->scratch, &h->scratch_bytes, y_extent * 8);
+      if (rc) return rc;
+      ALZ_HIP_CHECK(hipMemcpyAsync(h->scratch, y_dev, y_extent * 8, hipMemcpyDeviceToDevice, st));
+      io.x = h->scratch;
+    }
+    const char *name = "";
+    int rc = alz::launch_section(sec, io, st, &name);
+    if (rc) return rc;
+    h->last_kernel = name;
+    if (!h->last_kernels.empty()) h->last_kernels += "+";
+    h->last_kernels += name;
+  }
+  return ALZ_OK;
+}
+
+int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, int64_t n, int layout,
+                          int64_t ldx, int64_t ldy) {
+  if (!h || !x_host || !y_host) return fail(ALZ_E_ARG, "NULL argument");
+  if (n <= 0) return n == 0 ? ALZ_OK : fail(ALZ_E_ARG, "negative block length");
+  if (layout != ALZ_TIME_MAJOR && layout != ALZ_CHAN_MAJOR) return fail(ALZ_E_ARG, "bad layout");
+  DeviceGuard g(h->device);
+  if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
+  const uint64_t xe = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldx + h->n_inputs)
+                                               : (uint64_t)((h->n_inputs - 1) * ldx + n);
+  const uint64_t ye = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
+                                               : (uint64_t)((h->channels - 1) * ldy + n);
+  int rc = grow(&h->stage_x, &h->stage_x_bytes, xe * 8);
+  if (rc) return rc;
+  rc = grow(&h->stage_y, &h->stage_y_bytes, ye * 8);
+  if (rc) return rc;
+  ALZ_HIP_CHECK(hipMemcpy(h->stage_x, x_host, xe * 8, hipMemcpyHostToDevice));
+  rc = alz_bank_process_dev(h, h->stage_x, h->stage_y, n, layout, ldx, ldy, nullptr);
+  if (rc) return rc;
+  ALZ_HIP_CHECK(hipStreamSynchronize(nullptr));
+  ALZ_HIP_CHECK(hipMemcpy(y_host, h->stage_y, ye * 8, hipMemcpyDeviceToHost));
+  return ALZ_OK;
+}
+
+int alz_bank_sync(alz_bank_t *h) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  DeviceGuard g(h->device);
+  ALZ_HIP_CHECK(hipDeviceSynchronize());
+  return ALZ_OK;
+}
+
+const char *alz_bank_last_kernel(const alz_bank_t *h) { return h ? h->last_kernels.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// alz_common.h -- shared declarations of libalzhip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/alz.h"
+
+namespace alz {
+
+// thread-local last-error message (alz_last_error)
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define ALZ_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess)                                                               \
+      return ::alz::fail(ALZ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// One cascaded section as the kernels see it.  Device arrays are tap-major so
+// that lane == channel reads are coalesced:
+//   b[k * n_sets + set], a[k * n_sets + set]
+//   xh[k * channels + c] = input  of this section at time -1-k   (k < nb-1)
+//   yh[k * channels + c] = output of this section at time -1-k   (k < na-1)
+struct SectionDev {
+  int nb, na;
+  const double *b, *a;
+  double *xh, *yh;
+  unsigned present_b;  // bit k set: b_k != 0 for at least one set
+  unsigned present_a;  // bit k-1 set: a_k != 0 for at least one set (k >= 1)
+  bool uniform;        // every set has the same zero pattern
+  bool any_div;        // some a_0 != 1
+  bool shared_sets;    // n_sets == 1
+};
+
+// Block description handed to the launchers.
+struct BlockIO {
+  const double *x;
+  double *y;
+  int64_t n;          // samples per channel
+  int64_t sxn, sxc;   // x element strides (time, channel)
+  int64_t syn, syc;   // y element strides
+  int64_t channels;   // output channels
+  int64_t n_inputs;   // input channels
+  int64_t n_sets;     // coefficient sets
+  int mode;           // ALZ_BANK_DIAGONAL / ALZ_BANK_OUTER
+  int map_input;      // OUTER mode: this launch reads the n_inputs input channels
+  double zero;        // what an all-zero section yields (lazy_filters.py:227-231)
+};
+
+// alz_iir.hip
+int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
+                   const char **kernel_name);
+
+}  // namespace alz

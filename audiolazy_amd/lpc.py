@@ -1,0 +1,94 @@
+"""Batched LPC by the autocorrelation method on the GPU.
+
+Host mirror of the reference's ``acorr`` (audiolazy/lazy_analysis.py:277-312),
+``levinson_durbin`` (audiolazy/lazy_lpc.py:52-136) and ``lpc.kautocor``
+(audiolazy/lazy_lpc.py:229-272) for many frames at once; frames are what
+``Stream.blocks(size=frame_len, hop=hop)`` would yield from one signal.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import ParCorError  # noqa: F401
+
+
+class _DevBuf(object):
+  """Device allocation owned through the C ABI (no torch needed)."""
+
+  def __init__(self, nbytes, device=0):
+    self.device, self.nbytes = device, int(nbytes)
+    self.ptr = ctypes.c_void_p()
+    _ffi.check(_ffi.load().alz_malloc(device, max(self.nbytes, 8), ctypes.byref(self.ptr)))
+
+  def upload(self, arr):
+    arr = np.ascontiguousarray(arr)
+    _ffi.check(_ffi.load().alz_memcpy_h2d(self.device, self.ptr, arr.ctypes.data_as(ctypes.c_void_p),
+                                          arr.nbytes))
+    return self
+
+  def download(self, shape, dtype):
+    out = np.empty(shape, dtype=dtype)
+    _ffi.check(_ffi.load().alz_memcpy_d2h(self.device, out.ctypes.data_as(ctypes.c_void_p), self.ptr,
+                                          out.nbytes))
+    return out
+
+  def __del__(self):
+    p, self.ptr = getattr(self, "ptr", None), None
+    if p:
+      try:
+        _ffi.load().alz_free(self.device, p)
+      except Exception:
+        pass
+
+
+def _frame_count(n_samples, frame_len, hop):
+  return 0 if n_samples < frame_len else (n_samples - frame_len) // hop + 1
+
+
+def kautocor_frames(sig, frame_len, order, hop=None, device=0):
+  """lpc.kautocor on every full frame of ``sig``.
+
+  sig : 1-D float64 signal (NumPy) or a [F, frame_len] array of frames, or a
+        1-D float64 torch CUDA tensor (results are then CUDA tensors).
+  Returns (coefs [F, order+1], error [F], status [F]); status is 0 or
+  ``_ffi.E_PARCOR`` where the reference would raise ParCorError
+  (lazy_lpc.py:132-133).
+  """
+  L = _ffi.load()
+  hop = frame_len if hop is None else hop
+  if type(sig).__module__.startswith("torch"):
+    import torch
+    flat = sig.reshape(-1)
+    F = _frame_count(flat.numel(), frame_len, hop)
+    coefs = torch.empty((F, order + 1), dtype=torch.float64, device=sig.device)
+    err = torch.empty((F,), dtype=torch.float64, device=sig.device)
+    status = torch.empty((F,), dtype=torch.int32, device=sig.device)
+    stream = torch.cuda.current_stream(sig.device).cuda_stream
+    _ffi.check(L.alz_lpc_kautocor_dev(flat.data_ptr(), F, frame_len, hop, order, coefs.data_ptr(),
+                                      err.data_ptr(), status.data_ptr(), sig.device.index or 0,
+                                      ctypes.c_void_p(stream)))
+    return coefs, err, status
+  flat = np.ascontiguousarray(sig, dtype=np.float64).reshape(-1)
+  F = _frame_count(flat.size, frame_len, hop)
+  d_sig = _DevBuf(flat.nbytes, device).upload(flat)
+  d_c, d_e, d_s = _DevBuf(F * (order + 1) * 8, device), _DevBuf(F * 8, device), _DevBuf(F * 4, device)
+  _ffi.check(L.alz_lpc_kautocor_dev(d_sig.ptr, F, frame_len, hop, order, d_c.ptr, d_e.ptr, d_s.ptr,
+                                    device, None))
+  _ffi.check(L.alz_device_sync(device))
+  return (d_c.download((F, order + 1), np.float64), d_e.download((F,), np.float64),
+          d_s.download((F,), np.int32))
+
+
+def acorr_frames(sig, frame_len, max_lag, hop=None, device=0):
+  """acorr(blk, max_lag) for every full frame; bit-exact (same summation order
+  as lazy_analysis.py:311-312).  Returns r [F, max_lag+1]."""
+  L = _ffi.load()
+  hop = frame_len if hop is None else hop
+  flat = np.ascontiguousarray(sig, dtype=np.float64).reshape(-1)
+  F = _frame_count(flat.size, frame_len, hop)
+  d_sig = _DevBuf(flat.nbytes, device).upload(flat)
+  d_r = _DevBuf(F * (max_lag + 1) * 8, device)
+  _ffi.check(L.alz_acorr_dev(d_sig.ptr, F, frame_len, hop, max_lag, d_r.ptr, device, None))
+  _ffi.check(L.alz_device_sync(device))
+  return d_r.download((F, max_lag + 1), np.float64)

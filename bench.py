@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+Workload (configs[1]): a 4096-channel biquad IIR bank (one resonator per
+channel, 50 Hz .. 20 kHz log-spaced at 48 kHz), float64, 1 Mi-sample blocks,
+time-major [N, C] rows (the reference's vector-valued-sample layout), one
+MI355X per rank.  A "step" is one pass of the bank over one block of synthetic
+uniform(-1, 1) noise that is already resident in HBM; filter state carries over
+from step to step, so K steps are one continuous K*N-sample stream per channel.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; channels are
+   sharded with no data-path collective -> "scaling": "weak")
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ALG_BYTES_PER_SAMPLE = 16.0    # 8 B read + 8 B written per channel-sample
+
+
+def resonator_coefs(C, fs=48000.0):
+  """resonator.z_exp(fc, fc/10) per channel (reference lazy_filters.py:1245-1276),
+  designed by audiolazy_amd's own host-side mirror when present."""
+  fc = np.geomspace(50.0, 20000.0, C)
+  try:
+    from audiolazy_amd.filters import resonator
+    filts = [resonator.z_exp(2 * np.pi * f / fs, 2 * np.pi * f / 10 / fs) for f in fc]
+    b = np.array([fl.numlist for fl in filts], dtype=np.float64)
+    a = np.array([fl.denlist for fl in filts], dtype=np.float64)
+    return b, a
+  except ImportError:
+    w, bw = 2 * np.pi * fc / fs, 2 * np.pi * fc / 10 / fs
+    r = np.exp(-bw / 2)
+    a = np.stack([np.ones(C), -2 * r * np.cos(w), r * r], axis=1)
+    g = (1 - r * r) / 2
+    return np.stack([g, np.zeros(C), -g], axis=1), a
+
+
+def cpu_baseline(b, a, n_samples, budget_s=12.0):
+  """The oracle (a C port of the reference's generated loop, 1 thread) on a bounded
+  sample of the same workload: 64 channels x n_samples, repeated until ~budget_s."""
+  from oracle import oracle
+  C = 64
+  n = min(n_samples, 1 << 20)
+  rng = np.random.default_rng(1)
+  x = rng.uniform(-1, 1, (C, n))
+  sel = np.linspace(0, b.shape[0] - 1, C).astype(int)
+  bs, as_ = np.ascontiguousarray(b[sel]), np.ascontiguousarray(a[sel])
+  oracle.bank([3], [3], bs, as_, x[:, :1024], layout="chan")  # warm
+  done, t0 = 0, time.perf_counter()
+  while True:
+    oracle.bank([3], [3], bs, as_, x, layout="chan")
+    done += C * n
+    el = time.perf_counter() - t0
+    if el >= budget_s:
+      break
+  return {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1, "kind": "port",
+          "sample": "oracle/alz_oracle.c DF-I loop, %d of the %d channels x %d samples, channel-major, "
+                    "%d passes, 1 thread (host has %d logical cores)" % (C, b.shape[0], n, done // (C * n),
+                                                                         os.cpu_count() or 0)}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=2)
+  ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
+  ap.add_argument("--log2-samples", type=int, default=20, help="block length per channel = 2**this")
+  ap.add_argument("--layout", choices=["time", "chan"], default="time")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  import torch
+  import audiolazy_amd as alz
+  alz.load_library()  # raises loudly when libalzhip.so is missing: there is no CPU path
+
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+  torch.cuda.set_device(local)
+  dev = torch.device("cuda", local)
+
+  C, N = args.channels, 1 << args.log2_samples
+  # the global bank has world*C channels; this rank owns the contiguous shard [rank*C, (rank+1)*C)
+  b_all, a_all = resonator_coefs(world * C)
+  b, a = b_all[rank * C:(rank + 1) * C], a_all[rank * C:(rank + 1) * C]
+  bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
+  bank.reset()
+
+  shape = (N, C) if args.layout == "time" else (C, N)
+  g = torch.Generator(device=dev).manual_seed(20260924 + rank)
+  x = torch.empty(shape, dtype=torch.float64, device=dev)
+  rows = shape[0]
+  step_rows = max(1, rows // 16)
+  for r0 in range(0, rows, step_rows):   # chunked fill keeps the generator's temporaries small
+    x[r0:r0 + step_rows].uniform_(-1.0, 1.0, generator=g)
+  y = torch.empty(shape, dtype=torch.float64, device=dev)
+
+  def sync_all():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+
+  for _ in range(args.warmup):
+    bank.process(x, layout=args.layout, out=y)
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for _ in range(args.steps)]
+  sync_all()
+  t0 = time.perf_counter()
+  for s in range(args.steps):
+    ev[s][0].record()                  # same stream the kernel is launched on (torch's current)
+    bank.process(x, layout=args.layout, out=y)
+    ev[s][1].record()
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+  kernel_name = bank.last_kernel
+
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  # spot parity: 4 channels of the last block against the oracle would need the whole
+  # stream history; instead re-run a fresh 4096-sample block and compare bit for bit
+  parity = None
+  if rank == 0:
+    try:
+      from oracle import oracle
+      nchk = 4096
+      bank.reset()
+      xs = x[:nchk].contiguous() if args.layout == "time" else x[:, :nchk].contiguous()
+      ys = bank.process(xs, layout=args.layout).cpu().numpy()
+      ref = oracle.bank([3], [3], b, a, xs.cpu().numpy(), layout=args.layout)
+      parity = "bit-exact" if np.array_equal(ys.view(np.uint64), ref.view(np.uint64)) else "MISMATCH"
+    except Exception as exc:  # the oracle is a checker, never a dependency of the timed path
+      parity = "unchecked (%s)" % exc
+
+  if rank == 0:
+    samples = float(world) * C * N * args.steps
+    value = samples / elapsed / 1e9
+    k_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = ALG_BYTES_PER_SAMPLE * C * N / (k_avg_ms * 1e-3) / 1e9
+    out = {
+      "metric": "Gsamples/s through ZFilter IIR biquad bank",
+      "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f64", "data": "synthetic",
+      "config": {"workload": "configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), "
+                             "48 kHz float64, %d-sample blocks, 1 MI355X per rank" % (C, N),
+                 "channels_per_gpu": C, "block_samples": N,
+                 "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
+                 "kernel": kernel_name, "parity_spot_check": parity},
+      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N},
+    }
+    if not args.no_cpu_baseline and world == 1:
+      out["cpu_baseline"] = cpu_baseline(b, a, N)
+    print(json.dumps(out))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,135 @@
+/*
+ * alz.h -- C ABI of libalzhip.so, the MI355X (gfx950) blocked stream-filter engine.
+ *
+ * The reference (AudioLazy 0.6.1dev, pure Python) has no FFI: its boundary for
+ * this path is the callable protocol "a filter is any callable that receives an
+ * iterable and returns a Stream" (audiolazy/lazy_filters.py:975-978, 1033-1036)
+ * with the signature __call__(seq, memory=None, zero=0.) (:141, :840).  Each
+ * entry point below names the reference lines whose *execution* it replaces;
+ * the Python mirror of the callable protocol lives in audiolazy_amd/ and binds
+ * these symbols through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns an int status (ALZ_OK or a negative ALZ_E_*);
+ *     alz_last_error() returns a thread-local message for the last failure.
+ *   - plain pointers and sizes only; all samples, coefficients and state are
+ *     IEEE binary64 (the reference computes in CPython floats).
+ *   - "dev" pointers are device (HBM) pointers, "host" pointers host memory.
+ *     Data buffers are caller-owned; coefficients are copied at create time.
+ *   - a handle is bound to one device and is not thread-safe; distinct handles
+ *     may be used from distinct threads.  Calls are asynchronous with respect
+ *     to the hipStream_t passed as `stream` (NULL = the default stream).
+ *   - arithmetic: Direct Form I in the reference's generated term order with
+ *     separately rounded multiply and add (no FMA), zero coefficients absent
+ *     from the sum, division by a0 only when a0 != 1 -- results are
+ *     bit-identical to the reference generator (lazy_filters.py:197-257).
+ */
+#ifndef ALZ_H
+#define ALZ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALZ_VERSION 100 /* 0.1.0 */
+
+/* status codes; the Python shim re-raises the reference's exception types */
+#define ALZ_OK 0
+#define ALZ_E_ARG (-1)         /* bad argument                      -> ValueError */
+#define ALZ_E_NONCAUSAL (-2)   /* lazy_filters.py:165-168           -> ValueError("Non-causal filter") */
+#define ALZ_E_ZERO_GAIN (-3)   /* lazy_filters.py:177-178           -> ZeroDivisionError("Invalid filter gain") */
+#define ALZ_E_PARCOR (-4)      /* lazy_lpc.py:132-133               -> ParCorError */
+#define ALZ_E_HIP (-5)         /* HIP runtime failure               -> RuntimeError */
+#define ALZ_E_NOMEM (-6)       /* allocation failure                -> MemoryError */
+#define ALZ_E_UNSUPPORTED (-7) /* shape outside the engine's gate   -> NotImplementedError */
+
+/* sample layouts: element (n, c) of a block of n samples x C channels */
+#define ALZ_TIME_MAJOR 0 /* [N, C]: addr = n*ld + c   (the reference's vector-valued-sample rows) */
+#define ALZ_CHAN_MAJOR 1 /* [C, N]: addr = c*ld + n   (one Stream per row) */
+
+/* bank modes */
+#define ALZ_BANK_DIAGONAL 0 /* channel c: input c, coefficient set c (n_sets == n_inputs) */
+#define ALZ_BANK_OUTER 1    /* channel c = set*n_inputs + input: every coefficient set on
+                               every input (a filterbank; n_sets == 1 is "shared taps") */
+
+typedef struct alz_bank alz_bank_t;
+
+/* ---- library / device ---------------------------------------------------- */
+int alz_version(void);
+const char *alz_last_error(void);
+int alz_device_count(int *count);
+/* device memory helpers so a caller needs no other HIP binding */
+int alz_malloc(int device, uint64_t bytes, void **dev_ptr);
+int alz_free(int device, void *dev_ptr);
+int alz_memcpy_h2d(int device, void *dst_dev, const void *src_host, uint64_t bytes);
+int alz_memcpy_d2h(int device, void *dst_host, const void *src_dev, uint64_t bytes);
+int alz_device_sync(int device);
+
+/* ---- filter bank ---------------------------------------------------------
+ * Replaces the execution of LinearFilter.__call__ (lazy_filters.py:141-264),
+ * ZFilter.__call__ (:840-889) and CascadeFilter.__call__ (:988-990) for
+ * `channels` independent streams at once.
+ *
+ * A bank is `n_sections` cascaded sections (CascadeFilter order); section s has
+ * nb[s] numerator taps b_0..b_{nb-1} and na[s] denominator taps a_0..a_{na-1}
+ * (the reference's numlist / denlist, lazy_filters.py:55-67).  Coefficients:
+ *   b: [n_sets, sum(nb)]   a: [n_sets, sum(na)]   row-major, sections concatenated.
+ * Errors: ALZ_E_ZERO_GAIN if any a_0 == 0; ALZ_E_ARG on bad sizes.
+ */
+int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections,
+                    const int *nb, const int *na, const double *b_host,
+                    const double *a_host, int device, alz_bank_t **out);
+int alz_bank_destroy(alz_bank_t *h);
+int alz_bank_channels(const alz_bank_t *h, int64_t *channels);
+
+/* State = the reference generator's local variables (lazy_filters.py:243-250):
+ *   xh[c][hx(s) + k] = d_{k+1} of section s = its input  at time -1-k
+ *   yh[c][hy(s) + k] = m_{k+1} of section s = its output at time -1-k
+ * with hx(s) = sum_{t<s}(nb[t]-1), hy(s) = sum_{t<s}(na[t]-1); host arrays
+ * [channels, sum(nb-1)] and [channels, sum(na-1)], row-major.
+ * alz_bank_reset == memory=None: every d and m is `zero` (:185-186, :247-250).
+ * The state persists across process calls, so consecutive blocks equal one
+ * continuous reference run.                                                   */
+int alz_bank_reset(alz_bank_t *h, double zero);
+int alz_bank_set_state(alz_bank_t *h, const double *xh_host, const double *yh_host);
+int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host);
+
+/* Filter one block of n samples per channel.
+ *   x: n_inputs channels, y: `channels` channels, both in `layout`;
+ *   ldx / ldy: leading dimension in elements (TIME_MAJOR: >= channel count,
+ *   CHAN_MAJOR: >= n).  y may alias x only in DIAGONAL mode with ldx == ldy.
+ * process_host stages through device buffers owned by the handle.            */
+int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev,
+                         int64_t n, int layout, int64_t ldx, int64_t ldy,
+                         void *stream);
+int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host,
+                          int64_t n, int layout, int64_t ldx, int64_t ldy);
+int alz_bank_sync(alz_bank_t *h);
+
+/* Name of the kernel variant the last process call dispatched to (diagnostic;
+ * tests use it to prove the fast paths are the ones exercised).              */
+const char *alz_bank_last_kernel(const alz_bank_t *h);
+
+/* ---- LPC -------------------------------------------------------------------
+ * Replaces lpc.kautocor (lazy_lpc.py:229-272) = acorr(blk, order)
+ * (lazy_analysis.py:277-312) + levinson_durbin (lazy_lpc.py:52-136) for a batch
+ * of frames: frame f = sig[f*hop .. f*hop + frame_len).
+ *   coefs [n_frames, order+1] (numlist of the analysis FIR, coefs[.][0] == 1),
+ *   err   [n_frames]          (the filter's .error attribute),
+ *   status[n_frames]          ALZ_OK or ALZ_E_PARCOR (zero-energy frame; the
+ *                             reference raises ParCorError, lazy_lpc.py:132-133).
+ * Floating point: not bit-exact (standard O(order^2) recursion instead of the
+ * reference's dense inner products); tests hold it to 1e-9 normalised error. */
+int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
+                         int64_t hop, int order, double *coefs_dev,
+                         double *err_dev, int *status_dev, int device, void *stream);
+/* acorr alone (lazy_analysis.py:277-312): r [n_frames, max_lag+1] */
+int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
+                  int64_t hop, int max_lag, double *r_dev, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALZ_H */

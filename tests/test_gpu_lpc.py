@@ -1,0 +1,84 @@
+"""GPU parity for batched lpc.kautocor (reference lazy_lpc.py:229-272).
+
+acorr is bit-exact (same left-to-right sum).  Levinson-Durbin on the GPU is the
+standard O(order^2) recursion, not the reference's dense inner products, so it
+is floating-point parity: normalised max error of the coefficient vector and
+relative error of .error must be <= 1e-9 (north star allows 1e-6).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unhex
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def lpc():
+  import audiolazy_amd
+  assert audiolazy_amd.device_count() >= 1
+  from audiolazy_amd import lpc as m
+  return m
+
+
+def test_golden_acorr_bit_exact(lpc):
+  for case in load_golden("lpc.json")["acorr"]:
+    x = np.array(unhex(case["x"]))
+    lag = case["max_lag"] if case["max_lag"] is not None else len(x) - 1
+    if lag > 63:
+      continue
+    r = lpc.acorr_frames(x, len(x), lag)
+    assert np.array_equal(r[0].view(np.uint64), np.array(unhex(case["r"])).view(np.uint64))
+
+
+def test_golden_kautocor(lpc):
+  for case in load_golden("lpc.json")["kautocor"]:
+    x = np.array(unhex(case["x"]))
+    ref = np.array(unhex(case["coefs"]))
+    c, e, st = lpc.kautocor_frames(x, len(x), case["order"])
+    ref = np.concatenate([ref, np.zeros(c.shape[1] - len(ref))])
+    assert st[0] == 0
+    assert np.abs(c[0] - ref).max() / np.abs(ref).max() <= TOL
+    assert abs(e[0] - unhex(case["error"])) <= TOL * max(abs(unhex(case["error"])), 1e-300) + 1e-12
+
+
+def test_known_answers(lpc):
+  # reference tests/test_lpc.py:218-224: [-1,0,1,0]*4, order 2 -> 1 + 0.875 z^-2, error 1.875
+  c, e, st = lpc.kautocor_frames(np.array([-1., 0., 1., 0.] * 4), 16, 2)
+  np.testing.assert_allclose(c[0], [1, 0, .875], atol=1e-14)
+  assert e[0] == pytest.approx(1.875, rel=1e-13)
+  # reference lazy_lpc.py:250-259 style: the doctest signal of levinson_durbin, through kautocor
+  data = np.array([2., 2, 0, 0, -1, -1, 0, 0, 1, 1])
+  c, e, st = lpc.kautocor_frames(data, 10, 3)
+  np.testing.assert_allclose(c[0], [1, -0.625, 0.25, 0.125], atol=1e-14)
+  assert e[0] == pytest.approx(7.875, rel=1e-13)
+
+
+def test_batch_vs_oracle_with_hop_and_zero_frames(lpc):
+  from oracle import oracle
+  rng = np.random.default_rng(99)
+  L, hop, order = 480, 240, 16
+  F = 1000
+  sig = rng.uniform(-1, 1, (F - 1) * hop + L)
+  sig[20 * hop: 20 * hop + L] = 0.0   # frame 20 has zero energy -> ParCorError in the reference
+  c, e, st = lpc.kautocor_frames(sig, L, order, hop=hop)
+  rc, re, rst = oracle.kautocor_frames(sig, F, L, hop, order)
+  assert c.shape == (F, order + 1)
+  assert st[20] == -4 and rst[20] == -4        # ALZ_E_PARCOR
+  ok = rst == 0
+  assert np.array_equal(st == 0, ok)
+  err = np.abs(c[ok] - rc[ok]).max(axis=1) / np.abs(rc[ok]).max(axis=1)
+  assert err.max() <= TOL
+  assert (np.abs(e[ok] - re[ok]) / np.abs(re[ok])).max() <= TOL
+
+
+def test_order_above_31_uses_64_lane_slots(lpc):
+  from oracle import oracle
+  rng = np.random.default_rng(5)
+  L, order, F = 300, 40, 17
+  sig = rng.uniform(-1, 1, F * L)
+  c, e, st = lpc.kautocor_frames(sig, L, order)
+  rc, re, rst = oracle.kautocor_frames(sig, F, L, L, order)
+  assert (st == 0).all()
+  assert (np.abs(c - rc).max(axis=1) / np.abs(rc).max(axis=1)).max() <= 1e-7
