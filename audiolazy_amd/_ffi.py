@@ -56,6 +56,35 @@ class ParCorError(ZeroDivisionError):
 _lib = None
 
 
+def _pin_hip_runtime():
+  """One HIP runtime per process.
+
+  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so
+  (same SONAMEs as /opt/rocm's).  Whichever copy is loaded first serves every
+  later DT_NEEDED lookup, and a process that ends up with both (libalzhip.so
+  initialising /opt/rocm's copy, torch its own) sees "No HIP GPUs are
+  available" from the second one.  So before libalzhip.so is loaded, make
+  torch's copy the resident one when torch is installed; device pointers and
+  streams handed over from torch tensors then belong to the same runtime.
+  """
+  import importlib.util
+  import sys
+  if "torch" in sys.modules:
+    return
+  try:
+    spec = importlib.util.find_spec("torch")
+  except (ImportError, ValueError):
+    spec = None
+  if spec is None or not spec.origin:
+    return
+  path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+  if os.path.exists(path):
+    try:
+      ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+      pass
+
+
 def load():
   """Load libalzhip.so and bind every declared symbol (no GPU needed for this)."""
   global _lib
@@ -65,6 +94,7 @@ def load():
     raise ImportError(
       "audiolazy_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
       "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+  _pin_hip_runtime()
   try:
     L = ctypes.CDLL(LIB_PATH)
   except OSError as exc:  # e.g. no ROCm runtime on this machine

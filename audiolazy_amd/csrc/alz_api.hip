@@ -374,12 +374,37 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       ALZ_HIP_CHECK(hipMemcpyAsync(h->scratch, y_dev, y_extent * 8, hipMemcpyDeviceToDevice, st));
       io.x = h->scratch;
     }
+    // streaming kernel first (full tiles of full channel groups), k_small & co. for the rest
+    int64_t done_n = 0, done_c = 0;
     const char *name = "";
-    int rc = alz::launch_section(sec, io, st, &name);
+    io.c_first = 0;
+    io.c_count = h->channels;
+    int rc = generic ? ALZ_OK : alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
     if (rc) return rc;
-    h->last_kernel = name;
-    if (!h->last_kernels.empty()) h->last_kernels += "+";
-    h->last_kernels += name;
+    auto note = [&](const char *k) {
+      h->last_kernel = k;
+      if (!h->last_kernels.empty()) h->last_kernels += "+";
+      h->last_kernels += k;
+    };
+    if (done_c > 0) note(name);
+    if (done_c < h->channels) {  // ragged channel tail, whole block
+      io.c_first = done_c;
+      io.c_count = h->channels - done_c;
+      rc = alz::launch_section(sec, io, st, &name);
+      if (rc) return rc;
+      note(name);
+    }
+    if (done_c > 0 && done_n < n) {  // ragged time tail of the streamed channels
+      io.c_first = 0;
+      io.c_count = done_c;
+      io.x += done_n * io.sxn;
+      io.y += done_n * io.syn;
+      io.n = n - done_n;
+      rc = alz::launch_section(sec, io, st, &name);
+      if (rc) return rc;
+      note(name);
+      io.n = n;
+    }
   }
   return ALZ_OK;
 }

@@ -44,7 +44,8 @@ struct BlockIO {
   int64_t n;          // samples per channel
   int64_t sxn, sxc;   // x element strides (time, channel)
   int64_t syn, syc;   // y element strides
-  int64_t channels;   // output channels
+  int64_t channels;   // output channels of the bank (state array stride)
+  int64_t c_first, c_count;  // channel range this launch covers
   int64_t n_inputs;   // input channels
   int64_t n_sets;     // coefficient sets
   int mode;           // ALZ_BANK_DIAGONAL / ALZ_BANK_OUTER
@@ -52,8 +53,12 @@ struct BlockIO {
   double zero;        // what an all-zero section yields (lazy_filters.py:227-231)
 };
 
-// alz_iir.hip
+// alz_iir.hip: any section shape, channels [c_first, c_first + c_count)
 int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
                    const char **kernel_name);
+// alz_wave.hip: the streaming kernel takes the full tiles of the full channel groups it
+// can and reports how much that was; the caller finishes the rest with launch_section
+int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
+                int64_t *done_samples, int64_t *done_channels, const char **kernel_name);
 
 }  // namespace alz

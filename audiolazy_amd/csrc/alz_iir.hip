@@ -32,6 +32,7 @@ struct KArgs {
   double *y;
   int64_t n, sxn, sxc, syn, syc;
   int64_t channels, n_inputs, n_sets;
+  int64_t c_first, c_end;  // channel range of this launch
   int mode;
   int map_input;  // OUTER mode, first section: channel c reads input c % n_inputs
   int nb, na;
@@ -73,8 +74,8 @@ __device__ __forceinline__ double small_step(double d0, double d1, double d2, do
 
 template <unsigned PB, unsigned PA, bool DIV>
 __global__ __launch_bounds__(64) void k_small(KArgs p) {
-  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (c >= p.channels) return;
+  const int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.c_end) return;
   int64_t in, set;
   lane_ids(p, c, in, set);
   constexpr int NBH = (PB & 4u) ? 2 : (PB & 2u) ? 1 : 0;  // history depth actually read
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(64) void k_small(KArgs p) {
 // ---------------------------------------------------------------------------
 template <int NB, int NA>
 __global__ __launch_bounds__(64) void k_masked(KArgs p) {
-  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (c >= p.channels) return;
+  const int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.c_end) return;
   int64_t in, set;
   lane_ids(p, c, in, set);
 
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(64) void k_masked(KArgs p) {
 // for times before the block, from the state arrays.  x and y must not alias.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_generic(KArgs p, double *xh_new, double *yh_new) {
-  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (c >= p.channels) return;
+  const int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.c_end) return;
   int64_t in, set;
   lane_ids(p, c, in, set);
   const double *xp = p.x + in * p.sxc;
@@ -284,9 +285,10 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.x = io.x; p.y = io.y; p.n = io.n;
   p.sxn = io.sxn; p.sxc = io.sxc; p.syn = io.syn; p.syc = io.syc;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
+  p.c_first = io.c_first; p.c_end = io.c_first + io.c_count;
   p.mode = io.mode; p.map_input = io.map_input; p.nb = sec.nb; p.na = sec.na;
   p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh; p.zero = io.zero;
-  const dim3 grid((unsigned)((io.channels + 63) / 64)), block(64);
+  const dim3 grid((unsigned)((io.c_count + 63) / 64)), block(64);
   const bool nonempty = (sec.present_b | sec.present_a) != 0;
 
   if (sec.nb <= 3 && sec.na <= 3 && sec.uniform && nonempty) {

@@ -1,0 +1,289 @@
+// alz_wave.hip -- the streaming DF-I kernel: independent wavefront workers, LDS ring
+// fed by direct global->LDS DMA, wide coalesced stores.
+//
+// Same arithmetic as k_small in alz_iir.hip (reference audiolazy/lazy_filters.py
+// :197-257, bit-exact, -ffp-contract=off); what changes is how samples move:
+//
+//   * a wavefront owns G adjacent channels (lanes 0..G-1 run the recurrences, filter
+//     state in VGPRs) and walks time in tiles of 8 KiB = 512 16-byte pieces;
+//   * tiles arrive with global_load_lds_dwordx4 (no VGPR round trip, 64 x 16 B per
+//     instruction, 8 instructions per tile) into a ring of R = 4 LDS slots, three
+//     tiles (24 KiB) in flight per wave under counted s_waitcnt vmcnt(N);
+//   * the recurrence reads x from the slot with ds_read_b64, writes y back in place,
+//     and the finished tile leaves as 8 ds_read_b128 + global_store_dwordx4;
+//   * no workgroup barrier anywhere: one wave per workgroup, waves never talk.
+//
+// Why G matters: the recurrence is a serial dependence per channel (about 3 dependent
+// f64 ops, ~7.5 cycles each, and 4.7 cycles of issue per f64 op -- measured with
+// tools/ubench_f64.hip), so a lane advances one sample per ~30 cycles no matter how
+// many lanes are active.  Throughput is channels x step rate as long as every wave has
+// its own SIMD; small banks therefore use G = 16 so that 4096 channels become 256
+// waves, one per CU, each pulling only ~13 B/clk through its CU's memory path.
+//
+// Layouts (element (n, c) of the block):
+//   TIME_MAJOR  tile = [T rows][G ch], piece q -> row q/(G/2), channel pair q%(G/2)
+//   CHAN_MAJOR  tile = [G ch][T samples], piece q -> channel q/(T/2), sample pair q%(T/2);
+//               each 1 KiB DMA chunk is padded by 16 B in LDS to spread banks.
+// T = 512/G*... = 8192 / (8*G) samples per tile.
+#include "alz_common.h"
+
+namespace alz {
+
+static constexpr int kRing = 4;           // LDS slots per wave
+static constexpr int kChunks = 8;         // 1 KiB DMA instructions per tile
+static constexpr int kSlotBytes = 8192 + kChunks * 16;
+
+struct WArgs {
+  const double *x;
+  double *y;
+  int64_t ldx, ldy;       // leading dimensions in elements
+  int64_t n_tiles;        // full tiles to process
+  int64_t channels;       // state array stride
+  int64_t c_first;        // first channel handled by this launch
+  int64_t n_sets;
+  int nb, na;
+  const double *b, *a;
+  double *xh, *yh;
+};
+
+// one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
+// at lds_dst + lane*16.  M0 is saved/restored inside the same statement (hipcc reserves it).
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// wait until at most `n` vector-memory operations of this wave are outstanding.
+// n is a multiple of 8 in [0, 48]; s_waitcnt needs a literal.
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  }
+}
+
+template <unsigned PB, unsigned PA>
+__device__ __forceinline__ double wave_step(double d0, double d1, double d2, double m1, double m2,
+                                            double b0, double b1, double b2, double na1,
+                                            double na2) {
+  double acc = 0.0;
+  bool first = true;
+  if constexpr (PB & 1u) { acc = b0 * d0; first = false; }
+  if constexpr (PB & 2u) { const double t = b1 * d1; acc = first ? t : acc + t; first = false; }
+  if constexpr (PB & 4u) { const double t = b2 * d2; acc = first ? t : acc + t; first = false; }
+  if constexpr (PA & 1u) { const double t = na1 * m1; acc = first ? t : acc + t; first = false; }
+  if constexpr (PA & 2u) { const double t = na2 * m2; acc = first ? t : acc + t; first = false; }
+  return acc;
+}
+
+// G: channels per wave (16, 32 or 64).  CM: channel-major layout.
+template <int G, bool CM, unsigned PB, unsigned PA>
+__global__ __launch_bounds__(64) void k_wave(WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = 8192 / (8 * G);          // samples per channel per tile
+  const int lane = threadIdx.x;
+  const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;  // low 32 bits of the flat address == LDS offset
+
+  // per-lane source/destination offsets (in elements) of the lane's piece in chunk 0 of tile 0,
+  // and the element step from one chunk to the next / one tile to the next
+  int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+  if (!CM) {
+    // chunk j holds rows j*R8 .. j*R8+R8-1 with R8 = 128/G rows, each row G ch = G/2 pieces
+    constexpr int PPR = G / 2;               // pieces per row
+    const int row = lane / PPR, cp = lane % PPR;
+    x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
+    y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+    x_chunk = (int64_t)(64 / PPR) * p.ldx;
+    y_chunk = (int64_t)(64 / PPR) * p.ldy;
+    x_tile = (int64_t)T * p.ldx;
+    y_tile = (int64_t)T * p.ldy;
+  } else {
+    // chunk j holds channels j*C8 .. with C8 = 128/T channels, each channel T samples = T/2 pieces
+    constexpr int PPC = T / 2;               // pieces per channel
+    const int ch = lane / PPC, sp = lane % PPC;
+    x_off = (c0 + ch) * p.ldx + 2 * sp;
+    y_off = (c0 + ch) * p.ldy + 2 * sp;
+    x_chunk = (int64_t)(64 / PPC) * p.ldx;
+    y_chunk = (int64_t)(64 / PPC) * p.ldy;
+    x_tile = T;
+    y_tile = T;
+  }
+
+  // the lane's recurrence reads element e(u) = u*G + lane (TIME) or lane*T + u (CHAN) of the
+  // tile; byte offset = e*8 + (e/128)*16 (the 16-byte pad after every 1 KiB chunk)
+  const bool active = lane < G;
+  const int64_t c = c0 + (active ? lane : 0);
+  const int64_t set = (p.n_sets == 1) ? 0 : c;
+  double b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0;
+  if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
+  if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
+  if (PB & 4u) b2 = p.b[2 * p.n_sets + set];
+  if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
+  if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
+  double d1 = (p.nb > 1) ? p.xh[0 * p.channels + c] : 0.0;
+  double d2 = (p.nb > 2) ? p.xh[1 * p.channels + c] : 0.0;
+  double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
+  double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+
+  const double *xg = p.x + x_off;
+  double *yg = p.y + y_off;
+  const int64_t nt = p.n_tiles;
+
+  // prologue: tiles 0 .. kRing-2 into slots 0 .. kRing-2
+  for (int t = 0; t < kRing - 1 && t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j)
+      dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
+  }
+
+  for (int64_t i = 0; i < nt; ++i) {
+    const int slot = (int)(i % kRing);
+    // refill the slot freed by tile i-1 with tile i+kRing-1
+    const int64_t tn = i + kRing - 1;
+    if (tn < nt) {
+      const int sn = (int)(tn % kRing);
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j)
+        dma16(xg + tn * x_tile + j * x_chunk, lds0 + sn * kSlotBytes + j * 1040);
+    }
+    // operations issued after tile i's DMA: the DMA of the following tiles plus the
+    // stores of the preceding ones (completion is in issue order)
+    {
+      const int64_t loads_after = (nt - 1 - i < kRing - 1) ? (nt - 1 - i) : (kRing - 1);
+      const int64_t stores_after = (i < kRing - 1) ? i : (kRing - 1);
+      wait_vm((int)(loads_after + stores_after) * kChunks);
+    }
+
+    char *tile = smem + slot * kSlotBytes;
+    if (active) {
+#pragma unroll
+      for (int u0 = 0; u0 < T; u0 += 8) {
+        double xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = CM ? (lane * T + u0 + u) : ((u0 + u) * G + lane);
+          xv[u] = *reinterpret_cast<const double *>(tile + e * 8 + (e >> 7) * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double d0 = xv[u];
+          const double m0 = wave_step<PB, PA>(d0, d1, d2, m1, m2, b0, b1, b2, na1, na2);
+          const int e = CM ? (lane * T + u0 + u) : ((u0 + u) * G + lane);
+          *reinterpret_cast<double *>(tile + e * 8 + (e >> 7) * 16) = m0;
+          m2 = m1; m1 = m0; d2 = d1; d1 = d0;
+        }
+      }
+    }
+    // the finished tile leaves as eight 1 KiB stores (all 64 lanes, 16 B each)
+    double *yt = yg + i * y_tile;
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+      const double2 v = *reinterpret_cast<const double2 *>(tile + j * 1040 + lane * 16);
+      *reinterpret_cast<double2 *>(yt + j * y_chunk) = v;
+    }
+  }
+
+  if (active) {
+    if (p.nb > 1) p.xh[0 * p.channels + c] = d1;
+    if (p.nb > 2) p.xh[1 * p.channels + c] = d2;
+    if (p.na > 1) p.yh[0 * p.channels + c] = m1;
+    if (p.na > 2) p.yh[1 * p.channels + c] = m2;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dispatch: curated tap patterns (everything else stays on k_small)
+// ---------------------------------------------------------------------------
+typedef void (*wave_fn)(WArgs);
+
+template <int G, bool CM>
+static wave_fn pick_pattern(unsigned pb, unsigned pa) {
+#define ALZ_PAT(PB_, PA_) \
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_wave<G, CM, PB_, PA_>;
+  ALZ_PAT(1, 1)  // b0           / a1        lowpass.pole, highpass.pole
+  ALZ_PAT(3, 1)  // b0 b1        / a1        lowpass.z, highpass.z
+  ALZ_PAT(1, 3)  // b0           / a1 a2     resonator.poles_exp, lowpass.pole**2, gammatone poles
+  ALZ_PAT(3, 3)  // b0 b1        / a1 a2     gammatone.slaney sections
+  ALZ_PAT(5, 3)  // b0    b2     / a1 a2     resonator.z_exp
+  ALZ_PAT(7, 3)  // b0 b1 b2     / a1 a2     general biquad
+  ALZ_PAT(1, 2)  // b0           /    a2
+  ALZ_PAT(7, 0)  // 3-tap FIR
+  ALZ_PAT(3, 0)  // 2-tap FIR
+#undef ALZ_PAT
+  return nullptr;
+}
+
+static wave_fn pick_wave(int g, bool cm, unsigned pb, unsigned pa) {
+  if (g == 16) return cm ? pick_pattern<16, true>(pb, pa) : pick_pattern<16, false>(pb, pa);
+  if (g == 32) return cm ? pick_pattern<32, true>(pb, pa) : pick_pattern<32, false>(pb, pa);
+  return cm ? pick_pattern<64, true>(pb, pa) : pick_pattern<64, false>(pb, pa);
+}
+
+// Runs the streaming kernel over the part of the block it can take (full tiles of full
+// channel groups) and reports that part; the caller finishes the rest with k_small.
+//   *done_tiles_samples: samples per channel consumed (multiple of the tile length)
+//   *done_channels:      channels covered (multiple of G), starting at channel 0
+int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
+                int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+  *done_samples = 0;
+  *done_channels = 0;
+  if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform && !sec.any_div)) return ALZ_OK;
+  if (io.mode == ALZ_BANK_OUTER) return ALZ_OK;  // set index needs c / n_inputs: k_small handles it
+  const bool cm = io.sxn == 1 && io.syn == 1 && !(io.sxc == 1 && io.syc == 1);
+  const bool tm = io.sxc == 1 && io.syc == 1;
+  if (!cm && !tm) return ALZ_OK;
+  const int64_t ldx = cm ? io.sxc : io.sxn, ldy = cm ? io.syc : io.syn;
+  // 16-byte pieces: base pointers 16-byte aligned and even leading dimensions
+  if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
+  if ((ldx | ldy) & 1) return ALZ_OK;
+  // group width: keep at least ~256 waves in flight for small banks
+  int g = 64;
+  if (io.channels < 64 * 256) g = 32;
+  if (io.channels < 32 * 256) g = 16;
+  const int64_t groups = io.channels / g;
+  const int t = 8192 / (8 * g);
+  const int64_t tiles = io.n / t;
+  if (groups == 0 || tiles == 0) return ALZ_OK;
+  wave_fn fn = pick_wave(g, cm, sec.present_b, sec.present_a);
+  if (!fn) return ALZ_OK;
+
+  WArgs p;
+  p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy;
+  p.n_tiles = tiles; p.channels = io.channels; p.c_first = 0;
+  p.n_sets = io.n_sets;
+  p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
+  // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
+  // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
+  size_t lds = (size_t)kRing * kSlotBytes;
+  if (groups <= 256) lds = 96 * 1024;
+  static bool attr_set[3][2][64] = {};
+  const int gi = g == 16 ? 0 : g == 32 ? 1 : 2;
+  const unsigned key = (sec.present_b << 2 | sec.present_a) & 63;
+  if (!attr_set[gi][cm][key]) {
+    ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      96 * 1024));
+    attr_set[gi][cm][key] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(64), lds, stream, p);
+  ALZ_HIP_CHECK(hipGetLastError());
+  *done_samples = tiles * t;
+  *done_channels = groups * g;
+  *kernel_name = g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  return ALZ_OK;
+}
+
+}  // namespace alz

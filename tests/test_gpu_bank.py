@@ -106,7 +106,7 @@ def test_bank_vs_oracle_ragged_sizes(alz, oracle, layout, C, N):
   bank = alz.FilterBank([(b, a)], n_inputs=C)
   bank.reset()
   y = bank.process(x, layout=layout)
-  assert bank.last_kernel == "k_small"
+  assert "k_small" in bank.last_kernel or "k_wave" in bank.last_kernel
   assert same_bits(y, oracle.bank([3], [3], b, a, x, layout=layout))
 
 
