@@ -25,6 +25,8 @@
 //   CHAN_MAJOR  tile = [G ch][T samples], piece q -> channel q/(T/2), sample pair q%(T/2);
 //               each 1 KiB DMA chunk is padded by 16 B in LDS to spread banks.
 // T = 512/G*... = 8192 / (8*G) samples per tile.
+#include <stdlib.h>
+
 #include "alz_common.h"
 
 namespace alz {
@@ -44,6 +46,7 @@ struct WArgs {
   int nb, na;
   const double *b, *a;
   double *xh, *yh;
+  int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores (wrong output!)
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -59,6 +62,15 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
+}
+
+// one 1 KiB store, 16 B per lane.  Inline asm on purpose: a store hipcc knows about makes it
+// insert its own s_waitcnt vmcnt(7) in front of the next tile's stores, which (with the DMA
+// loads it cannot see in the queue) drains the whole prefetch ring every tile.  The trailing
+// s_nop covers the "VMEM store of more than 8 bytes, then overwrite of its data VGPRs" hazard.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(double *gdst, dbl2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
 
 // wait until at most `n` vector-memory operations of this wave are outstanding.
@@ -123,10 +135,13 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     y_tile = T;
   }
 
-  // the lane's recurrence reads element e(u) = u*G + lane (TIME) or lane*T + u (CHAN) of the
-  // tile; byte offset = e*8 + (e/128)*16 (the 16-byte pad after every 1 KiB chunk)
-  const bool active = lane < G;
-  const int64_t c = c0 + (active ? lane : 0);
+  // Every lane runs the recurrence: with G < 64 the lanes G..63 are "ghosts" that mirror the
+  // channel of lane & (G-1).  A partially masked wave issues f64 ops ~36 % slower on gfx950
+  // (tools/ubench_rows.hip: 56 vs 41 cycles/step), so nothing here is exec-masked; ghosts read
+  // the same LDS words as their real lane (broadcast) and write into dummy slots behind the ring.
+  const int cl = lane & (G - 1);
+  const bool real = lane < G;
+  const int64_t c = c0 + cl;
   const int64_t set = (p.n_sets == 1) ? 0 : c;
   double b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0;
   if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
@@ -139,12 +154,18 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
   double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
 
+  // Consume the coefficient/state loads here, before any DMA is queued: hipcc then waits for
+  // them now, its own vmcnt scoreboard is empty for the rest of the kernel, and it places no
+  // s_waitcnt vmcnt(0) of its own inside the tile loop (where it would drain the DMA ring).
+  asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(na1), "+v"(na2));
+  asm volatile("" : "+v"(d1), "+v"(d2), "+v"(m1), "+v"(m2));
+
   const double *xg = p.x + x_off;
   double *yg = p.y + y_off;
   const int64_t nt = p.n_tiles;
 
   // prologue: tiles 0 .. kRing-2 into slots 0 .. kRing-2
-  for (int t = 0; t < kRing - 1 && t < nt; ++t) {
+  for (int t = 0; t < kRing - 1 && t < nt && !(p.dbg & 1); ++t) {
 #pragma unroll
     for (int j = 0; j < kChunks; ++j)
       dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     const int slot = (int)(i % kRing);
     // refill the slot freed by tile i-1 with tile i+kRing-1
     const int64_t tn = i + kRing - 1;
-    if (tn < nt) {
+    if (tn < nt && !(p.dbg & 1)) {
       const int sn = (int)(tn % kRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
@@ -169,35 +190,107 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     }
 
     char *tile = smem + slot * kSlotBytes;
-    if (active) {
+    if (!(p.dbg & 2)) {
+      // element e(u) = u*G + cl (TIME) or cl*T + u (CHAN); byte = e*8 + (e/128)*16 (chunk pad)
+      // (T and G divide 128, so the pad term splits into a per-lane part and a per-u part)
+      const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
+      const char *rd = tile + lane_off;
+      char *wr = (real ? tile : smem + (kRing - 1 + lane / G) * kSlotBytes) + lane_off;
+#define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+      // Three-stage software pipeline over chunks of 8 samples, pinned with sched_barrier:
+      //   LDS reads of chunk k+2  |  feed-forward sums p[] of chunk k+1  |  recurrence of chunk k
+      // The feed-forward ops (independent of the recurrence) are slotted between the dependent
+      // ops t3 -> s1 -> y of the recurrence, whose ~7.5-cycle result latency would otherwise
+      // stall the in-order wave (29 instead of 41 cycles/step, tools/ubench_biquad.hip).
+      constexpr int NCH = T / 8;
+      double xr[3][8], pp[2][8];
 #pragma unroll
-      for (int u0 = 0; u0 < T; u0 += 8) {
-        double xv[8];
+      for (int u = 0; u < 8; ++u) xr[0][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(u));
+      if (NCH > 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = CM ? (lane * T + u0 + u) : ((u0 + u) * G + lane);
-          xv[u] = *reinterpret_cast<const double *>(tile + e * 8 + (e >> 7) * 16);
+        for (int u = 0; u < 8; ++u) xr[1][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(8 + u));
+      }
+      // feed-forward of chunk 0 (not overlapped: once per tile)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double x0 = xr[0][u];
+        const double x1 = u >= 1 ? xr[0][u - 1] : d1;
+        const double x2 = u >= 2 ? xr[0][u - 2] : (u == 1 ? d1 : d2);
+        double acc = 0.0;
+        bool first = true;
+        if constexpr (PB & 1u) { acc = b0 * x0; first = false; }
+        if constexpr (PB & 2u) { const double t = b1 * x1; acc = first ? t : acc + t; first = false; }
+        if constexpr (PB & 4u) { const double t = b2 * x2; acc = first ? t : acc + t; first = false; }
+        pp[0][u] = acc;
+      }
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int xc = k % 3, xn = (k + 1) % 3, xl = (k + 2) % 3;
+        if (k + 2 < NCH) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            xr[xl][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u));
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const double d0 = xv[u];
-          const double m0 = wave_step<PB, PA>(d0, d1, d2, m1, m2, b0, b1, b2, na1, na2);
-          const int e = CM ? (lane * T + u0 + u) : ((u0 + u) * G + lane);
-          *reinterpret_cast<double *>(tile + e * 8 + (e >> 7) * 16) = m0;
-          m2 = m1; m1 = m0; d2 = d1; d1 = d0;
+          // fillers: feed-forward of step u of chunk k+1
+          const bool ff = k + 1 < NCH;
+          const double x0 = xr[xn][u];
+          const double x1 = u >= 1 ? xr[xn][u - 1] : xr[xc][7];
+          const double x2 = u >= 2 ? xr[xn][u - 2] : xr[xc][6 + u];
+          // ALZ_PIN(v): an empty asm that "rewrites" v -- the value must exist at this point of
+          // the instruction stream, which is what fixes the issue order (sched_barrier alone
+          // lets hipcc sink the pure feed-forward ops next to their use)
+#define ALZ_PIN(v) asm volatile("" : "+v"(v))
+          double fa = 0.0, fb = 0.0, t3 = 0.0, t4 = 0.0, acc = pp[k & 1][u];
+          if constexpr ((PA & 1u) != 0) { t3 = na1 * m1; ALZ_PIN(t3); }
+          if constexpr (PA == 2u) { t4 = na2 * m2; ALZ_PIN(t4); }
+          if (ff) {                                   // filler A
+            if constexpr (PB & 1u) { fa = b0 * x0; ALZ_PIN(fa); }
+            else if constexpr (PB & 2u) { fa = b1 * x1; ALZ_PIN(fa); }
+          }
+          if constexpr (PA == 3u) { acc = acc + t3; ALZ_PIN(acc); }   // s1
+          if (ff) {                                   // filler B
+            if constexpr ((PB & 3u) == 3u) { fb = b1 * x1; ALZ_PIN(fb); }
+            else if constexpr ((PB & 5u) == 5u) { fb = b2 * x2; ALZ_PIN(fb); }
+          }
+          if constexpr (PA == 3u) { t4 = na2 * m2; ALZ_PIN(t4); }
+          if (ff) {                                   // filler C
+            double pn = fa;
+            if constexpr ((PB & 3u) == 3u || (PB & 5u) == 5u) { pn = fa + fb; ALZ_PIN(pn); }
+            if constexpr (PB == 7u) { double h = b2 * x2; ALZ_PIN(h); pn = pn + h; ALZ_PIN(pn); }
+            pp[(k + 1) & 1][u] = pn;
+          }
+          if constexpr (PA == 3u) acc = acc + t4;     // y
+          else if constexpr (PA == 1u) acc = acc + t3;
+          else if constexpr (PA == 2u) acc = acc + t4;
+          ALZ_PIN(acc);
+#undef ALZ_PIN
+          *reinterpret_cast<double *>(wr + ALZ_EOFF(k * 8 + u)) = acc;
+          m2 = m1; m1 = acc;
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      d1 = xr[(NCH - 1) % 3][7];
+      d2 = xr[(NCH - 1) % 3][6];
+#undef ALZ_EOFF
     }
-    // the finished tile leaves as eight 1 KiB stores (all 64 lanes, 16 B each)
+    // the finished tile leaves as eight 1 KiB stores (all 64 lanes, 16 B each): all eight LDS
+    // reads are issued back to back (one exposed LDS latency per tile instead of eight)
     double *yt = yg + i * y_tile;
+    if (!(p.dbg & 4)) {
+      dbl2 v[kChunks];
 #pragma unroll
-    for (int j = 0; j < kChunks; ++j) {
-      const double2 v = *reinterpret_cast<const double2 *>(tile + j * 1040 + lane * 16);
-      *reinterpret_cast<double2 *>(yt + j * y_chunk) = v;
+      for (int j = 0; j < kChunks; ++j)
+        v[j] = *reinterpret_cast<const dbl2 *>(tile + j * 1040 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the asm stores are invisible to hipcc
 
-  if (active) {
+  if (real) {
     if (p.nb > 1) p.xh[0 * p.channels + c] = d1;
     if (p.nb > 2) p.xh[1 * p.channels + c] = d2;
     if (p.na > 1) p.yh[0 * p.channels + c] = m1;
@@ -266,9 +359,11 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.n_tiles = tiles; p.channels = io.channels; p.c_first = 0;
   p.n_sets = io.n_sets;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
+  static const int dbg_env = getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0;
+  p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = (size_t)kRing * kSlotBytes;
+  size_t lds = (size_t)(kRing + 64 / g - 1) * kSlotBytes;  // ring + the ghost lanes' dummy slots
   if (groups <= 256) lds = 96 * 1024;
   static bool attr_set[3][2][64] = {};
   const int gi = g == 16 ? 0 : g == 32 ? 1 : 2;
