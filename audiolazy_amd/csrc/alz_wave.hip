@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   // Every lane runs the recurrence: with G < 64 the lanes G..63 are "ghosts" that mirror the
   // channel of lane & (G-1).  A partially masked wave issues f64 ops ~36 % slower on gfx950
   // (tools/ubench_rows.hip: 56 vs 41 cycles/step), so nothing here is exec-masked; ghosts read
-  // the same LDS words as their real lane (broadcast) and write into dummy slots behind the ring.
+  // the same LDS words as their real lane (broadcast) and compute the same y.
   const int cl = lane & (G - 1);
   const bool real = lane < G;
   const int64_t c = c0 + cl;
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
       // (T and G divide 128, so the pad term splits into a per-lane part and a per-u part)
       const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
       const char *rd = tile + lane_off;
-      char *wr = (real ? tile : smem + (kRing - 1 + lane / G) * kSlotBytes) + lane_off;
+      // write address: lane group r = lane / G owns row r of each group of 64/G rows
+      char *wr = tile + lane_off + (CM ? (lane / G) * 8 : (lane / G) * G * 8);
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
       // Three-stage software pipeline over chunks of 8 samples, pinned with sched_barrier:
       //   LDS reads of chunk k+2  |  feed-forward sums p[] of chunk k+1  |  recurrence of chunk k
@@ -232,45 +233,41 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
             xr[xl][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u));
         }
         __builtin_amdgcn_sched_barrier(0);
+        double yv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          // fillers: feed-forward of step u of chunk k+1
-          const bool ff = k + 1 < NCH;
-          const double x0 = xr[xn][u];
-          const double x1 = u >= 1 ? xr[xn][u - 1] : xr[xc][7];
-          const double x2 = u >= 2 ? xr[xn][u - 2] : xr[xc][6 + u];
-          // ALZ_PIN(v): an empty asm that "rewrites" v -- the value must exist at this point of
-          // the instruction stream, which is what fixes the issue order (sched_barrier alone
-          // lets hipcc sink the pure feed-forward ops next to their use)
-#define ALZ_PIN(v) asm volatile("" : "+v"(v))
-          double fa = 0.0, fb = 0.0, t3 = 0.0, t4 = 0.0, acc = pp[k & 1][u];
-          if constexpr ((PA & 1u) != 0) { t3 = na1 * m1; ALZ_PIN(t3); }
-          if constexpr (PA == 2u) { t4 = na2 * m2; ALZ_PIN(t4); }
-          if (ff) {                                   // filler A
-            if constexpr (PB & 1u) { fa = b0 * x0; ALZ_PIN(fa); }
-            else if constexpr (PB & 2u) { fa = b1 * x1; ALZ_PIN(fa); }
-          }
-          if constexpr (PA == 3u) { acc = acc + t3; ALZ_PIN(acc); }   // s1
-          if (ff) {                                   // filler B
-            if constexpr ((PB & 3u) == 3u) { fb = b1 * x1; ALZ_PIN(fb); }
-            else if constexpr ((PB & 5u) == 5u) { fb = b2 * x2; ALZ_PIN(fb); }
-          }
-          if constexpr (PA == 3u) { t4 = na2 * m2; ALZ_PIN(t4); }
-          if (ff) {                                   // filler C
-            double pn = fa;
-            if constexpr ((PB & 3u) == 3u || (PB & 5u) == 5u) { pn = fa + fb; ALZ_PIN(pn); }
-            if constexpr (PB == 7u) { double h = b2 * x2; ALZ_PIN(h); pn = pn + h; ALZ_PIN(pn); }
+          // feed-forward of step u of chunk k+1: independent of the recurrence below, so hipcc
+          // slots these ops into the stalls of the dependent chain t3 -> s1 -> y (hand-pinning
+          // the order was measured slower than its own schedule: tools/ubench_loop.hip)
+          if (k + 1 < NCH) {
+            const double x0 = xr[xn][u];
+            const double x1 = u >= 1 ? xr[xn][u - 1] : xr[xc][7];
+            const double x2 = u >= 2 ? xr[xn][u - 2] : xr[xc][6 + u];
+            double pn = 0.0;
+            bool first = true;
+            if constexpr (PB & 1u) { pn = b0 * x0; first = false; }
+            if constexpr (PB & 2u) { const double t = b1 * x1; pn = first ? t : pn + t; first = false; }
+            if constexpr (PB & 4u) { const double t = b2 * x2; pn = first ? t : pn + t; first = false; }
             pp[(k + 1) & 1][u] = pn;
           }
-          if constexpr (PA == 3u) acc = acc + t4;     // y
-          else if constexpr (PA == 1u) acc = acc + t3;
-          else if constexpr (PA == 2u) acc = acc + t4;
-          ALZ_PIN(acc);
-#undef ALZ_PIN
-          *reinterpret_cast<double *>(wr + ALZ_EOFF(k * 8 + u)) = acc;
+          double acc = pp[k & 1][u];
+          if constexpr (PA & 1u) acc = acc + na1 * m1;
+          if constexpr (PA & 2u) acc = acc + na2 * m2;
+          yv[u] = acc;
           m2 = m1; m1 = acc;
-          __builtin_amdgcn_sched_barrier(0);
+          // Leaving through LDS: a 64-lane ds_write_b64 costs the wave ~18 cycles, so one per step
+          // would be a third of the loop.  The ghost lanes hold the SAME y as their real lane at
+          // every step, so lane group r = lane / G keeps the y of step (u0 + r) and a single
+          // ds_write_b64 stores 64 / G consecutive rows of the tile.
+          constexpr int RPW = 64 / G;  // rows per write
+          if ((u + 1) % RPW == 0) {
+            double yw = yv[u - (RPW - 1)];
+#pragma unroll
+            for (int r = 1; r < RPW; ++r) yw = (lane / G == r) ? yv[u - (RPW - 1) + r] : yw;
+            *reinterpret_cast<double *>(wr + ALZ_EOFF(k * 8 + u - (RPW - 1))) = yw;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       d1 = xr[(NCH - 1) % 3][7];
       d2 = xr[(NCH - 1) % 3][6];
@@ -363,7 +360,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = (size_t)(kRing + 64 / g - 1) * kSlotBytes;  // ring + the ghost lanes' dummy slots
+  size_t lds = (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
   static bool attr_set[3][2][64] = {};
   const int gi = g == 16 ? 0 : g == 32 ? 1 : 2;
