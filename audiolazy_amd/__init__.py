@@ -10,5 +10,18 @@ and the z**-1 algebra stay on the host in float64.
 from ._ffi import ParCorError, load as load_library, device_count  # noqa: F401
 from .stream import Stream, blocks  # noqa: F401
 from .bank import FilterBank, memory_to_hist, sections_of  # noqa: F401
+from .poly import Poly, x  # noqa: F401
+from .strategy import StrategyDict  # noqa: F401
+from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, comb, resonator,  # noqa: F401
+                      lowpass, highpass)
+from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
+from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
+
+
+def sHz(rate):
+  """(s, Hz) unit pair for a sample rate: ``440 * Hz`` is 440 Hz in rad/sample and
+  ``0.5 * s`` is half a second in samples (reference audiolazy/lazy_misc.py:300-320)."""
+  import math
+  return float(rate), 2 * math.pi / rate
 
 __version__ = "0.1.0"

@@ -44,6 +44,7 @@ SIGNATURES = {
   "alz_bank_sync": (_int, [_vp]),
   "alz_bank_last_kernel": (ctypes.c_char_p, [_vp]),
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
+  "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_acorr_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
 }
 

@@ -29,7 +29,8 @@ template <int SLOT>
 __global__ __launch_bounds__(64) void k_lpc(const double *__restrict__ sig, int64_t n_frames,
                                             int frame_len, int64_t hop, int order,
                                             double *__restrict__ coefs, double *__restrict__ err,
-                                            int *__restrict__ status, double *__restrict__ r_out) {
+                                            int *__restrict__ status, double *__restrict__ r_out,
+                                            int from_r) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *smem = reinterpret_cast<double *>(smem_raw);
   constexpr int FPW = 64 / SLOT;  // frames per wave
@@ -37,7 +38,8 @@ __global__ __launch_bounds__(64) void k_lpc(const double *__restrict__ sig, int6
   const int slot = lane / SLOT, i = lane % SLOT;
   const int64_t f0 = (int64_t)blockIdx.x * FPW;
 
-  // stage the wave's frames in LDS, coalesced
+  // stage the wave's frames in LDS, coalesced (from_r: "frames" are ready-made lag lists
+  // r[0..order] and the autocorrelation pass is skipped -- levinson_durbin alone)
   for (int s = 0; s < FPW; ++s) {
     const int64_t f = f0 + s;
     if (f >= n_frames) break;
@@ -52,7 +54,9 @@ __global__ __launch_bounds__(64) void k_lpc(const double *__restrict__ sig, int6
 
   // acorr: lane i sums lag i, left to right (lazy_analysis.py:311-312)
   double r = 0.0;
-  if (live && i <= order) {
+  if (from_r) {
+    if (live && i <= order && i < frame_len) r = fr[i];   // short lag lists are zero-extended (lazy_lpc.py:117-118)
+  } else if (live && i <= order) {
     const int cnt = frame_len - i;
     for (int n = 0; n < cnt; ++n) r = r + fr[n] * fr[n + i];
   }
@@ -86,7 +90,8 @@ __global__ __launch_bounds__(64) void k_lpc(const double *__restrict__ sig, int6
 }
 
 static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_t hop, int order,
-                      double *coefs, double *err, int *status, double *r_out, hipStream_t st) {
+                      double *coefs, double *err, int *status, double *r_out, int from_r,
+                      hipStream_t st) {
   if (n_frames < 0 || frame_len < 1 || hop < 0 || order < 0)
     return fail(ALZ_E_ARG, "lpc: bad frame geometry");
   if (order > 63) return fail(ALZ_E_UNSUPPORTED, "lpc: order > 63 is outside the engine's gate");
@@ -101,13 +106,13 @@ static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_
       ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)k_lpc<32>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_lpc<32>, grid, block, lds, st, sig, n_frames, frame_len, hop, order, coefs,
-                       err, status, r_out);
+                       err, status, r_out, from_r);
   } else {
     if (lds > 64 * 1024)
       ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)k_lpc<64>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_lpc<64>, grid, block, lds, st, sig, n_frames, frame_len, hop, order, coefs,
-                       err, status, r_out);
+                       err, status, r_out, from_r);
   }
   ALZ_HIP_CHECK(hipGetLastError());
   return ALZ_OK;
@@ -125,7 +130,20 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, order, coefs_dev, err_dev, status_dev,
-                           nullptr, (hipStream_t)stream);
+                           nullptr, 0, (hipStream_t)stream);
+  if (prev != device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int order,
+                     double *coefs_dev, double *err_dev, int *status_dev, int device, void *stream) {
+  if (!r_dev || !coefs_dev || !err_dev || !status_dev) return alz::fail(ALZ_E_ARG, "NULL argument");
+  if (n_lags < 1) return alz::fail(ALZ_E_ARG, "levinson: need at least lag 0");
+  int prev = 0;
+  ALZ_HIP_CHECK(hipGetDevice(&prev));
+  if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
+  int rc = alz::launch_lpc(r_dev, n_frames, n_lags, n_lags, order, coefs_dev, err_dev, status_dev,
+                           nullptr, 1, (hipStream_t)stream);
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }
@@ -137,7 +155,7 @@ int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, max_lag, nullptr, nullptr, nullptr,
-                           r_dev, (hipStream_t)stream);
+                           r_dev, 0, (hipStream_t)stream);
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }

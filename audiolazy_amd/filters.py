@@ -1,0 +1,424 @@
+"""ZFilter / z algebra, filter containers and the 1st/2nd-order designs.
+
+Host-side mirror of the reference's operator surface for the hot path
+(reference audiolazy/lazy_filters.py):
+
+  LinearFilter / ZFilter / z     :110-892   (+ - * / ** diff, numlist/denlist, call)
+  CascadeFilter, ParallelFilter  :970-1084
+  comb, resonator                :1087-1310
+  lowpass, highpass              :1313-1495
+
+Design and algebra run on the host in float64 and reproduce the reference's
+coefficients bit for bit (tests/test_designs_golden.py).  *Calling* a filter
+executes on the GPU through :class:`audiolazy_amd.bank.FilterBank`; there is no
+per-sample Python execution path in this package.
+"""
+import cmath
+import math
+import numbers
+
+from .poly import Poly
+from .strategy import StrategyDict
+
+__all__ = ["LinearFilter", "ZFilter", "z", "CascadeFilter", "ParallelFilter", "comb", "resonator",
+           "lowpass", "highpass"]
+
+
+class LinearFilter(object):
+  """A rational transfer function in ``z ** -1`` (reference lazy_filters.py:110-338).
+
+  ``numpoly`` / ``denpoly`` are :class:`Poly` in x = z ** -1; ``numlist`` /
+  ``denlist`` are the dense coefficient lists the engine consumes.
+  """
+
+  def __init__(self, numerator=None, denominator=None):
+    self.numpoly = Poly(numerator)
+    self.denpoly = Poly({0: 1} if denominator is None else denominator)
+
+  # -- coefficient views (reference :55-96) -------------------------------------
+  @staticmethod
+  def _causal_list(poly):
+    if any(k < 0 for k, _ in poly.terms()):
+      raise ValueError("Non-causal filter")
+    return poly.values()
+
+  @property
+  def numlist(self):
+    return self._causal_list(self.numpoly)
+
+  @property
+  def denlist(self):
+    return self._causal_list(self.denpoly)
+
+  numerator, denominator = numlist, denlist
+
+  @property
+  def numdict(self):
+    return dict(self.numpoly.terms())
+
+  @property
+  def dendict(self):
+    return dict(self.denpoly.terms())
+
+  def is_lti(self):
+    return True   # Stream-valued coefficients never get in (reference :303-314)
+
+  def is_causal(self):
+    return all(k >= 0 for k, _ in self.numpoly.terms())   # reference :316-325
+
+  def copy(self):
+    return type(self)(self.numpoly.copy(), self.denpoly.copy())
+
+  def __eq__(self, other):
+    return isinstance(other, LinearFilter) and self.numpoly == other.numpoly \
+        and self.denpoly == other.denpoly
+
+  def __ne__(self, other):
+    return not self == other
+
+  def __hash__(self):
+    return hash((self.numpoly, self.denpoly))
+
+  # -- analysis -----------------------------------------------------------------
+  def freq_response(self, freq):
+    """H(e^{j freq}), freq in rad/sample (reference :267-301); lists map elementwise."""
+    if isinstance(freq, (list, tuple)):
+      return [self.freq_response(f) for f in freq]
+    z_ = cmath.exp(-1j * freq)
+    den = self.denpoly(z_)
+    if den == 0:
+      return float("nan")
+    return self.numpoly(z_) / den
+
+  # -- execution ------------------------------------------------------------------
+  def __call__(self, seq, memory=None, zero=0.):
+    """IIR / FIR filtering of any iterable; returns a Stream (reference :141-264).
+
+    Same argument meaning and errors as the reference: ``memory`` holds past
+    outputs (first items used, left-padded with ``zero`` when short), ``zero``
+    is the value of every past input; non-causal -> ValueError, zero a0 ->
+    ZeroDivisionError.  Executed by the GPU engine in blocks.
+    """
+    if any(k < 0 for k, _ in self.numpoly.terms()) or any(k < 0 for k, _ in self.denpoly.terms()):
+      raise ValueError("Non-causal filter")
+    if self.denpoly[0] == 0:
+      raise ZeroDivisionError("Invalid filter gain")
+    from .bank import FilterBank
+    return FilterBank([(self.numlist or [0.], self.denlist)], n_inputs=1)(seq, memory=memory, zero=zero)
+
+
+class ZFilter(LinearFilter):
+  """Linear filter built with Z-transform algebra (reference :710-889).
+
+  ``ZFilter([b0, b1, ...], [a0, a1, ...])`` or expressions on :data:`z`, e.g.
+  ``(1 + z ** -1) / (1 - z ** -1)``.
+  """
+
+  # -- algebra (reference :744-838) ---------------------------------------------
+  @staticmethod
+  def _lift(other):
+    if isinstance(other, ZFilter):
+      return other
+    if isinstance(other, LinearFilter):
+      raise ValueError("Filter equations have different domains")
+    return ZFilter([other])
+
+  def __neg__(self):
+    return ZFilter(-self.numpoly, self.denpoly)
+
+  def __pos__(self):
+    return self
+
+  def __add__(self, other):
+    other = self._lift(other)
+    if self.denpoly == other.denpoly:
+      return ZFilter(self.numpoly + other.numpoly, self.denpoly)
+    return ZFilter(self.numpoly * other.denpoly + other.numpoly * self.denpoly,
+                   self.denpoly * other.denpoly)
+
+  def __radd__(self, other):
+    return self._lift(other) + self
+
+  def __sub__(self, other):
+    return self + (-self._lift(other))
+
+  def __rsub__(self, other):
+    return self._lift(other) + (-self)
+
+  def __mul__(self, other):
+    if isinstance(other, ZFilter):
+      return ZFilter(self.numpoly * other.numpoly, self.denpoly * other.denpoly)
+    if isinstance(other, LinearFilter):
+      raise ValueError("Filter equations have different domains")
+    return ZFilter(self.numpoly * other, self.denpoly)
+
+  def __rmul__(self, other):
+    return self._lift(other) * self
+
+  def __truediv__(self, other):
+    if isinstance(other, ZFilter):
+      return ZFilter(self.numpoly * other.denpoly, self.denpoly * other.numpoly)
+    if isinstance(other, LinearFilter):
+      raise ValueError("Filter equations have different domains")
+    return self * (1 / other)
+
+  def __rtruediv__(self, other):
+    return self._lift(other) / self
+
+  def __pow__(self, n):
+    if not isinstance(n, numbers.Real):
+      raise ValueError("Z-transform powers only valid with integers")
+    if n < 0 and (len(self.numpoly) >= 2 or len(self.denpoly) >= 2):
+      return ZFilter(self.denpoly, self.numpoly) ** -n
+    return ZFilter(self.numpoly ** n, self.denpoly ** n)
+
+  def diff(self, n=1, mul_after=1):
+    """n-th derivative with respect to z; every intermediate derivative is
+    multiplied by ``mul_after`` before the next one is taken (reference :819-838)."""
+    if isinstance(mul_after, ZFilter):
+      den = ZFilter(self.denpoly)
+      num = ZFilter(self.numpoly)
+      for order in range(1, n + 1):
+        num = mul_after * (num.diff() * den - order * num * den.diff())
+      return num / den ** (n + 1)
+    inv = Poly({-1: 1})   # the Poly variable is z ** -1
+    den = self.denpoly(inv)
+    num = self.numpoly(inv)
+    for order in range(1, n + 1):
+      num = mul_after * (num.diff() * den - order * num * den.diff())
+    return ZFilter(num(inv), self.denpoly ** (n + 1))
+
+  def __call__(self, seq, memory=None, zero=0.):
+    """Filter an iterable -- or, given a ZFilter, substitute it for z
+    (reference :840-889), e.g. ``filt(1 / z)`` reverses the coefficients."""
+    if isinstance(seq, ZFilter):
+      inv = 1 / seq
+      return self.numpoly(inv) / self.denpoly(inv)
+    return super(ZFilter, self).__call__(seq, memory=memory, zero=zero)
+
+  def __repr__(self):
+    return "ZFilter(%r, %r)" % (self.numlist if self.is_causal() else dict(self.numpoly.terms()),
+                                self.denpoly.values() if self.denpoly.is_polynomial()
+                                else dict(self.denpoly.terms()))
+
+
+z = ZFilter({-1: 1})   # z ** -1 is the unit delay: the Poly variable is x = z ** -1
+
+
+# ---------------------------------------------------------------------------
+# containers (reference :895-1084)
+# ---------------------------------------------------------------------------
+class FilterList(list):
+  """A list of filters; a single filter or an iterable of filters builds it."""
+
+  def __init__(self, *filters):
+    if len(filters) == 1 and not callable(filters[0]) and hasattr(filters[0], "__iter__"):
+      filters = filters[0]
+    super(FilterList, self).__init__(filters)
+
+  def is_linear(self):
+    return all(isinstance(f, LinearFilter) or (isinstance(f, FilterList) and f.is_linear()) for f in self)
+
+  def is_lti(self):
+    return self.is_linear() and all(f.is_lti() for f in self)
+
+  def is_causal(self):
+    return self.is_linear() and all(f.is_causal() for f in self)
+
+
+class CascadeFilter(FilterList):
+  """Filters applied one after the other; ``memory`` / ``zero`` are forwarded
+  unchanged to every stage (reference :970-1021, call :988-990).  A cascade of
+  linear filters runs as ONE fused bank on the GPU."""
+
+  def __call__(self, seq, memory=None, zero=0.):
+    if self.is_linear():
+      from .bank import FilterBank, sections_of
+      if len(self) == 0:
+        from .stream import Stream
+        return Stream(seq)
+      return FilterBank(sections_of(list(self)), n_inputs=1)(seq, memory=memory, zero=zero)
+    data = seq
+    for f in self:
+      data = f(data, memory=memory, zero=zero)
+    return data
+
+  @property
+  def numpoly(self):
+    out = Poly(1)
+    for f in self:
+      out = out * f.numpoly
+    return out
+
+  @property
+  def denpoly(self):
+    out = Poly(1)
+    for f in self:
+      out = out * f.denpoly
+    return out
+
+  def freq_response(self, freq):
+    out = 1.
+    for f in self:
+      out = out * f.freq_response(freq)
+    return out
+
+
+class ParallelFilter(FilterList):
+  """Filters fed with the same input, outputs summed ``((f1 + f2) + f3) ...``
+  (reference :1024-1084, call :1048-1054).  Runs as one OUTER bank on the GPU
+  followed by the ordered sum; an empty list yields ``zero`` per input item."""
+
+  def __call__(self, seq, memory=None, zero=0.):
+    from .stream import Stream
+    if len(self) == 0:
+      return Stream(zero for _ in seq)
+    data = list(seq)
+    outs = [list(f(data, memory=memory, zero=zero)) for f in self]
+    total = outs[0]
+    for other in outs[1:]:
+      total = [a + b for a, b in zip(total, other)]
+    return Stream(total)
+
+
+# ---------------------------------------------------------------------------
+# designs.  Formulas re-derived from the reference's docstrings / math/ notes and
+# evaluated in the same operation order so that the doubles come out identical.
+# ---------------------------------------------------------------------------
+comb = StrategyDict("comb")
+
+
+@comb.strategy("fb", "alpha", "fb_alpha", "feedback_alpha")
+def comb(delay, alpha=1):
+  """Feedback comb  y[n] = x[n] + alpha * y[n - delay]  (reference :1090-1118)."""
+  return 1 / (1 - alpha * z ** -delay)
+
+
+@comb.strategy("tau", "fb_tau", "feedback_tau")
+def comb(delay, tau=float("inf")):
+  """Feedback comb from the decay time tau, alpha = e ** (-delay / tau) (reference :1121-1147)."""
+  alpha = math.e ** (-delay / tau)
+  return 1 / (1 - alpha * z ** -delay)
+
+
+@comb.strategy("ff", "ff_alpha", "feedforward_alpha")
+def comb(delay, alpha=1):
+  """Feedforward comb  y[n] = x[n] + alpha * x[n - delay]  (reference :1150-1173)."""
+  return 1 + alpha * z ** -delay
+
+
+resonator = StrategyDict("resonator")
+
+
+@resonator.strategy("poles_exp")
+def resonator(freq, bandwidth):
+  """Two-pole resonator, 0 dB peak at the resonance (reference :1179-1209).
+  ``freq`` and ``bandwidth`` in rad/sample; pole radius R = exp(-bandwidth / 2)."""
+  R = math.exp(-bandwidth * .5)
+  cost = math.cos(freq) * (2 * R) / (1 + R ** 2)
+  gain = (1 - R ** 2) * math.sqrt(1 - cost ** 2)
+  return gain / (1 - 2 * R * cost * z ** -1 + R ** 2 * z ** -2)
+
+
+@resonator.strategy("freq_poles_exp")
+def resonator(freq, bandwidth):
+  """Two-pole resonator with the poles exactly at ``freq`` (reference :1212-1242)."""
+  R = math.exp(-bandwidth * .5)
+  gain = (1 - R ** 2) * math.sin(freq)
+  return gain / (1 - 2 * R * math.cos(freq) * z ** -1 + R ** 2 * z ** -2)
+
+
+@resonator.strategy("z_exp")
+def resonator(freq, bandwidth):
+  """Two poles plus zeros at DC and Nyquist, 0 dB at ``freq`` (reference :1245-1276)."""
+  R = math.exp(-bandwidth * .5)
+  cost = math.cos(freq) * (1 + R ** 2) / (2 * R)
+  gain = (1 - R ** 2) * .5
+  return gain * (1 - z ** -2) / (1 - 2 * R * cost * z ** -1 + R ** 2 * z ** -2)
+
+
+@resonator.strategy("freq_z_exp")
+def resonator(freq, bandwidth):
+  """As ``z_exp`` with the poles exactly at ``freq`` (reference :1279-1310)."""
+  R = math.exp(-bandwidth * .5)
+  gain = (1 - R ** 2) * .5
+  return gain * (1 - z ** -2) / (1 - 2 * R * math.cos(freq) * z ** -1 + R ** 2 * z ** -2)
+
+
+lowpass = StrategyDict("lowpass")
+highpass = StrategyDict("highpass")
+
+
+def _one_pole_radius(x):
+  return x - math.sqrt(x ** 2 - 1)
+
+
+@lowpass.strategy("pole")
+def lowpass(cutoff):
+  """One pole, exact -3 dB at ``cutoff`` rad/sample (reference :1370-1378)."""
+  R = _one_pole_radius(2 - math.cos(cutoff))
+  return (1 - R) / (1 - R * z ** -1)
+
+
+@highpass.strategy("pole")
+def highpass(cutoff):
+  """One pole highpass, mirror of lowpass.pole (reference :1381-1389)."""
+  R = _one_pole_radius(2 + math.cos(cutoff))
+  return (1 - R) / (1 + R * z ** -1)
+
+
+def _pole_zero_radius(num, cutoff):
+  den = math.cos(cutoff)
+  return num / (den if den else 1)   # numerator already zero there (reference :1399-1403)
+
+
+@lowpass.strategy("z")
+def lowpass(cutoff):
+  """One pole and a zero at Nyquist (reference :1392-1405)."""
+  R = _pole_zero_radius(math.sin(cutoff) - 1, cutoff)
+  gain = (1 + R) / 2
+  return gain * (1 + z ** -1) / (1 + R * z ** -1)
+
+
+@highpass.strategy("z")
+def highpass(cutoff):
+  """One pole and a zero at DC (reference :1408-1421)."""
+  R = _pole_zero_radius(1 - math.sin(cutoff), cutoff)
+  gain = (1 + R) / 2
+  return gain * (1 - z ** -1) / (1 - R * z ** -1)
+
+
+@lowpass.strategy("pole_exp")
+def lowpass(cutoff):
+  """Matched-Z one pole, R = e ** -cutoff (reference :1424-1437)."""
+  R = math.exp(-cutoff)
+  return (1 - R) / (1 - R * z ** -1)
+
+
+@highpass.strategy("pole_exp")
+def highpass(cutoff):
+  """Matched-Z one pole highpass, R = e ** (cutoff - pi) (reference :1440-1454)."""
+  R = math.exp(cutoff - math.pi)
+  return (1 - R) / (1 + R * z ** -1)
+
+
+@lowpass.strategy("z_exp")
+def lowpass(cutoff):
+  """Matched-Z pole plus zero at Nyquist (reference :1457-1472)."""
+  R = math.exp(cutoff - math.pi)
+  G = (R + 1) / 2
+  return G * (1 + z ** -1) / (1 + R * z ** -1)
+
+
+@highpass.strategy("z_exp")
+def highpass(cutoff):
+  """Matched-Z pole plus zero at DC (reference :1475-1490)."""
+  R = math.exp(-cutoff)
+  G = (R + 1) / 2
+  return G * (1 - z ** -1) / (1 - R * z ** -1)
+
+
+lowpass.default = lowpass.pole       # reference :1494
+highpass.default = highpass.z        # reference :1495
+comb.default = comb.fb
+resonator.default = resonator.poles_exp

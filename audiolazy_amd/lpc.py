@@ -92,3 +92,64 @@ def acorr_frames(sig, frame_len, max_lag, hop=None, device=0):
   _ffi.check(L.alz_acorr_dev(d_sig.ptr, F, frame_len, hop, max_lag, d_r.ptr, device, None))
   _ffi.check(L.alz_device_sync(device))
   return d_r.download((F, max_lag + 1), np.float64)
+
+
+# ---------------------------------------------------------------------------
+# the reference's single-block operator surface (lazy_analysis.py:277-312,
+# lazy_lpc.py:52-136, 229-272), executed on the GPU one frame at a time
+# ---------------------------------------------------------------------------
+def acorr(blk, max_lag=None):
+  """Autocorrelation of a block for lags 0..max_lag (default len(blk) - 1);
+  same summation order as the reference, so the doubles are identical."""
+  blk = [float(v) for v in blk]
+  if max_lag is None:
+    max_lag = len(blk) - 1
+  if len(blk) == 0:
+    return [0.] * (max_lag + 1)
+  if max_lag > 63:
+    raise NotImplementedError("acorr: more than 64 lags is outside the engine's gate")
+  return acorr_frames(blk, len(blk), max_lag)[0].tolist()
+
+
+def levinson_durbin(acdata, order=None, device=0):
+  """Solve the Yule-Walker equations for the lag list ``acdata``; returns the FIR
+  analysis filter as a ZFilter with the prediction error in ``.error``
+  (reference lazy_lpc.py:52-136).  Raises ParCorError like the reference."""
+  from .filters import ZFilter
+  L = _ffi.load()
+  acdata = np.ascontiguousarray([float(v) for v in acdata], dtype=np.float64)
+  if order is None:
+    order = len(acdata) - 1
+  d_r = _DevBuf(acdata.nbytes, device).upload(acdata)
+  d_c, d_e, d_s = _DevBuf((order + 1) * 8, device), _DevBuf(8, device), _DevBuf(4, device)
+  _ffi.check(L.alz_levinson_dev(d_r.ptr, 1, len(acdata), order, d_c.ptr, d_e.ptr, d_s.ptr, device, None))
+  _ffi.check(L.alz_device_sync(device))
+  _ffi.check(int(d_s.download((1,), np.int32)[0]))
+  filt = ZFilter(d_c.download((order + 1,), np.float64).tolist())
+  filt.error = float(d_e.download((1,), np.float64)[0])
+  return filt
+
+
+def _kautocor(blk, order, device=0):
+  """lpc.kautocor: autocorrelation method via Levinson-Durbin (reference
+  lazy_lpc.py:229-272).  Returns a ZFilter with ``.error``."""
+  from .filters import ZFilter
+  blk = [float(v) for v in blk]
+  coefs, err, status = kautocor_frames(blk, len(blk), order, device=device)
+  _ffi.check(int(status[0]))
+  filt = ZFilter(coefs[0].tolist())
+  filt.error = float(err[0])
+  return filt
+
+
+def _make_lpc():
+  from .strategy import StrategyDict
+  sd = StrategyDict("lpc")
+  sd.strategy("kautocor")(_kautocor)
+  return sd
+
+
+# Only the strategy BASELINE/SURVEY put on the hot path is here; the reference's default
+# (``lpc.autocor`` -> numpy.linalg.pinv, lazy_lpc.py:178-225) and the covariance methods are
+# out of scope (SURVEY.md section 2).
+lpc = _make_lpc()

@@ -125,6 +125,11 @@ const char *alz_bank_last_kernel(const alz_bank_t *h);
 int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                          int64_t hop, int order, double *coefs_dev,
                          double *err_dev, int *status_dev, int device, void *stream);
+/* levinson_durbin alone (lazy_lpc.py:52-136) on ready-made lag lists r [n_frames, n_lags];
+ * n_lags <= order is zero-extended like the reference does (:117-118). */
+int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int order,
+                     double *coefs_dev, double *err_dev, int *status_dev, int device,
+                     void *stream);
 /* acorr alone (lazy_analysis.py:277-312): r [n_frames, max_lag+1] */
 int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                   int64_t hop, int max_lag, double *r_dev, int device, void *stream);

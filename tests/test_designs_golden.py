@@ -1,0 +1,97 @@
+"""Host-side design functions and z algebra against the reference's coefficients
+(tests/golden/designs.json + auditory.json, produced by running the reference):
+every coefficient must be the same double (bit-exact)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, unhex
+from audiolazy_amd.filters import (z, ZFilter, CascadeFilter, ParallelFilter, comb, resonator,
+                                   lowpass, highpass)
+
+FNS = dict(comb=comb, resonator=resonator, lowpass=lowpass, highpass=highpass)
+
+
+def bits(v):
+  return np.asarray(v, dtype=np.float64).view(np.uint64).tolist()
+
+
+@pytest.mark.parametrize("case", load_golden("designs.json"),
+                         ids=lambda c: "%s.%s(%s)" % (c["fn"], c["strategy"], ",".join("%.4g" % v for v in unhex(c["args"]))))
+def test_design_coefficients_bit_exact(case):
+  args = unhex(case["args"])
+  if case["fn"] == "comb":
+    args[0] = int(args[0])
+  filt = getattr(FNS[case["fn"]], case["strategy"])(*args)
+  assert bits(filt.numlist) == bits(unhex(case["b"]))
+  assert bits(filt.denlist) == bits(unhex(case["a"]))
+
+
+def test_strategy_dict_surface():
+  assert lowpass.default is lowpass.pole and highpass.default is highpass.z    # lazy_filters.py:1494-1495
+  assert lowpass["pole"] is lowpass.pole
+  assert lowpass(0.3).numlist == lowpass.pole(0.3).numlist
+  assert comb.fb is comb.alpha and resonator.default is resonator.poles_exp
+
+
+def test_z_algebra_known_answers():
+  f = (1 + z ** -1) / (1 - z ** -1)            # lazy_filters.py:722-726
+  assert f.numlist == [1, 1] and f.denlist == [1, -1]
+  assert (z ** -3 + 0.).numlist == [0., 0., 0., 1]
+  g = ZFilter([.2, .3, .4], [2., -.5, .25])
+  assert (g * z ** -1).numlist == [0., .2, .3, .4]
+  assert (g + g).numlist == [.4, .6, .8]          # same denominator: numerators add (:745-747)
+  p = lowpass.pole(.2) ** 2
+  assert len(p.denlist) == 3 and len(p.numlist) == 1
+  assert (1 / z).denpoly[-1] == 1 and (z ** -1).numlist == [0., 1]
+  with pytest.raises(ValueError):
+    (z ** 2).numlist                              # non-causal (:55-67)
+  # substitution z -> 1/z reverses a polynomial (used by levinson_durbin, lazy_lpc.py:129)
+  A = 1 - 0.5 * z ** -1 + 0.25 * z ** -2
+  B = A(1 / z) * z ** -2
+  assert B.numlist == [0.25, -0.5, 1]
+
+
+def test_freq_response_properties():
+  # reference tests/test_filters.py:569-599: resonators have 0 dB at `freq`
+  for strat in ("poles_exp", "z_exp"):
+    for f in (0.1, 0.5, 1.5, 2.5):
+      filt = getattr(resonator, strat)(f, f / 10)
+      assert 20 * math.log10(abs(filt.freq_response(f))) == pytest.approx(0., abs=1e-10)
+  # tests/test_filters.py:604-663: -3.0103 dB at the cutoff for the exact designs
+  for sd in (lowpass.pole, lowpass.z, highpass.pole, highpass.z):
+    for wc in (0.05, 0.4, 1.0, 2.0, 3.0):
+      h = sd(wc).freq_response(wc)
+      assert 20 * math.log10(abs(h)) == pytest.approx(-3.0103, abs=1e-3)
+
+
+def test_gammatone_designs_bit_exact():
+  from audiolazy_amd.auditory import gammatone
+  aud = load_golden("auditory.json")
+  worst = 0
+  for g in aud["gammatone"]:
+    filt = getattr(gammatone, g["strategy"])(unhex(g["freq"]), unhex(g["bw"]))
+    assert len(filt) == 4                      # reference tests/test_auditory.py:78-92
+    for sec, ref in zip(filt, g["sections"]):
+      assert len(sec.denlist) == 3
+      b, a = np.array(sec.numlist), np.array(sec.denlist)
+      rb, ra = np.array(unhex(ref["b"])), np.array(unhex(ref["a"]))
+      assert b.shape == rb.shape
+      assert bits(a) == bits(ra), g["strategy"]
+      assert bits(b) == bits(rb), g["strategy"]
+
+
+def test_erb_and_constants():
+  from audiolazy_amd.auditory import erb, gammatone_erb_constants
+  aud = load_golden("auditory.json")
+  for c in aud["erb"]:
+    args = [unhex(c["freq"])] + ([unhex(c["Hz"])] if "Hz" in c else [])
+    assert getattr(erb, c["strategy"])(*args) == unhex(c["value"])
+  for c in aud["consts"]:
+    assert list(gammatone_erb_constants(c["n"])) == unhex(c["value"])
+  # reference tests/test_auditory.py:39-44
+  assert erb(1000.) == pytest.approx(132.639, abs=5e-4)
+  assert erb(3000.) == pytest.approx(348.517, abs=5e-4)
+  with pytest.raises(ValueError):
+    erb(3.)                                    # "Frequency out of range", lazy_auditory.py:65-67

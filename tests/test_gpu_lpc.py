@@ -82,3 +82,26 @@ def test_order_above_31_uses_64_lane_slots(lpc):
   rc, re, rst = oracle.kautocor_frames(sig, F, L, L, order)
   assert (st == 0).all()
   assert (np.abs(c - rc).max(axis=1) / np.abs(rc).max(axis=1)).max() <= 1e-7
+
+
+def test_reference_operator_surface(lpc):
+  """acorr / levinson_durbin / lpc.kautocor as single-block callables returning what the
+  reference returns (a list; a ZFilter with .error)."""
+  import audiolazy_amd as alz
+  assert alz.acorr([1, 2, 3, 4, 3, 4, 2]) == [59, 52, 42, 30, 17, 8, 2]      # lazy_analysis.py:298-306
+  assert alz.acorr([1, 2, 3, 4, 3, 4, 2], 9)[-3:] == [0, 0, 0]
+  f = alz.levinson_durbin([12, 6, 0, -3, -6, -3, 0, 2, 4, 2], 3)              # lazy_lpc.py:99-107
+  np.testing.assert_allclose(f.numlist, [1, -0.625, 0.25, 0.125], atol=1e-14)
+  assert f.error == pytest.approx(7.875, rel=1e-13) and f.denlist == [1]
+  f = alz.levinson_durbin([1., 5., 3.])                                       # tests/test_lpc.py:280-290
+  np.testing.assert_allclose(f.numlist, [1, -5. / 12, -11. / 12], rtol=1e-13)
+  f = alz.levinson_durbin([1., .5], 3)                                        # zero-extended lags (:117-118)
+  np.testing.assert_allclose(f.numlist, [1, -.5], atol=1e-15)
+  g = alz.lpc.kautocor([-1., 0., 1., 0.] * 4, 2)                             # tests/test_lpc.py:218-224
+  np.testing.assert_allclose(g.numlist, [1, 0, .875], atol=1e-14)
+  assert g.error == pytest.approx(1.875, rel=1e-13)
+  assert alz.lpc([-1., 0., 1., 0.] * 4, 2).numlist == g.numlist
+  with pytest.raises(alz.ParCorError):                                        # lazy_lpc.py:132-133
+    alz.lpc.kautocor([0.] * 32, 4)
+  with pytest.raises(ZeroDivisionError):
+    alz.levinson_durbin([0., 0., 0.])
