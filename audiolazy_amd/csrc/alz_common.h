@@ -56,6 +56,10 @@ struct BlockIO {
 // alz_iir.hip: any section shape, channels [c_first, c_first + c_count)
 int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
                    const char **kernel_name);
+// alz_fir.hip: long feedback-free sections on time-major blocks (x != y); *taken says whether
+// the shape was this kernel's
+int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
+               const char **kernel_name);
 // alz_wave.hip: the streaming kernel takes the full tiles of the full channel groups it
 // can and reports how much that was; the caller finishes the rest with launch_section
 int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,

@@ -305,7 +305,11 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
     hipLaunchKernelGGL((k_masked<16, 9>), grid, block, 0, stream, p);
     *kernel_name = "k_masked<16,9>";
   } else {
-    if (io.x == io.y) return fail(ALZ_E_ARG, "k_generic cannot run in place");
+    if (io.x == io.y) return fail(ALZ_E_ARG, "k_fir / k_generic cannot run in place");
+    bool taken = false;
+    int rc = launch_fir(sec, io, stream, &taken, kernel_name);
+    if (rc) return rc;
+    if (taken) return ALZ_OK;
     const int64_t nx = (int64_t)(sec.nb - 1) * io.channels;
     const int64_t ny = (int64_t)(sec.na - 1) * io.channels;
     double *xh_new = sec.xh + nx, *yh_new = sec.yh + ny;

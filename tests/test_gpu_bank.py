@@ -183,7 +183,7 @@ def test_mixed_zero_patterns_use_masked_kernel(alz, oracle):
 
 
 @pytest.mark.parametrize("nb,na,kern", [(8, 3, "k_masked<8,3>"), (12, 7, "k_masked<16,9>"),
-                                        (40, 12, "k_generic"), (300, 1, "k_generic")])
+                                        (40, 12, "k_generic"), (300, 1, "k_fir")])
 def test_higher_orders(alz, oracle, nb, na, kern):
   rng = np.random.default_rng(nb * 100 + na)
   C, N = 70, 700
@@ -259,3 +259,99 @@ def test_full_scale_properties(alz):
   y4 = bank.process(x * 4.0)            # scaling by a power of two is exact in binary64
   assert torch.equal(y4, y * 4.0)
   assert torch.isfinite(y).all()
+
+
+def hamming_sinc(ntaps=256, fc=0.1):
+  """256-point Hamming-windowed sinc lowpass at 0.1 fs, plain float64."""
+  import math
+  m = (ntaps - 1) / 2.0
+  taps = []
+  for i in range(ntaps):
+    t = i - m
+    ideal = 2 * fc if t == 0 else math.sin(2 * math.pi * fc * t) / (math.pi * t)
+    taps.append(ideal * (0.54 - 0.46 * math.cos(2 * math.pi * i / (ntaps - 1))))
+  return taps
+
+
+@pytest.mark.parametrize("C,N", [(64, 300), (200, 1000), (130, 77)])
+def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
+  rng = np.random.default_rng(C + N)
+  taps = np.array(hamming_sinc())
+  x = rng.uniform(-1, 1, (N, C))
+  bank = alz.FilterBank([(taps, [1.0])], n_inputs=C)
+  bank.reset(zero=0.125)
+  y = bank.process(x)
+  assert bank.last_kernel == "k_fir<shared>"
+  ref = oracle.bank([256], [1], taps, np.array([1.0]), x, xh=np.full((C, 255), 0.125), zero=0.125)
+  assert same_bits(y, ref)
+  # blocks continue the stream (history kept on the device), including blocks shorter than the taps
+  x2 = rng.uniform(-1, 1, (40, C))
+  x3 = rng.uniform(-1, 1, (500, C))
+  whole = oracle.bank([256], [1], taps, np.array([1.0]), np.concatenate([x, x2, x3]),
+                      xh=np.full((C, 255), 0.125), zero=0.125)
+  assert same_bits(bank.process(x2), whole[N:N + 40])
+  assert same_bits(bank.process(x3), whole[N + 40:])
+  # channel-major blocks take the catch-all kernel, same numbers
+  bank.reset(zero=0.125)
+  yc = bank.process(np.ascontiguousarray(x.T), layout="chan")
+  assert "k_generic" in bank.last_kernel and same_bits(yc, ref.T)
+
+
+def test_fir_per_channel_taps_zero_taps_and_gain(alz, oracle):
+  rng = np.random.default_rng(77)
+  C, N, nb = 96, 400, 40
+  b = rng.uniform(-1, 1, (C, nb))
+  b[::3, 5] = 0.0
+  b[1::5, 0] = 0.0
+  b[7] = 0.0                                   # all-zero channel -> yields `zero`
+  a = rng.uniform(0.5, 2.0, (C, 1))
+  x = rng.uniform(-1, 1, (N, C))
+  x[100, 9] = np.inf                           # b[9, 5] == 0: the inf must not reach y through that tap
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset(zero=-0.5)
+  y = bank.process(x)
+  assert bank.last_kernel == "k_fir<per-channel>"
+  ref = oracle.bank([nb], [1], b, a, x, xh=np.full((C, nb - 1), -0.5), zero=-0.5)
+  assert same_bits(y, ref)
+  assert np.all(y[:, 7] == -0.5)
+
+
+def test_fir_in_a_cascade_and_outer_mode(alz, oracle):
+  rng = np.random.default_rng(5)
+  S, N = 40, 600
+  taps = np.array(hamming_sinc(64, 0.2))
+  x = rng.uniform(-1, 1, (N, S))
+  secs = [([0.5, 0.25], [1.0, -0.3]), (taps, [1.0])]   # IIR then FIR: second stage runs "in place"
+  bank = alz.FilterBank(secs, n_inputs=S)
+  bank.reset()
+  y = bank.process(x)
+  ref = oracle.bank([2, 64], [2, 1], np.concatenate([[0.5, 0.25], taps]), np.array([1.0, -0.3, 1.0]), x)
+  assert same_bits(y, ref)
+  two = np.stack([taps, taps[::-1] * 0.5])
+  fb = alz.FilterBank([(two, [1.0])], n_inputs=S, mode="outer")
+  fb.reset()
+  yo = fb.process(x)
+  for band in range(2):
+    assert same_bits(yo[:, band * S:(band + 1) * S], oracle.bank([64], [1], two[band], np.array([1.0]), x))
+
+
+def test_fir_config3_width_properties(alz):
+  """BASELINE cfg3 width (8192 channels, 256 shared taps): linearity and block-split invariance."""
+  import torch
+  C, N = 8192, 2048
+  bank = alz.FilterBank([(hamming_sinc(), [1.0])], n_inputs=C)
+  g = torch.Generator(device="cuda").manual_seed(9)
+  x = torch.rand((N, C), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+  bank.reset()
+  y = bank.process(x)
+  bank.reset()
+  y2 = torch.cat([bank.process(x[:700].contiguous()), bank.process(x[700:].contiguous())])
+  assert torch.equal(y, y2)
+  bank.reset()
+  assert torch.equal(bank.process(x * 0.5), y * 0.5)
+  # a unit impulse on one channel reproduces the taps (tests/test_filters.py:76-107 style)
+  imp = torch.zeros((300, C), dtype=torch.float64, device="cuda")
+  imp[0, 123] = 1.0
+  bank.reset()
+  h = bank.process(imp)[:, 123].cpu().numpy()
+  assert np.array_equal(h[:256], np.array(hamming_sinc())) and np.all(h[256:] == 0)
