@@ -70,27 +70,47 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
 #pragma unroll
     for (int r = 0; r < kFirR; ++r) acc[r] = -0.0;
 
+    // x window: xw[j] = row t0 - kb - (K-1) + j, j = 0 .. R+K-2.  Going to the next tap block
+    // moves the window K rows into the past: R-1 rows are kept (register moves), K are loaded.
+    double xw[kFirR + kFirK - 1];
+    auto load_row = [&](int64_t t) -> double {
+      if (t > p.n - 1) t = p.n - 1;                         // past the block: value is never used
+      int64_t hk = -t - 1;                                  // before the stream: history row
+      if (hk > p.nb - 2) hk = p.nb - 2;                     // beyond the delay line: never used
+      const double *src = (t >= 0) ? p.x + t * p.sxn + in : p.xh + (hk < 0 ? 0 : hk) * p.channels + c;
+      return *src;
+    };
+#pragma unroll
+    for (int j = kFirK; j < kFirR + kFirK - 1; ++j) xw[j] = load_row(t0 - (kFirK - 1) + j);
     for (int kb = 0; kb < p.nb; kb += kFirK) {
-      // rows t0 - kb - (K-1) + j,  j = 0 .. R+K-2
-      double xw[kFirR + kFirK - 1];
+      if (kb > 0) {
 #pragma unroll
-      for (int j = 0; j < kFirR + kFirK - 1; ++j) {
-        int64_t t = t0 - kb - (kFirK - 1) + j;
-        if (t > p.n - 1) t = p.n - 1;                       // past the block: value is never used
-        const int64_t hk = (-t - 1 < p.nb - 1) ? -t - 1 : p.nb - 2;   // before the stream: history row
-        const double *src = (t >= 0) ? p.x + t * p.sxn + in : p.xh + (hk < 0 ? 0 : hk) * p.channels + c;
-        xw[j] = *src;
+        for (int j = kFirR + kFirK - 2; j >= kFirK; --j) xw[j] = xw[j - kFirK];
       }
+      const int64_t tb = t0 - kb - (kFirK - 1);
+      if (tb >= 0) {                                        // whole row group inside the block
+        const double *r0 = p.x + tb * p.sxn + in;
 #pragma unroll
-      for (int kk = 0; kk < kFirK; ++kk) {
-        const int k = kb + kk;
-        if (k >= p.nb) break;
-        if constexpr (SHARED) {
-          const double bk = p.b[k];                         // wave-uniform: scalar load
-          if (bk == 0.0) continue;
+        for (int j = 0; j < kFirK; ++j) xw[j] = r0[j * p.sxn];
+      } else {                                              // reaches into the history rows
 #pragma unroll
-          for (int r = 0; r < kFirR; ++r) acc[r] = acc[r] + bk * xw[r - kk + (kFirK - 1)];
-        } else {
+        for (int j = 0; j < kFirK; ++j) xw[j] = load_row(tb + j);
+      }
+      if constexpr (SHARED) {
+        double bk[kFirK];                                   // wave-uniform taps: scalar loads
+#pragma unroll
+        for (int kk = 0; kk < kFirK; ++kk) bk[kk] = (kb + kk < p.nb) ? p.b[kb + kk] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < kFirK; ++kk) {
+          if (bk[kk] == 0.0) continue;                      // absent from the reference's sum
+#pragma unroll
+          for (int r = 0; r < kFirR; ++r) acc[r] = acc[r] + bk[kk] * xw[r - kk + (kFirK - 1)];
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < kFirK; ++kk) {
+          const int k = kb + kk;
+          if (k >= p.nb) break;
           const double bk = p.b[(int64_t)k * p.n_sets + set];
           const bool nz = bk != 0.0;
 #pragma unroll

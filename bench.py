@@ -47,6 +47,18 @@ def resonator_coefs(C, fs=48000.0):
     return np.stack([g, np.zeros(C), -g], axis=1), a
 
 
+def fir_taps(ntaps=256, fc=0.1):
+  """256-point Hamming-windowed sinc lowpass at 0.1 fs in plain float64."""
+  import math
+  m = (ntaps - 1) / 2.0
+  out = []
+  for i in range(ntaps):
+    t = i - m
+    ideal = 2 * fc if t == 0 else math.sin(2 * math.pi * fc * t) / (math.pi * t)
+    out.append(ideal * (0.54 - 0.46 * math.cos(2 * math.pi * i / (ntaps - 1))))
+  return np.array(out)
+
+
 def cpu_baseline(b, a, n_samples, budget_s=12.0):
   """The oracle (a C port of the reference's generated loop, 1 thread) on a bounded
   sample of the same workload: 64 channels x n_samples, repeated until ~budget_s."""
@@ -80,6 +92,8 @@ def main():
   ap.add_argument("--log2-samples", type=int, default=20, help="block length per channel = 2**this")
   ap.add_argument("--layout", choices=["time", "chan"], default="time")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--workload", choices=["biquad", "fir"], default="biquad",
+                  help="biquad = configs[1] (the contract line); fir = configs[2], 256 shared taps x 8192 ch")
   args = ap.parse_args()
 
   import torch
@@ -97,10 +111,18 @@ def main():
   dev = torch.device("cuda", local)
 
   C, N = args.channels, 1 << args.log2_samples
-  # the global bank has world*C channels; this rank owns the contiguous shard [rank*C, (rank+1)*C)
-  b_all, a_all = resonator_coefs(world * C)
-  b, a = b_all[rank * C:(rank + 1) * C], a_all[rank * C:(rank + 1) * C]
-  bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
+  if args.workload == "fir":
+    if args.channels == 4096 and args.log2_samples == 20:   # configs[2] defaults
+      C, N = 8192, 1 << 18
+    b, a = fir_taps(), np.array([1.0])
+    bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
+    nsec = ([256], [1])
+  else:
+    # the global bank has world*C channels; this rank owns the contiguous shard [rank*C, (rank+1)*C)
+    b_all, a_all = resonator_coefs(world * C)
+    b, a = b_all[rank * C:(rank + 1) * C], a_all[rank * C:(rank + 1) * C]
+    bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
+    nsec = ([3], [3])
   bank.reset()
 
   shape = (N, C) if args.layout == "time" else (C, N)
@@ -148,7 +170,7 @@ def main():
       bank.reset()
       xs = x[:nchk].contiguous() if args.layout == "time" else x[:, :nchk].contiguous()
       ys = bank.process(xs, layout=args.layout).cpu().numpy()
-      ref = oracle.bank([3], [3], b, a, xs.cpu().numpy(), layout=args.layout)
+      ref = oracle.bank(nsec[0], nsec[1], b, a, xs.cpu().numpy(), layout=args.layout)
       parity = "bit-exact" if np.array_equal(ys.view(np.uint64), ref.view(np.uint64)) else "MISMATCH"
     except Exception as exc:  # the oracle is a checker, never a dependency of the timed path
       parity = "unchecked (%s)" % exc
@@ -158,22 +180,36 @@ def main():
     value = samples / elapsed / 1e9
     k_avg_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = ALG_BYTES_PER_SAMPLE * C * N / (k_avg_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N}
+    workload = ("configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), 48 kHz float64, "
+                "%d-sample blocks, 1 MI355X per rank" % (C, N))
+    metric = "Gsamples/s through ZFilter IIR biquad bank"
+    if args.workload == "fir":
+      # 256 mul + 255 add per output sample, unfused (bit-exact mode): FP64 vector issue is the
+      # roof (78.6 TFLOP/s spec, MI355X_MICROARCH.md / SURVEY.md 8d), not HBM
+      flops = 511.0 * C * N
+      tf = flops / (k_avg_ms * 1e-3) / 1e12
+      roof = {"bound": "valu_f64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+              "traffic": None, "kernel_ms_avg": k_avg_ms, "algorithmic_flops_per_launch": flops,
+              "hbm_GBps": achieved}
+      workload = ("configs[2]: 256-tap FIR lowpass (Hamming-windowed sinc, shared taps) x %d channels, "
+                  "float64, %d-sample blocks, 1 MI355X per rank" % (C, N))
+      metric = "Gsamples/s through ZFilter FIR-256 bank"
     out = {
-      "metric": "Gsamples/s through ZFilter IIR biquad bank",
+      "metric": metric,
       "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps,
       "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "f64", "data": "synthetic",
-      "config": {"workload": "configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), "
-                             "48 kHz float64, %d-sample blocks, 1 MI355X per rank" % (C, N),
+      "config": {"workload": workload,
                  "channels_per_gpu": C, "block_samples": N,
                  "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
                  "kernel": kernel_name, "parity_spot_check": parity},
-      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                   "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N},
+      "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.workload == "biquad":
       out["cpu_baseline"] = cpu_baseline(b, a, N)
     print(json.dumps(out))
   if world > 1:
