@@ -1,0 +1,101 @@
+"""Channel sharding across the GPUs of a node (one process per GPU).
+
+The filter path has no exchange step: channels (cfg2/3), input streams of a filterbank
+(cfg4) and frames (cfg5) are independent units, so every rank filters its own contiguous
+shard with no data-path collective.  The only collective offered is the one
+a *downstream* consumer may need -- all channels of a block on every rank / on one rank, or
+the ParallelFilter-style sum over bands -- as a single torch.distributed call (backend
+"nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+Nothing here touches the reference's algorithms: the reference is single-process
+(lazy_stream.py:114 "not thread-safe"), this module is the MI355X-side scale-out.
+"""
+import os
+
+
+def world_info():
+  """(rank, world_size, local_rank) from the torchrun environment (defaults: single process)."""
+  return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+          int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_range(n_units, world, rank):
+  """Contiguous balanced shard [start, stop) of ``n_units`` for ``rank``: the first
+  ``n_units % world`` ranks get one extra unit; every unit belongs to exactly one rank."""
+  if world < 1 or not 0 <= rank < world:
+    raise ValueError("bad rank/world")
+  base, extra = divmod(n_units, world)
+  start = rank * base + min(rank, extra)
+  return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n_units, world):
+  return [shard_range(n_units, world, r)[1] - shard_range(n_units, world, r)[0] for r in range(world)]
+
+
+def local_bank(sections, n_channels, rank=None, world=None, device=None, **kwargs):
+  """The FilterBank for this rank's shard of a DIAGONAL bank.
+
+  sections: [(b, a), ...] with b/a either shared ([nb]) or per channel ([n_channels, nb]);
+  per-channel rows are sliced to the shard.  Returns (bank, (start, stop)).
+  """
+  import numpy as np
+  from .bank import FilterBank
+  r, w, local = world_info()
+  rank = r if rank is None else rank
+  world = w if world is None else world
+  device = local if device is None else device
+  start, stop = shard_range(n_channels, world, rank)
+  secs = []
+  for b, a in sections:
+    b, a = np.asarray(b, dtype=np.float64), np.asarray(a, dtype=np.float64)
+    secs.append((b[start:stop] if b.ndim == 2 else b, a[start:stop] if a.ndim == 2 else a))
+  return FilterBank(secs, n_inputs=stop - start, device=device, **kwargs), (start, stop)
+
+
+def gather_channels(y_local, n_channels, channel_dim=-1, group=None, dst=None):
+  """Assemble the full-width block from the per-rank shards along ``channel_dim``.
+
+  y_local : torch tensor holding this rank's channels [.., stop - start, ..].
+  dst None -> every rank gets the full block (all_gather); dst = r -> only rank r does
+  (gather; others get None).  Shards may be ragged: they are padded to the largest shard
+  for the collective and trimmed afterwards.
+  """
+  import torch
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return y_local
+  world, rank = dist.get_world_size(group), dist.get_rank(group)
+  sizes = shard_sizes(n_channels, world)
+  biggest = max(sizes)
+  moved = y_local.movedim(channel_dim, 0).contiguous()
+  if moved.shape[0] != sizes[rank]:
+    raise ValueError("rank %d holds %d channels, its shard has %d" % (rank, moved.shape[0], sizes[rank]))
+  if moved.shape[0] < biggest:
+    pad = torch.zeros((biggest - moved.shape[0],) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
+    moved = torch.cat([moved, pad])
+  if dst is None:
+    parts = [torch.empty_like(moved) for _ in range(world)]
+    dist.all_gather(parts, moved, group=group)
+  else:
+    parts = [torch.empty_like(moved) for _ in range(world)] if rank == dst else None
+    dist.gather(moved, parts, dst=dst, group=group)
+    if rank != dst:
+      return None
+  full = torch.cat([p[:n] for p, n in zip(parts, sizes)])
+  return full.movedim(0, channel_dim)
+
+
+def mixdown(y_local, group=None, dst=None):
+  """Sum of every rank's block (ParallelFilter / Streamix-style mix over shards): all_reduce,
+  or reduce to ``dst``.  Note the summation order across ranks is the collective's, so this is
+  floating-point (not bit-exact) with respect to a single-process left-to-right sum."""
+  import torch.distributed as dist
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return y_local
+  out = y_local.clone()
+  if dst is None:
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
+  dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM, group=group)
+  return out if dist.get_rank(group) == dst else None
