@@ -296,6 +296,192 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// k_duo: the same streaming scheme with the work split over the two waves of a workgroup.
+//
+//   AUX wave  queues the tile DMA, waits for it, computes the feed-forward sums
+//             p[n] = b0*x[n] (+ b1*x[n-1]) (+ b2*x[n-2]) for a whole tile with all 64 lanes
+//             (time-parallel: 16 channels x 4 row blocks), and stores finished y tiles;
+//   REC wave  runs only the serial part  y[n] = (p[n] + (-a1)*y[n-1]) + (-a2)*y[n-2]
+//             (4 f64 ops and one LDS read per step, one row-select LDS write per 4 steps).
+//
+// p and the recurrence term order are exactly the reference's left-to-right sum (numerator
+// terms first, lazy_filters.py:198-224), so the split changes nothing numerically.  The waves
+// meet at one s_barrier per tile: while REC works on tile i, AUX stores tile i-1, queues tile
+// i+3 and prepares p for tile i+1.  LDS: a 4-slot x ring (DMA target) + a 3-slot p/y ring.
+// G = 16 channels per workgroup (the REC wave's other 48 lanes are ghosts as in k_wave).
+// ---------------------------------------------------------------------------
+static constexpr int kXRing = 4, kPRing = 3;
+
+template <bool CM, unsigned PB, unsigned PA>
+__global__ __launch_bounds__(128) void k_duo(WArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 16, T = 64;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int cl = lane & 15, q = lane >> 4;
+  const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
+  const int64_t c = c0 + cl;
+  const int64_t set = (p.n_sets == 1) ? 0 : c;
+  const int64_t nt = p.n_tiles;
+  char *xring = smem;
+  char *pring = smem + kXRing * kSlotBytes;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  // byte offset of element (row/sample u, channel cl) inside a slot
+  const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
+#define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+
+  if (wave == 1) {
+    // ------------------------------ AUX ------------------------------
+    int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+    if (!CM) {
+      const int row = lane / 8, cp = lane % 8;
+      x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
+      y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+      x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
+      x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
+    } else {
+      const int ch = lane / 32, sp = lane % 32;
+      x_off = (c0 + ch) * p.ldx + 2 * sp;
+      y_off = (c0 + ch) * p.ldy + 2 * sp;
+      x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
+      x_tile = T; y_tile = T;
+    }
+    double b0 = 0, b1 = 0, b2 = 0;
+    if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
+    if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
+    if (PB & 4u) b2 = p.b[2 * p.n_sets + set];
+    double d1 = (p.nb > 1) ? p.xh[0 * p.channels + c] : 0.0;   // x[-1], x[-2] of the stream
+    double d2 = (p.nb > 2) ? p.xh[1 * p.channels + c] : 0.0;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(d1), "+v"(d2));
+    const double *xg = p.x + x_off;
+    double *yg = p.y + y_off;
+
+    auto queue_tile = [&](int64_t t) {
+      const int s = (int)(t % kXRing);
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j)
+        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlotBytes + j * 1040);
+    };
+    // feed-forward of tile t: lane (q, cl) owns rows 16q .. 16q+15 of channel cl
+    auto feed_forward = [&](int64_t t) {
+      const char *xs = xring + (int)(t % kXRing) * kSlotBytes + lane_off;
+      const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kSlotBytes + lane_off;  // tile t-1
+      char *ps = pring + (int)(t % kPRing) * kSlotBytes + lane_off;
+      double xv[18];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xv[j + 2] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q + j));
+      if (q > 0) {
+        xv[1] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q - 1));
+        xv[0] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q - 2));
+      } else if (t > 0) {
+        xv[1] = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1));
+        xv[0] = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2));
+      } else {
+        xv[1] = d1;
+        xv[0] = d2;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double acc = 0.0;
+        bool first = true;
+        if constexpr (PB & 1u) { acc = b0 * xv[j + 2]; first = false; }
+        if constexpr (PB & 2u) { const double v = b1 * xv[j + 1]; acc = first ? v : acc + v; first = false; }
+        if constexpr (PB & 4u) { const double v = b2 * xv[j]; acc = first ? v : acc + v; first = false; }
+        *reinterpret_cast<double *>(ps + ALZ_EOFF(16 * q + j)) = acc;
+      }
+    };
+    auto store_tile = [&](int64_t t) {
+      const char *ps = pring + (int)(t % kPRing) * kSlotBytes;
+      double *yt = yg + t * y_tile;
+      dbl2 v[kChunks];
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ps + j * 1040 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
+    };
+
+    for (int t = 0; t < kXRing - 1 && t < nt; ++t) queue_tile(t);
+    wait_vm((int)((nt < kXRing - 1 ? nt : kXRing - 1) - 1) * kChunks);   // tile 0 has landed
+    feed_forward(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int64_t i = 0; i < nt; ++i) {
+      if (i >= 1) store_tile(i - 1);
+      if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
+      if (i + 1 < nt) {
+        const int64_t last = (i + 3 < nt - 1) ? i + 3 : nt - 1;
+        const int64_t dma_after = last - (i + 1);
+        const int64_t stores_after = i < 2 ? i : 2;
+        wait_vm((int)(dma_after + stores_after) * kChunks);
+        feed_forward(i + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    store_tile(nt - 1);
+    // input history for the next block: the last two x samples (held by the q == 3 lanes)
+    if (q == 3) {
+      const char *xs = xring + (int)((nt - 1) % kXRing) * kSlotBytes + lane_off;
+      if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
+      if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    // ------------------------------ REC ------------------------------
+    double na1 = 0, na2 = 0;
+    if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
+    if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
+    double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
+    double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
+    __builtin_amdgcn_s_barrier();                            // p of tile 0 is ready
+    for (int64_t i = 0; i < nt; ++i) {
+      char *tile = pring + (int)(i % kPRing) * kSlotBytes;
+      const char *rd = tile + lane_off;
+      char *wr = tile + lane_off + (CM ? q * 8 : q * G * 8);  // lane group q owns row q of each 4
+      constexpr int NCH = T / 8;
+      double pr[3][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[0][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(u));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(8 + u));
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (k + 2 < NCH) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          double acc = pr[k % 3][u];
+          if constexpr (PA & 1u) acc = acc + na1 * m1;
+          if constexpr (PA & 2u) acc = acc + na2 * m2;
+          yv[u] = acc;
+          m2 = m1; m1 = acc;
+          if ((u & 3) == 3) {
+            double yw = yv[u - 3];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) yw = (q == r) ? yv[u - 3 + r] : yw;
+            *reinterpret_cast<double *>(wr + ALZ_EOFF(k * 8 + u - 3)) = yw;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // y of tile i done, p of tile i+1 ready
+    }
+    if (lane < G) {
+      if (p.na > 1) p.yh[0 * p.channels + c] = m1;
+      if (p.na > 2) p.yh[1 * p.channels + c] = m2;
+    }
+  }
+#undef ALZ_EOFF
+}
+
+// ---------------------------------------------------------------------------
 // dispatch: curated tap patterns (everything else stays on k_small)
 // ---------------------------------------------------------------------------
 typedef void (*wave_fn)(WArgs);
@@ -313,6 +499,15 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   ALZ_PAT(1, 2)  // b0           /    a2
   ALZ_PAT(7, 0)  // 3-tap FIR
   ALZ_PAT(3, 0)  // 2-tap FIR
+#undef ALZ_PAT
+  return nullptr;
+}
+
+template <bool CM>
+static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
+#define ALZ_PAT(PB_, PA_) \
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_>;
+  ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
 }
@@ -348,7 +543,12 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   const int t = 8192 / (8 * g);
   const int64_t tiles = io.n / t;
   if (groups == 0 || tiles == 0) return ALZ_OK;
-  wave_fn fn = pick_wave(g, cm, sec.present_b, sec.present_a);
+  // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
+  static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
+  wave_fn duo = (g == 16 && duo_env) ? (cm ? pick_duo_pattern<true>(sec.present_b, sec.present_a)
+                                           : pick_duo_pattern<false>(sec.present_b, sec.present_a))
+                                     : nullptr;
+  wave_fn fn = duo ? duo : pick_wave(g, cm, sec.present_b, sec.present_a);
   if (!fn) return ALZ_OK;
 
   WArgs p;
@@ -360,21 +560,21 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = (size_t)kRing * kSlotBytes;
+  size_t lds = duo ? (size_t)(kXRing + kPRing) * kSlotBytes : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
-  static bool attr_set[3][2][64] = {};
-  const int gi = g == 16 ? 0 : g == 32 ? 1 : 2;
+  static bool attr_set[4][2][64] = {};
+  const int gi = duo ? 3 : g == 16 ? 0 : g == 32 ? 1 : 2;
   const unsigned key = (sec.present_b << 2 | sec.present_a) & 63;
   if (!attr_set[gi][cm][key]) {
     ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       96 * 1024));
     attr_set[gi][cm][key] = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(64), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(duo ? 128 : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
   *done_channels = groups * g;
-  *kernel_name = g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  *kernel_name = duo ? "k_duo<16>" : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
   return ALZ_OK;
 }
 
