@@ -183,6 +183,17 @@ def main():
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N}
+    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
+    # from inside this process): measured traffic / algorithmic ratio of the same kernel at
+    # 2**18-sample blocks, scaled to this launch's algorithmic bytes
+    try:
+      pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+      if args.workload == "biquad" and pmc["kernel"].split("<")[0] in kernel_name:
+        roof["traffic"] = pmc["traffic_over_algorithmic"] * ALG_BYTES_PER_SAMPLE * C * N
+        roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes, x%.5f of algorithmic)" \
+                                 % pmc["traffic_over_algorithmic"]
+    except (OSError, KeyError, ValueError):
+      pass
     workload = ("configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), 48 kHz float64, "
                 "%d-sample blocks, 1 MI355X per rank" % (C, N))
     metric = "Gsamples/s through ZFilter IIR biquad bank"
