@@ -350,62 +350,90 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   const uint64_t y_extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
                                                       : (uint64_t)((h->channels - 1) * ldy + n);
 
-  for (int s = 0; s < h->n_sections; ++s) {
-    const alz::SectionDev &sec = h->sec[s];
-    const bool generic = !(sec.nb <= 16 && sec.na <= 9);
-    io.y = y_dev;
-    io.syn = syn;
-    io.syc = syc;
-    if (s == 0) {
-      io.x = x_dev;
-      io.sxn = sxn;
-      io.sxc = sxc;
-      io.map_input = h->mode == ALZ_BANK_OUTER;
-    } else {
-      io.x = y_dev;
-      io.sxn = syn;
-      io.sxc = syc;
-      io.map_input = 0;
-    }
-    if (generic && io.x == io.y) {
-      // k_generic reads its history from the block, so it cannot overwrite it
-      int rc = grow(&h->scratch, &h->scratch_bytes, y_extent * 8);
+  auto note = [&](const char *k) {
+    h->last_kernel = k;
+    if (!h->last_kernels.empty()) h->last_kernels += "+";
+    h->last_kernels += k;
+  };
+
+  // Section by section over channels [c_first, c_first + c_count) and samples
+  // [t_first, t_first + t_count): the streaming kernel takes what it can (only when the range
+  // is the whole bank), the lane-per-channel kernels finish the ragged rest.
+  auto run_sections = [&](int64_t c_first, int64_t c_count, int64_t t_first, int64_t t_count) -> int {
+    const bool whole = c_first == 0 && c_count == h->channels;
+    for (int s = 0; s < h->n_sections; ++s) {
+      const alz::SectionDev &sec = h->sec[s];
+      const bool generic = !(sec.nb <= 16 && sec.na <= 9);
+      io.n = t_count;
+      io.y = y_dev + t_first * syn;
+      io.syn = syn;
+      io.syc = syc;
+      if (s == 0) {
+        io.x = x_dev + t_first * sxn;
+        io.sxn = sxn;
+        io.sxc = sxc;
+        io.map_input = h->mode == ALZ_BANK_OUTER;
+      } else {
+        io.x = io.y;
+        io.sxn = syn;
+        io.sxc = syc;
+        io.map_input = 0;
+      }
+      if (generic && io.x == io.y) {
+        // k_fir / k_generic read their history from the block, so they cannot overwrite it
+        int rc = grow(&h->scratch, &h->scratch_bytes, y_extent * 8);
+        if (rc) return rc;
+        ALZ_HIP_CHECK(hipMemcpyAsync(h->scratch, y_dev, y_extent * 8, hipMemcpyDeviceToDevice, st));
+        io.x = h->scratch + t_first * syn;
+      }
+      int64_t done_n = 0, done_c = 0;
+      const char *name = "";
+      io.c_first = c_first;
+      io.c_count = c_count;
+      int rc = (generic || !whole) ? ALZ_OK : alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
       if (rc) return rc;
-      ALZ_HIP_CHECK(hipMemcpyAsync(h->scratch, y_dev, y_extent * 8, hipMemcpyDeviceToDevice, st));
-      io.x = h->scratch;
+      if (done_c > 0) note(name);
+      if (done_c < c_count) {  // channels the streaming kernel did not take, whole time range
+        io.c_first = c_first + done_c;
+        io.c_count = c_count - done_c;
+        rc = alz::launch_section(sec, io, st, &name);
+        if (rc) return rc;
+        note(name);
+      }
+      if (done_c > 0 && done_n < t_count) {  // ragged time tail of the streamed channels
+        io.c_first = c_first;
+        io.c_count = done_c;
+        io.x += done_n * io.sxn;
+        io.y += done_n * io.syn;
+        io.n = t_count - done_n;
+        rc = alz::launch_section(sec, io, st, &name);
+        if (rc) return rc;
+        note(name);
+      }
     }
-    // streaming kernel first (full tiles of full channel groups), k_small & co. for the rest
-    int64_t done_n = 0, done_c = 0;
+    return ALZ_OK;
+  };
+
+  // fused cascade: all sections in one pass over the full tiles of the full channel groups;
+  // the ragged remainder (and every other cascade) goes section by section
+  int64_t fused_n = 0, fused_c = 0;
+  if (h->n_sections >= 2 && x_dev != y_dev) {
+    io.n = n;
+    io.x = x_dev; io.y = y_dev;
+    io.sxn = sxn; io.sxc = sxc; io.syn = syn; io.syc = syc;
+    io.map_input = h->mode == ALZ_BANK_OUTER;
+    io.c_first = 0; io.c_count = h->channels;
     const char *name = "";
-    io.c_first = 0;
-    io.c_count = h->channels;
-    int rc = generic ? ALZ_OK : alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
+    int rc = alz::launch_cascade(h->sec.data(), h->n_sections, io, st, &fused_n, &fused_c, &name);
     if (rc) return rc;
-    auto note = [&](const char *k) {
-      h->last_kernel = k;
-      if (!h->last_kernels.empty()) h->last_kernels += "+";
-      h->last_kernels += k;
-    };
-    if (done_c > 0) note(name);
-    if (done_c < h->channels) {  // ragged channel tail, whole block
-      io.c_first = done_c;
-      io.c_count = h->channels - done_c;
-      rc = alz::launch_section(sec, io, st, &name);
-      if (rc) return rc;
-      note(name);
-    }
-    if (done_c > 0 && done_n < n) {  // ragged time tail of the streamed channels
-      io.c_first = 0;
-      io.c_count = done_c;
-      io.x += done_n * io.sxn;
-      io.y += done_n * io.syn;
-      io.n = n - done_n;
-      rc = alz::launch_section(sec, io, st, &name);
-      if (rc) return rc;
-      note(name);
-      io.n = n;
-    }
+    if (fused_c > 0) note(name);
   }
+  if (fused_c == 0) return run_sections(0, h->channels, 0, n);
+  if (fused_c < h->channels) {
+    int rc = run_sections(fused_c, h->channels - fused_c, 0, n);
+    if (rc) return rc;
+  }
+  if (fused_n < n) return run_sections(0, fused_c, fused_n, n - fused_n);
   return ALZ_OK;
 }
 
@@ -416,19 +444,25 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   if (layout != ALZ_TIME_MAJOR && layout != ALZ_CHAN_MAJOR) return fail(ALZ_E_ARG, "bad layout");
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
-  const uint64_t xe = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldx + h->n_inputs)
-                                               : (uint64_t)((h->n_inputs - 1) * ldx + n);
-  const uint64_t ye = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
-                                               : (uint64_t)((h->channels - 1) * ldy + n);
-  int rc = grow(&h->stage_x, &h->stage_x_bytes, xe * 8);
+  // Stage through device buffers with an EVEN leading dimension and 16-byte aligned rows, so
+  // the streaming kernels (16-byte DMA pieces) apply whatever pitch the host arrays have.
+  const int64_t in_cols = layout == ALZ_TIME_MAJOR ? h->n_inputs : n;
+  const int64_t out_cols = layout == ALZ_TIME_MAJOR ? h->channels : n;
+  const int64_t in_rows = layout == ALZ_TIME_MAJOR ? n : h->n_inputs;
+  const int64_t out_rows = layout == ALZ_TIME_MAJOR ? n : h->channels;
+  if (ldx < in_cols || ldy < out_cols) return fail(ALZ_E_ARG, "leading dimension too small");
+  const int64_t lsx = (in_cols + 1) & ~(int64_t)1, lsy = (out_cols + 1) & ~(int64_t)1;
+  int rc = grow(&h->stage_x, &h->stage_x_bytes, (uint64_t)in_rows * lsx * 8);
   if (rc) return rc;
-  rc = grow(&h->stage_y, &h->stage_y_bytes, ye * 8);
+  rc = grow(&h->stage_y, &h->stage_y_bytes, (uint64_t)out_rows * lsy * 8);
   if (rc) return rc;
-  ALZ_HIP_CHECK(hipMemcpy(h->stage_x, x_host, xe * 8, hipMemcpyHostToDevice));
-  rc = alz_bank_process_dev(h, h->stage_x, h->stage_y, n, layout, ldx, ldy, nullptr);
+  ALZ_HIP_CHECK(hipMemcpy2D(h->stage_x, (size_t)lsx * 8, x_host, (size_t)ldx * 8, (size_t)in_cols * 8,
+                            (size_t)in_rows, hipMemcpyHostToDevice));
+  rc = alz_bank_process_dev(h, h->stage_x, h->stage_y, n, layout, lsx, lsy, nullptr);
   if (rc) return rc;
   ALZ_HIP_CHECK(hipStreamSynchronize(nullptr));
-  ALZ_HIP_CHECK(hipMemcpy(y_host, h->stage_y, ye * 8, hipMemcpyDeviceToHost));
+  ALZ_HIP_CHECK(hipMemcpy2D(y_host, (size_t)ldy * 8, h->stage_y, (size_t)lsy * 8, (size_t)out_cols * 8,
+                            (size_t)out_rows, hipMemcpyDeviceToHost));
   return ALZ_OK;
 }
 

@@ -1,0 +1,305 @@
+// alz_casc.hip -- fused cascades: up to four sections per pass, intermediate samples never
+// leave registers (BASELINE config 4, the gammatone bank).
+//
+// Replaces CascadeFilter.__call__ (reference audiolazy/lazy_filters.py:988-990: four nested
+// generators) for the gammatone cascades of lazy_auditory.py:158-218.  Every section is the same
+// bit-exact DF-I step as everywhere else (separately rounded mul/add, reference term order,
+// absent taps absent); stage s+1 consumes the output stream of stage s, so the fused result is
+// identical to running the sections one after the other.
+//
+// Shape of the work: a filterbank is an OUTER bank -- channel = band * n_inputs + stream -- with
+// hundreds of thousands of channels, so all 64 lanes of a wave are real channels (no ghosts) and
+// the kernel is bound by f64 issue (28 ops per output sample for gammatone.slaney) and by the
+// 8 B/sample of output it has to write; the input is tiny by comparison (every input sample is
+// shared by all bands and comes from L2 / Infinity Cache).  Data movement is k_wave's: 8 KiB
+// tiles (64 channels x 16 samples) arrive by global_load_lds DMA into a 4-slot LDS ring, results
+// go back through the slot as 1 KiB stores.  One wave per workgroup, no barriers.
+#include "alz_common.h"
+
+namespace alz {
+
+static constexpr int kCRing = 4;
+static constexpr int kCChunks = 8;
+static constexpr int kCSlot = 8192 + kCChunks * 16;
+
+struct CArgs {
+  const double *x;
+  double *y;
+  int64_t ldx, ldy;
+  int64_t n_tiles;
+  int64_t channels, n_inputs, n_sets;
+  int64_t c_first;
+  int mode;
+  int nsec;
+  int nb[4], na[4];
+  const double *b[4], *a[4];
+  double *xh[4], *yh[4];
+};
+
+__device__ __forceinline__ void c_dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+typedef double cdbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void c_store16(double *gdst, cdbl2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void c_wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  }
+}
+
+// One section over a chunk of W samples held in registers: v[] in, v[] out (in place).
+// NB taps (pattern PB, bit k <=> b_k present), PA bit k-1 <=> a_k present; dx[] = the NB-1
+// previous inputs (dx[0] most recent), m1/m2 the previous outputs.
+template <int W, int NB, unsigned PB, unsigned PA>
+__device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)[8], double na1,
+                                              double na2, double (&dx)[7], double &m1, double &m2) {
+  double p[W];
+  // feed-forward sums: independent of this section's recurrence, free to overlap with it
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    double acc = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if ((PB >> k) & 1u) {
+        const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dx[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
+        const double t = bc[k] * xv;
+        acc = first ? t : acc + t;
+        first = false;
+      }
+    }
+    p[u] = acc;
+  }
+  // new input history (before v is overwritten)
+  double ndx[7];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) ndx[k] = (W - 1 - k >= 0) ? v[W - 1 - k < 0 ? 0 : W - 1 - k] : dx[k - W < 0 ? 0 : k - W];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) dx[k] = ndx[k];
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    double acc = p[u];
+    if constexpr (PB != 0u) {
+      if constexpr (PA & 1u) acc = acc + na1 * m1;
+      if constexpr (PA & 2u) acc = acc + na2 * m2;
+    } else {
+      bool first = true;
+      if constexpr (PA & 1u) { acc = na1 * m1; first = false; }
+      if constexpr (PA & 2u) { const double t = na2 * m2; acc = first ? t : acc + t; }
+    }
+    v[u] = acc;
+    m2 = m1;
+    m1 = acc;
+  }
+}
+
+constexpr int nb_of(unsigned pb) {
+  int n = 1;
+  for (int k = 0; k < 8; ++k)
+    if ((pb >> k) & 1u) n = k + 1;
+  return n;
+}
+
+// CM: channel-major blocks ([C, N]); else time-major.  Section s has pattern (PBs, PAs);
+// PB == 0 && PA == 0 marks "no such section".
+template <bool CM, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
+          unsigned PB3, unsigned PA3>
+__global__ __launch_bounds__(64) void k_casc(CArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 64, T = 16;
+  constexpr int NS = (PB3 | PA3) ? 4 : (PB2 | PA2) ? 3 : (PB1 | PA1) ? 2 : 1;
+  constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
+  constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
+  const int lane = threadIdx.x;
+  const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
+  const int64_t c = c0 + lane;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  // OUTER: channel = set * n_inputs + input; the 64 channels of a wave share one set
+  const bool outer = p.mode == ALZ_BANK_OUTER;
+  const int64_t in0 = outer ? c0 % p.n_inputs : c0;
+  const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
+
+  int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+  if (!CM) {
+    const int row = lane / 32, cp = lane % 32;           // 2 rows of 64 channels per 1 KiB chunk
+    x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
+    y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+    x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
+    x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
+  } else {
+    // 8 channels x 16 samples per chunk.  The 16-byte pieces of a channel row are XOR-swizzled
+    // with the channel index on the GLOBAL side (the DMA lands linearly in LDS): lane (ch, k)
+    // moves piece k ^ ch, so the 64 lanes that later read "their" channel hit distinct banks.
+    const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
+    x_off = (in0 + ch) * p.ldx + 2 * sp;
+    y_off = (c0 + ch) * p.ldy + 2 * sp;
+    x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
+    x_tile = T; y_tile = T;
+  }
+
+  // coefficients and state of every section, in registers
+  double bc[4][8], na1[4], na2[4], dx[4][7], m1[4], m2[4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      bc[s][k] = ((PBS[s] >> k) & 1u) ? p.b[s][(int64_t)k * p.n_sets + set] : 0.0;
+    na1[s] = (PAS[s] & 1u) ? -p.a[s][1 * p.n_sets + set] : 0.0;
+    na2[s] = (PAS[s] & 2u) ? -p.a[s][2 * p.n_sets + set] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dx[s][k] = (k < p.nb[s] - 1) ? p.xh[s][(int64_t)k * p.channels + c] : 0.0;
+    m1[s] = (p.na[s] > 1) ? p.yh[s][0 * p.channels + c] : 0.0;
+    m2[s] = (p.na[s] > 2) ? p.yh[s][1 * p.channels + c] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    asm volatile("" : "+v"(na1[s]), "+v"(na2[s]), "+v"(m1[s]), "+v"(m2[s]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bc[s][k]));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(dx[s][k]));
+  }
+
+  const double *xg = p.x + x_off;
+  double *yg = p.y + y_off;
+  const int64_t nt = p.n_tiles;
+  for (int t = 0; t < kCRing - 1 && t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kCSlot + j * 1040);
+  }
+  // element (sample u, lane) of a slot.  TIME: (u*64 + lane)*8 + (u/2)*16.
+  // CHAN: chunk lane/8 (1040 B each), row lane%8 (128 B), piece (u/2) ^ (lane%8), half u&1.
+  const int lane_off = CM ? (lane / 8) * 1040 + (lane % 8) * 128 : lane * 8;
+  int swz[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
+#define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+
+  for (int64_t i = 0; i < nt; ++i) {
+    const int slot = (int)(i % kCRing);
+    const int64_t tn = i + kCRing - 1;
+    if (tn < nt) {
+      const int sn = (int)(tn % kCRing);
+#pragma unroll
+      for (int j = 0; j < kCChunks; ++j) c_dma16(xg + tn * x_tile + j * x_chunk, lds0 + sn * kCSlot + j * 1040);
+    }
+    {
+      const int64_t loads_after = (nt - 1 - i < kCRing - 1) ? (nt - 1 - i) : (kCRing - 1);
+      const int64_t stores_after = (i < kCRing - 1) ? i : (kCRing - 1);
+      c_wait_vm((int)(loads_after + stores_after) * kCChunks);
+    }
+    char *tile = smem + slot * kCSlot + lane_off;
+#pragma unroll
+    for (int h = 0; h < T / 8; ++h) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double *>(tile + ALZ_COFF(h * 8 + u));
+      section_chunk<8, nb_of(PB0), PB0, PA0>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0]);
+      if constexpr (NS > 1) section_chunk<8, nb_of(PB1), PB1, PA1>(v, bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
+      if constexpr (NS > 2) section_chunk<8, nb_of(PB2), PB2, PA2>(v, bc[2], na1[2], na2[2], dx[2], m1[2], m2[2]);
+      if constexpr (NS > 3) section_chunk<8, nb_of(PB3), PB3, PA3>(v, bc[3], na1[3], na2[3], dx[3], m1[3], m2[3]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<double *>(tile + ALZ_COFF(h * 8 + u)) = v[u];
+    }
+    double *yt = yg + i * y_tile;
+    const char *ts = smem + slot * kCSlot;
+    cdbl2 w[kCChunks];
+#pragma unroll
+    for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ts + j * 1040 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+  }
+#undef ALZ_COFF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k < p.nb[s] - 1) p.xh[s][(int64_t)k * p.channels + c] = dx[s][k];
+    if (p.na[s] > 1) p.yh[s][0 * p.channels + c] = m1[s];
+    if (p.na[s] > 2) p.yh[s][1 * p.channels + c] = m2[s];
+  }
+}
+
+typedef void (*casc_fn)(CArgs);
+
+template <bool CM>
+static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
+#define ALZ_CASC(B0, A0, B1, A1, B2, A2, B3, A3, NS_)                                          \
+  if (ns == NS_ && pb[0] == B0 && pa[0] == A0 && (NS_ < 2 || (pb[1] == B1 && pa[1] == A1)) && \
+      (NS_ < 3 || (pb[2] == B2 && pa[2] == A2)) && (NS_ < 4 || (pb[3] == B3 && pa[3] == A3)))  \
+    return (casc_fn)k_casc<CM, B0, A0, B1, A1, B2, A2, B3, A3>;
+  ALZ_CASC(3, 3, 3, 3, 3, 3, 3, 3, 4)        // gammatone.slaney
+  ALZ_CASC(5, 3, 1, 3, 5, 3, 1, 3, 4)        // gammatone.klapuri
+  ALZ_CASC(0xFE, 3, 1, 3, 1, 3, 1, 3, 4)     // gammatone.sampled (8-tap numerator, b0 == 0)
+  ALZ_CASC(1, 1, 1, 1, 0, 0, 0, 0, 2)        // lowpass.pole twice as a cascade
+  ALZ_CASC(7, 3, 7, 3, 0, 0, 0, 0, 2)        // two general biquads
+  ALZ_CASC(7, 3, 7, 3, 7, 3, 7, 3, 4)        // four general biquads
+#undef ALZ_CASC
+  return nullptr;
+}
+
+// Whole cascade in one pass when its section patterns are one of the fused combinations.
+// Handles the full 16-sample tiles of the full 64-channel groups; reports what it covered.
+int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                   int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+  *done_samples = 0;
+  *done_channels = 0;
+  if (nsec < 2 || nsec > 4) return ALZ_OK;
+  unsigned pb[4] = {0, 0, 0, 0}, pa[4] = {0, 0, 0, 0};
+  for (int s = 0; s < nsec; ++s) {
+    if (secs[s].nb > 8 || secs[s].na > 3 || !secs[s].uniform || secs[s].any_div) return ALZ_OK;
+    pb[s] = secs[s].present_b;
+    pa[s] = secs[s].present_a;
+    if ((pb[s] | pa[s]) == 0) return ALZ_OK;
+    // the kernel keeps exactly as much input history as the highest present tap needs
+    if (secs[s].nb != nb_of(pb[s])) return ALZ_OK;
+    if (secs[s].na != (pa[s] & 2u ? 3 : pa[s] & 1u ? 2 : 1)) return ALZ_OK;
+  }
+  const bool cm = io.sxn == 1 && io.syn == 1 && !(io.sxc == 1 && io.syc == 1);
+  const bool tm = io.sxc == 1 && io.syc == 1;
+  if (!cm && !tm) return ALZ_OK;
+  const int64_t ldx = cm ? io.sxc : io.sxn, ldy = cm ? io.syc : io.syn;
+  if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
+  if ((ldx | ldy) & 1) return ALZ_OK;
+  if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0) return ALZ_OK;  // a wave = one band
+  const int64_t groups = io.channels / 64, tiles = io.n / 16;
+  if (groups == 0 || tiles == 0) return ALZ_OK;
+  casc_fn fn = cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec);
+  if (!fn) return ALZ_OK;
+  CArgs p;
+  p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = tiles;
+  p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
+  p.c_first = 0; p.mode = io.mode; p.nsec = nsec;
+  for (int s = 0; s < 4; ++s) {
+    const SectionDev &d = secs[s < nsec ? s : 0];
+    p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
+  }
+  const size_t lds = (size_t)kCRing * kCSlot;
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(64), lds, stream, p);
+  ALZ_HIP_CHECK(hipGetLastError());
+  *done_samples = tiles * 16;
+  *done_channels = groups * 64;
+  *kernel_name = "k_casc";
+  return ALZ_OK;
+}
+
+}  // namespace alz

@@ -56,6 +56,10 @@ struct BlockIO {
 // alz_iir.hip: any section shape, channels [c_first, c_first + c_count)
 int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
                    const char **kernel_name);
+// alz_casc.hip: a whole cascade (2..4 sections of a fused pattern) in one pass; reports the
+// samples / channels it covered (full 16-sample tiles of full 64-channel groups)
+int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                   int64_t *done_samples, int64_t *done_channels, const char **kernel_name);
 // alz_fir.hip: long feedback-free sections on time-major blocks (x != y); *taken says whether
 // the shape was this kernel's
 int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,

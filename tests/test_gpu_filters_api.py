@@ -120,3 +120,59 @@ def test_karplus_strong_style_comb_with_callable_memory(al):
   from oracle import oracle
   ref = oracle.df1(filt.numlist, filt.denlist, [0.] * 400, memory=noise)
   assert same_bits(y, ref)
+
+
+@pytest.mark.parametrize("layout", ["chan", "time"])
+@pytest.mark.parametrize("strategy", ["slaney", "klapuri", "sampled"])
+def test_fused_gammatone_bank(al, strategy, layout):
+  """cfg4 shape: x [S, N] -> y [B, S, N] (or time-major [N, B*S]); the fused cascade kernel takes
+  the full 16-sample tiles of the 64-stream groups, the ragged tail goes section by section."""
+  from oracle import oracle
+  s, Hz = al.sHz(48000)
+  B, S, N = 5, 128, 1000 + 7
+  fcs = [f * Hz for f in al.erb_space(50., 20000., B)]
+  rng = np.random.default_rng(11)
+  x = rng.uniform(-1, 1, (S, N))
+  bank = al.gammatone_bank(fcs, S, strategy=strategy, Hz=Hz)
+  bank.reset()
+  y = bank.process(x if layout == "chan" else np.ascontiguousarray(x.T), layout=layout)
+  assert "k_casc" in bank.last_kernel
+  if layout == "time":
+    y = y.T
+  assert y.shape == (B * S, N)
+  k = al.gammatone_erb_constants(4)[0]
+  for b, fc in enumerate(fcs):
+    band = getattr(al.gammatone, strategy)(fc, k * al.erb(fc, Hz))
+    secs = [(f.numlist, f.denlist) for f in band]
+    nb, na = [len(q[0]) for q in secs], [len(q[1]) for q in secs]
+    ref = oracle.bank(nb, na, np.concatenate([q[0] for q in secs]), np.concatenate([q[1] for q in secs]),
+                      x, layout="chan")
+    assert same_bits(y[b * S:(b + 1) * S], ref), (strategy, b)
+  # the next block continues every cascade from the state the fused kernel left
+  x2 = rng.uniform(-1, 1, (S, 100))
+  y2 = bank.process(x2 if layout == "chan" else np.ascontiguousarray(x2.T), layout=layout)
+  y2 = y2.T if layout == "time" else y2
+  band = getattr(al.gammatone, strategy)(fcs[2], k * al.erb(fcs[2], Hz))
+  secs = [(f.numlist, f.denlist) for f in band]
+  whole = oracle.bank([len(q[0]) for q in secs], [len(q[1]) for q in secs],
+                      np.concatenate([q[0] for q in secs]), np.concatenate([q[1] for q in secs]),
+                      np.concatenate([x, x2], axis=1), layout="chan")
+  assert same_bits(y2[2 * S:3 * S], whole[:, N:])
+
+
+def test_fused_diagonal_cascade_of_biquads(al):
+  from oracle import oracle
+  rng = np.random.default_rng(2)
+  C, N = 192, 500
+  b1, b2 = rng.uniform(-1, 1, (C, 3)), rng.uniform(-1, 1, (C, 3))
+  a1 = np.concatenate([np.ones((C, 1)), rng.uniform(-.4, .4, (C, 2))], axis=1)
+  a2 = np.concatenate([np.ones((C, 1)), rng.uniform(-.4, .4, (C, 2))], axis=1)
+  x = rng.uniform(-1, 1, (N, C))
+  bank = al.FilterBank([(b1, a1), (b2, a2)], n_inputs=C)
+  bank.reset(memory=[0.25, -0.5], zero=0.125)
+  y = bank.process(x)
+  assert "k_casc" in bank.last_kernel
+  yh = np.tile(np.array([0.25, -0.5, 0.25, -0.5]), (C, 1))
+  ref = oracle.bank([3, 3], [3, 3], np.concatenate([b1, b2], axis=1), np.concatenate([a1, a2], axis=1), x,
+                    xh=np.full((C, 4), 0.125), yh=yh, zero=0.125)
+  assert same_bits(y, ref)
