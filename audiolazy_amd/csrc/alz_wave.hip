@@ -310,8 +310,14 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 // i+3 and prepares p for tile i+1.  LDS: a 4-slot x ring (DMA target) + a 3-slot p/y ring.
 // G = 16 channels per workgroup (the REC wave's other 48 lanes are ghosts as in k_wave).
 // ---------------------------------------------------------------------------
-static constexpr int kXRing = 4, kPRing = 3;
+static constexpr int kXRing = 4, kPRing = 3, kYRing = 2;
 
+// Skew.  The four lane groups of the REC wave are exact copies of the same 16 recurrences; group
+// q runs q steps behind group 0 (it reads p[s - q] at step s).  At every step with s % 4 == 3
+// the wave then holds y[s-3..s] -- one row per lane group -- and a single ds_write_b64 of the
+// value each lane has just computed stores four rows: no per-step 18-cycle LDS write and no
+// row-select moves either.  y goes to its own small ring (p must stay readable for the lagging
+// groups across the tile boundary).  Group 0 is never behind, so it owns the final state.
 template <bool CM, unsigned PB, unsigned PA>
 __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,10 +331,16 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   const int64_t nt = p.n_tiles;
   char *xring = smem;
   char *pring = smem + kXRing * kSlotBytes;
+  char *yring = pring + kPRing * kSlotBytes;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  // byte offset of element (row/sample u, channel cl) inside a slot
+  // x ring (DMA target): byte offset of element (u, cl) = lane_off + ALZ_EOFF(u), 16-byte pad
+  // after every 1 KiB chunk.  p and y rings: TIME rows are unpadded (row u at u*128), CHAN rows
+  // keep the pad between channel pairs (REC's lanes read one channel each).
   const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+  constexpr int kStep = CM ? 8 : G * 8;               // bytes from sample u to u+1 in the p/y rings
+  constexpr int kOutChunk = CM ? 1040 : 1024;         // bytes per 1 KiB store chunk in the y ring
+  const int lane_off_p = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
 
   if (wave == 1) {
     // ------------------------------ AUX ------------------------------
@@ -362,11 +374,11 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       for (int j = 0; j < kChunks; ++j)
         dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlotBytes + j * 1040);
     };
-    // feed-forward of tile t: lane (q, cl) owns rows 16q .. 16q+15 of channel cl
+    // feed-forward of tile t: lane (q, cl) owns samples 16q .. 16q+15 of channel cl
     auto feed_forward = [&](int64_t t) {
       const char *xs = xring + (int)(t % kXRing) * kSlotBytes + lane_off;
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kSlotBytes + lane_off;  // tile t-1
-      char *ps = pring + (int)(t % kPRing) * kSlotBytes + lane_off;
+      char *ps = pring + (int)(t % kPRing) * kSlotBytes + lane_off_p;
       double xv[18];
 #pragma unroll
       for (int j = 0; j < 16; ++j) xv[j + 2] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q + j));
@@ -387,15 +399,15 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         if constexpr (PB & 1u) { acc = b0 * xv[j + 2]; first = false; }
         if constexpr (PB & 2u) { const double v = b1 * xv[j + 1]; acc = first ? v : acc + v; first = false; }
         if constexpr (PB & 4u) { const double v = b2 * xv[j]; acc = first ? v : acc + v; first = false; }
-        *reinterpret_cast<double *>(ps + ALZ_EOFF(16 * q + j)) = acc;
+        *reinterpret_cast<double *>(ps + (16 * q + j) * kStep) = acc;
       }
     };
     auto store_tile = [&](int64_t t) {
-      const char *ps = pring + (int)(t % kPRing) * kSlotBytes;
+      const char *ys = yring + (int)(t % kYRing) * kSlotBytes;
       double *yt = yg + t * y_tile;
       dbl2 v[kChunks];
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ps + j * 1040 + lane * 16);
+      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * kOutChunk + lane * 16);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
@@ -435,38 +447,43 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
     asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
     __builtin_amdgcn_s_barrier();                            // p of tile 0 is ready
+    constexpr int NCH = T / 8;
     for (int64_t i = 0; i < nt; ++i) {
-      char *tile = pring + (int)(i % kPRing) * kSlotBytes;
-      const char *rd = tile + lane_off;
-      char *wr = tile + lane_off + (CM ? q * 8 : q * G * 8);  // lane group q owns row q of each 4
-      constexpr int NCH = T / 8;
+      // this lane reads sample (u - q) of the tile; u - q < 0 lives in the previous tile's slot
+      const char *cur = pring + (int)(i % kPRing) * kSlotBytes + lane_off_p - q * kStep;
+      const char *prv = pring + (int)((i + kPRing - 1) % kPRing) * kSlotBytes + lane_off_p + (T - q) * kStep;
+      char *wr = yring + (int)(i % kYRing) * kSlotBytes + lane_off_p - q * kStep;
       double pr[3][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pr[0][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(u));
+      for (int u = 0; u < 8; ++u) {
+        const char *src = (u < 3 && u < q) ? prv : cur;       // (u < q is per-lane; u >= 3 never)
+        pr[0][u] = *reinterpret_cast<const double *>(src + u * kStep);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(8 + u));
+      for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         if (k + 2 < NCH) {
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u));
+            pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
         }
         __builtin_amdgcn_sched_barrier(0);
-        double yv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           double acc = pr[k % 3][u];
           if constexpr (PA & 1u) acc = acc + na1 * m1;
           if constexpr (PA & 2u) acc = acc + na2 * m2;
-          yv[u] = acc;
-          m2 = m1; m1 = acc;
-          if ((u & 3) == 3) {
-            double yw = yv[u - 3];
-#pragma unroll
-            for (int r = 1; r < 4; ++r) yw = (q == r) ? yv[u - 3 + r] : yw;
-            *reinterpret_cast<double *>(wr + ALZ_EOFF(k * 8 + u - 3)) = yw;
+          if (k == 0 && u < 3 && i == 0) {
+            // start of the stream: group q has nothing to do before step q; hold its state
+            const bool on = u >= q;
+            m2 = on ? m1 : m2;
+            m1 = on ? acc : m1;
+          } else {
+            m2 = m1;
+            m1 = acc;
           }
+          if ((u & 3) == 3) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -560,7 +577,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = duo ? (size_t)(kXRing + kPRing) * kSlotBytes : (size_t)kRing * kSlotBytes;
+  size_t lds = duo ? (size_t)(kXRing + kPRing + kYRing) * kSlotBytes : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
   static bool attr_set[4][2][64] = {};
   const int gi = duo ? 3 : g == 16 ? 0 : g == 32 ? 1 : 2;

@@ -83,6 +83,71 @@ def cpu_baseline(b, a, n_samples, budget_s=12.0):
                                                                          os.cpu_count() or 0)}
 
 
+def side_workload(args, alz, torch, dev, rank, world, local):
+  """configs[3] (gammatone bank) and configs[4] (LPC frames): same timing protocol, own metric."""
+  import torch.distributed as dist
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+  g = torch.Generator(device=dev).manual_seed(20260924 + rank)
+  if args.workload == "gammatone":
+    B, S, N = 256, 64, 1 << 16            # 512 streams over 8 GPUs -> 64 streams per GPU, all bands local
+    s_, Hz = alz.sHz(48000)
+    fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
+    bank = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz, device=local)
+    bank.reset()
+    x = torch.empty((S, N), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=g)
+    y = torch.empty((B * S, N), dtype=torch.float64, device=dev)
+    step = lambda: bank.process(x, layout="chan", out=y)
+    units, unit_name = float(B) * S * N, "Gsamples/s"
+    alg_bytes = (8.0 + 8.0 / B) * B * S * N
+    metric = "Gsamples/s (band x stream x sample outputs) through the ERB gammatone bank"
+    workload = ("configs[3]: ERB gammatone filterbank (gammatone.slaney, 4-section cascades), %d bands x %d "
+                "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
+                "x [S, N] -> y [B, S, N]" % (B, S, N))
+  else:
+    F, L, order = 65536, 480, 16
+    sig = torch.empty((F * L,), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=g)
+    from audiolazy_amd.lpc import kautocor_frames
+    step = lambda: kautocor_frames(sig, L, order)
+    units, unit_name = float(F), "Gframes/s"
+    alg_bytes = 3984.0 * F
+    metric = "Gframes/s through lpc.kautocor (autocorrelation + Levinson-Durbin, order 16, 10 ms frames)"
+    workload = "configs[4]: lazy_lpc order-16 on %d concurrent 480-sample frames, float64" % F
+
+  def sync_all():
+    torch.cuda.synchronize(dev)
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize(dev)
+  for _ in range(args.warmup):
+    step()
+  sync_all()
+  t0 = time.perf_counter()
+  for s in range(args.steps):
+    ev[s][0].record()
+    step()
+    ev[s][1].record()
+  sync_all()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  if rank == 0:
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    print(json.dumps({
+      "metric": metric, "value": world * units * args.steps / elapsed / 1e9, "unit": unit_name,
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_lpc"},
+      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms_avg": k_ms,
+                   "algorithmic_bytes_per_launch": alg_bytes}}))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -92,8 +157,9 @@ def main():
   ap.add_argument("--log2-samples", type=int, default=20, help="block length per channel = 2**this")
   ap.add_argument("--layout", choices=["time", "chan"], default="time")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--workload", choices=["biquad", "fir"], default="biquad",
-                  help="biquad = configs[1] (the contract line); fir = configs[2], 256 shared taps x 8192 ch")
+  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc"], default="biquad",
+                  help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
+                       "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
 
   import torch
@@ -110,6 +176,8 @@ def main():
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
 
+  if args.workload in ("gammatone", "lpc"):
+    return side_workload(args, alz, torch, dev, rank, world, local)
   C, N = args.channels, 1 << args.log2_samples
   if args.workload == "fir":
     if args.channels == 4096 and args.log2_samples == 20:   # configs[2] defaults
