@@ -412,20 +412,20 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
 
-    for (int t = 0; t < kXRing - 1 && t < nt; ++t) queue_tile(t);
+    for (int t = 0; t < kXRing - 1 && t < nt && !(p.dbg & 1); ++t) queue_tile(t);
     wait_vm((int)((nt < kXRing - 1 ? nt : kXRing - 1) - 1) * kChunks);   // tile 0 has landed
     feed_forward(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < nt; ++i) {
-      if (i >= 1) store_tile(i - 1);
-      if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
+      if (i >= 1 && !(p.dbg & 4)) store_tile(i - 1);
+      if (i + kXRing - 1 < nt && !(p.dbg & 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         const int64_t last = (i + 3 < nt - 1) ? i + 3 : nt - 1;
         const int64_t dma_after = last - (i + 1);
         const int64_t stores_after = i < 2 ? i : 2;
-        wait_vm((int)(dma_after + stores_after) * kChunks);
-        feed_forward(i + 1);
+        wait_vm((p.dbg & 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
+        if (!(p.dbg & 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
