@@ -14,6 +14,8 @@
 // shared by all bands and comes from L2 / Infinity Cache).  Data movement is k_wave's: 8 KiB
 // tiles (64 channels x 16 samples) arrive by global_load_lds DMA into a 4-slot LDS ring, results
 // go back through the slot as 1 KiB stores.  One wave per workgroup, no barriers.
+#include <stdlib.h>
+
 #include "alz_common.h"
 
 namespace alz {
@@ -34,6 +36,7 @@ struct CArgs {
   int nb[4], na[4];
   const double *b[4], *a[4];
   double *xh[4], *yh[4];
+  int dbg;  // ALZ_WAVE_DEBUG ablation bits (wrong output!): 1 no DMA, 2 no section arithmetic, 4 no stores
 };
 
 __device__ __forceinline__ void c_dma16(const void *gsrc, unsigned lds_dst) {
@@ -239,6 +242,169 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_pipe: the same four-section cascade as a wave pipeline.  A workgroup is five waves on the
+// four SIMDs of a CU: wave s (s = 0..3) is cascade section s, wave 4 (AUX) queues the tile DMA and
+// stores finished tiles.  At barrier interval t section s works on tile t - s; tiles are handed
+// from section to section through 2-slot LDS rings in a lane-private layout
+// [8 pieces][64 lanes][16 B] (ds_read/write_b128, conflict-free).  Each wave then issues ~7 f64
+// ops per sample instead of 28, so with 16384 channels (256 workgroups) the step is ~4x shorter.
+// Section order, term order and rounding are unchanged: stage s+1 consumes exactly the doubles
+// stage s produced.
+// ---------------------------------------------------------------------------
+static constexpr int kPXRing = 3;
+static constexpr int kPSlots = kPXRing + 2 + 2 + 2 + 2;   // x ring, q1, q2, q3, y rings
+
+template <bool CM, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
+          unsigned PB3, unsigned PA3>
+__global__ __launch_bounds__(320) void k_pipe(CArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = 64, T = 16;
+  constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
+  constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
+  const int64_t c = c0 + lane;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const bool outer = p.mode == ALZ_BANK_OUTER;
+  const int64_t in0 = outer ? c0 % p.n_inputs : c0;
+  const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
+  const int64_t nt = p.n_tiles;
+  char *xring = smem;
+  char *qring = smem + kPXRing * kCSlot;                 // q1 | q2 | q3 : 2 slots each
+  char *yring = qring + 6 * kCSlot;
+  // DMA-layout element offsets (x ring and y ring), as in k_casc
+  const int lane_off = CM ? (lane / 8) * 1040 + (lane % 8) * 128 : lane * 8;
+  int swz[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
+#define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+
+  if (wave == 4) {
+    // ------------------------------ AUX ------------------------------
+    int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+    if (!CM) {
+      const int row = lane / 32, cp = lane % 32;
+      x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
+      y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+      x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
+      x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
+    } else {
+      const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
+      x_off = (in0 + ch) * p.ldx + 2 * sp;
+      y_off = (c0 + ch) * p.ldy + 2 * sp;
+      x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
+      x_tile = T; y_tile = T;
+    }
+    const double *xg = p.x + x_off;
+    double *yg = p.y + y_off;
+    auto queue_tile = [&](int64_t t) {
+      const int s = (int)(t % kPXRing);
+#pragma unroll
+      for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kCSlot + j * 1040);
+    };
+    auto store_tile = [&](int64_t t) {
+      const char *ys = yring + (int)(t % 2) * kCSlot;
+      double *yt = yg + t * y_tile;
+      cdbl2 w[kCChunks];
+#pragma unroll
+      for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+    };
+    if (!(p.dbg & 1)) queue_tile(0);
+    if (nt > 1 && !(p.dbg & 1)) queue_tile(1);
+    c_wait_vm((nt > 1 && !(p.dbg & 1)) ? 8 : 0);                              // tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    for (int64_t t = 0; t < nt + 4; ++t) {
+      const bool st = t >= 4 && t - 4 < nt;
+      const bool ld = t + 2 < nt;
+      if (st && !(p.dbg & 4)) store_tile(t - 4);
+      if (ld && !(p.dbg & 1)) queue_tile(t + 2);
+      if (t + 1 < nt) c_wait_vm((p.dbg & 5) ? 0 : ((st ? 1 : 0) + (ld ? 1 : 0)) * 8);   // tile t+1 has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    // --------------------------- section `wave` ---------------------------
+    double bc[8], na1 = 0, na2 = 0, dx[7], m1, m2;
+    int nbv = 1, nav = 1;
+    unsigned pbv = 0, pav = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (wave == s) { pbv = PBS[s]; pav = PAS[s]; nbv = p.nb[s]; nav = p.na[s]; }
+    const double *bsrc = p.b[0], *asrc = p.a[0];
+    double *xhs = p.xh[0], *yhs = p.yh[0];
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+      if (wave == s) { bsrc = p.b[s]; asrc = p.a[s]; xhs = p.xh[s]; yhs = p.yh[s]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bc[k] = ((pbv >> k) & 1u) ? bsrc[(int64_t)k * p.n_sets + set] : 0.0;
+    if (pav & 1u) na1 = -asrc[1 * p.n_sets + set];
+    if (pav & 2u) na2 = -asrc[2 * p.n_sets + set];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) dx[k] = (k < nbv - 1) ? xhs[(int64_t)k * p.channels + c] : 0.0;
+    m1 = (nav > 1) ? yhs[0 * p.channels + c] : 0.0;
+    m2 = (nav > 2) ? yhs[1 * p.channels + c] : 0.0;
+    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bc[k]));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(dx[k]));
+
+    __builtin_amdgcn_s_barrier();
+    for (int64_t t = 0; t < nt + 4; ++t) {
+      const int64_t tile = t - wave;
+      if (tile >= 0 && tile < nt) {
+        double v[16];
+        // input: section 0 reads the DMA layout, the others the lane-private hand-off layout
+        if (wave == 0) {
+          const char *src = xring + (int)(tile % kPXRing) * kCSlot + lane_off;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double *>(src + ALZ_COFF(u));
+        } else {
+          const char *src = qring + ((wave - 1) * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * 1024);
+            v[2 * j] = w.x;
+            v[2 * j + 1] = w.y;
+          }
+        }
+        if (p.dbg & 2) { m1 = v[3]; }
+        else if (wave == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc, na1, na2, dx, m1, m2);
+        else if (wave == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc, na1, na2, dx, m1, m2);
+        else if (wave == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc, na1, na2, dx, m1, m2);
+        else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc, na1, na2, dx, m1, m2);
+        if (wave == 3) {
+          char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
+        } else {
+          char *dst = qring + (wave * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            cdbl2 w;
+            w.x = v[2 * j];
+            w.y = v[2 * j + 1];
+            *reinterpret_cast<cdbl2 *>(dst + j * 1024) = w;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (k < nbv - 1) xhs[(int64_t)k * p.channels + c] = dx[k];
+    if (nav > 1) yhs[0 * p.channels + c] = m1;
+    if (nav > 2) yhs[1 * p.channels + c] = m2;
+  }
+#undef ALZ_COFF
+}
+
 typedef void (*casc_fn)(CArgs);
 
 template <bool CM>
@@ -254,6 +420,19 @@ static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
   ALZ_CASC(7, 3, 7, 3, 0, 0, 0, 0, 2)        // two general biquads
   ALZ_CASC(7, 3, 7, 3, 7, 3, 7, 3, 4)        // four general biquads
 #undef ALZ_CASC
+  return nullptr;
+}
+
+template <bool CM>
+static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
+#define ALZ_PIPE(B0, A0, B1, A1, B2, A2, B3, A3)                                                 \
+  if (pb[0] == B0 && pa[0] == A0 && pb[1] == B1 && pa[1] == A1 && pb[2] == B2 && pa[2] == A2 &&  \
+      pb[3] == B3 && pa[3] == A3)                                                                \
+    return (casc_fn)k_pipe<CM, B0, A0, B1, A1, B2, A2, B3, A3>;
+  ALZ_PIPE(3, 3, 3, 3, 3, 3, 3, 3)        // gammatone.slaney
+  ALZ_PIPE(5, 3, 1, 3, 5, 3, 1, 3)        // gammatone.klapuri
+  ALZ_PIPE(0xFE, 3, 1, 3, 1, 3, 1, 3)     // gammatone.sampled
+#undef ALZ_PIPE
   return nullptr;
 }
 
@@ -283,22 +462,34 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0) return ALZ_OK;  // a wave = one band
   const int64_t groups = io.channels / 64, tiles = io.n / 16;
   if (groups == 0 || tiles == 0) return ALZ_OK;
-  casc_fn fn = cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec);
+  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
+  casc_fn pipe = (nsec == 4 && pipe_env) ? (cm ? pick_pipe<true>(pb, pa) : pick_pipe<false>(pb, pa)) : nullptr;
+  casc_fn fn = pipe ? pipe : (cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
   if (!fn) return ALZ_OK;
   CArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = tiles;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
   p.c_first = 0; p.mode = io.mode; p.nsec = nsec;
+  static const int dbg_env = getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0;
+  p.dbg = dbg_env;
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
   }
-  const size_t lds = (size_t)kCRing * kCSlot;
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(64), lds, stream, p);
+  const size_t lds = pipe ? (size_t)kPSlots * kCSlot : (size_t)kCRing * kCSlot;
+  if (pipe) {
+    static bool attr[2][3] = {};
+    const int pi = pb[0] == 3 ? 0 : pb[0] == 5 ? 1 : 2;
+    if (!attr[cm][pi]) {
+      ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr[cm][pi] = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 320 : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * 16;
   *done_channels = groups * 64;
-  *kernel_name = "k_casc";
+  *kernel_name = pipe ? "k_pipe" : "k_casc";
   return ALZ_OK;
 }
 
