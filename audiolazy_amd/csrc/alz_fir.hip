@@ -22,8 +22,8 @@
 
 namespace alz {
 
-static constexpr int kFirR = 16;   // outputs per lane held in registers
-static constexpr int kFirK = 8;    // taps per block
+static constexpr int kFirR = 32;   // outputs per lane held in registers
+static constexpr int kFirK = 16;   // taps per block
 static constexpr int kFirTB = 256; // output rows per wave
 
 struct FArgs {
