@@ -89,6 +89,178 @@ __global__ __launch_bounds__(64) void k_lpc(const double *__restrict__ sig, int6
   }
 }
 
+// ---------------------------------------------------------------------------
+// Second generation, two kernels.
+//
+// k_acorr_dense: lanes are (frame, lag) pairs packed densely -- pair index = block*64 + lane,
+// frame = index / P, lag = index % P with P = max_lag + 1 -- so all 64 lanes work (the slot
+// kernel above keeps 17 of 32 busy at order 16).  The few frames a wave touches are staged in
+// LDS; every lane walks its lag left to right: bit-exact acorr (lazy_analysis.py:311-312).
+//
+// k_levinson_lane: one lane per frame, the whole O(order^2) recursion in registers (the loops
+// are fully unrolled up to kLevMax so the coefficient array is statically indexed); no
+// cross-lane traffic at all.  Same update as the slot kernel, floating-point parity (<= 1e-9).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_acorr_dense(const double *__restrict__ sig, int64_t n_frames,
+                                                     int frame_len, int64_t hop, int P,
+                                                     double *__restrict__ r_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *smem = reinterpret_cast<double *>(smem_raw);
+  const int lane = threadIdx.x;
+  const int64_t idx0 = (int64_t)blockIdx.x * 64;
+  const int64_t total = n_frames * P;
+  const int64_t f_lo = idx0 / P;
+  int64_t f_hi = (idx0 + 63) / P;
+  if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+  const int nfr = (int)(f_hi - f_lo + 1);
+  // frames sit at a stride = 16 (mod 32) doubles: the two frames a 32-lane half touches then
+  // occupy opposite halves of the 64 LDS banks
+  const int fstride = ((frame_len + 15) / 32) * 32 + 16;
+  for (int s = 0; s < nfr; ++s) {
+    const double *src = sig + (f_lo + s) * hop;
+    for (int n = lane; n < frame_len; n += 64) smem[s * fstride + n] = src[n];
+  }
+  __syncthreads();
+  const int64_t idx = idx0 + lane;
+  if (idx >= total) return;
+  const int64_t f = idx / P;
+  const int i = (int)(idx - f * P);
+  const double *fr = smem + (int)(f - f_lo) * fstride;
+  const int cnt = frame_len - i;
+  double acc = 0.0;
+  int n = 0;
+  for (; n + 4 <= cnt; n += 4) {
+    const double x0 = fr[n], x1 = fr[n + 1], x2 = fr[n + 2], x3 = fr[n + 3];
+    const double y0 = fr[n + i], y1 = fr[n + i + 1], y2 = fr[n + i + 2], y3 = fr[n + i + 3];
+    acc = acc + x0 * y0;
+    acc = acc + x1 * y1;
+    acc = acc + x2 * y2;
+    acc = acc + x3 * y3;
+  }
+  for (; n < cnt; ++n) acc = acc + fr[n] * fr[n + i];
+  r_out[idx] = acc;
+}
+
+// k_acorr_lane<P>: one lane per frame, P = max_lag + 1 accumulators per lane.  Per sample the
+// lane needs ONE new value (its window fr[n .. n+P-1] slides in registers, rotated by unrolling
+// P steps) for P multiply-adds: no LDS, no cross-lane traffic, f64-issue-bound.  Every lag still
+// sums left to right, so the result is bit-identical to the reference (lazy_analysis.py:311-312).
+template <int P>
+__global__ __launch_bounds__(64) void k_acorr_lane(const double *__restrict__ sig, int64_t n_frames,
+                                                    int frame_len, int64_t hop, double *__restrict__ r_out) {
+  int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = f < n_frames;
+  if (!live) f = n_frames - 1;
+  const double *fr = sig + f * hop;
+  const int L = frame_len;
+  double acc[P], w[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    acc[i] = 0.0;
+    w[i] = (i < L) ? fr[i] : 0.0;
+  }
+  int n = 0;
+  // full steps: every lag of steps n .. n+P-1 is inside the frame and so is the refill fr[n+u+P]
+  for (; n + 2 * P - 1 < L; n += P) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const double x = w[u];                               // fr[n+u]; w[(u+i) % P] = fr[n+u+i]
+#pragma unroll
+      for (int i = 0; i < P; ++i) acc[i] = acc[i] + x * w[(u + i) % P];
+      w[u] = fr[n + u + P];
+    }
+  }
+  // tail: lags run off the end of the frame one by one
+  for (; n < L; ++n) {
+    const double x = fr[n];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+      if (n + i < L) acc[i] = acc[i] + x * fr[n + i];
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) r_out[f * P + i] = acc[i];
+  }
+}
+
+typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
+static acorr_lane_fn pick_acorr_lane(int P) {
+  switch (P) {
+    case 9: return k_acorr_lane<9>;
+    case 11: return k_acorr_lane<11>;
+    case 13: return k_acorr_lane<13>;
+    case 17: return k_acorr_lane<17>;
+    case 21: return k_acorr_lane<21>;
+    case 25: return k_acorr_lane<25>;
+    case 33: return k_acorr_lane<33>;
+    default: return nullptr;
+  }
+}
+
+static constexpr int kLevMax = 32;
+
+__global__ __launch_bounds__(64) void k_levinson_lane(const double *__restrict__ r_in, int64_t n_frames,
+                                                       int n_lags, int order, double *__restrict__ coefs,
+                                                       double *__restrict__ err, int *__restrict__ status) {
+  const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (f >= n_frames) return;
+  double r[kLevMax + 1], a[kLevMax + 1];
+#pragma unroll
+  for (int i = 0; i <= kLevMax; ++i) {
+    r[i] = (i <= order && i < n_lags) ? r_in[f * n_lags + i] : 0.0;   // zero-extended lags (lazy_lpc.py:117-118)
+    a[i] = 0.0;
+  }
+  a[0] = 1.0;
+  double E = r[0];
+  int st = ALZ_OK;
+#pragma unroll
+  for (int m = 1; m <= kLevMax; ++m) {
+    if (m <= order) {   // (no break: the loop must unroll fully to keep a[] and r[] in registers)
+    double num = r[m];
+#pragma unroll
+    for (int i = 1; i < m; ++i) num = num + a[i] * r[m - i];
+    if (E == 0.0) st = ALZ_E_PARCOR;                 // inner(B, B) == 0, lazy_lpc.py:132-133
+    const double k = (st == ALZ_OK) ? -(num / E) : 0.0;
+#pragma unroll
+    for (int i = 1; 2 * i <= m; ++i) {
+      const double ai = a[i], aj = a[m - i];
+      a[i] = ai + k * aj;
+      if (2 * i != m) a[m - i] = aj + k * ai;
+    }
+    a[m] = k;
+    E = E * (1.0 - k * k);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i <= kLevMax; ++i)
+    if (i <= order) coefs[f * (order + 1) + i] = a[i];
+  err[f] = E;
+  status[f] = st;
+}
+
+// dense acorr launch; returns false (and launches nothing) when the staged frames do not fit LDS
+static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_len, int64_t hop,
+                               int max_lag, double *r_out, hipStream_t st, int *rc) {
+  *rc = ALZ_OK;
+  const int P = max_lag + 1;
+  // lane-per-frame form for the usual orders when there are enough frames to fill the chip
+  if (acorr_lane_fn lane_fn = (n_frames >= 16384 && frame_len >= 2 * P) ? pick_acorr_lane(P) : nullptr) {
+    hipLaunchKernelGGL(lane_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, sig, n_frames,
+                       frame_len, hop, r_out);
+    if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_lane launch failed");
+    return true;
+  }
+  if (P > 64) return false;
+  const int nfr_max = 64 / P + 2;
+  const size_t lds = (size_t)nfr_max * (((frame_len + 15) / 32) * 32 + 16) * sizeof(double);
+  if (lds > 64 * 1024) return false;
+  const int64_t total = n_frames * P;
+  hipLaunchKernelGGL(k_acorr_dense, dim3((unsigned)((total + 63) / 64)), dim3(64), lds, st, sig, n_frames,
+                     frame_len, hop, P, r_out);
+  if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_dense launch failed");
+  return true;
+}
+
 static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_t hop, int order,
                       double *coefs, double *err, int *status, double *r_out, int from_r,
                       hipStream_t st) {
@@ -129,8 +301,30 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
-  int rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, order, coefs_dev, err_dev, status_dev,
-                           nullptr, 0, (hipStream_t)stream);
+  int rc = ALZ_OK;
+  bool done = false;
+  if (order <= alz::kLevMax && n_frames > 0) {
+    // two passes through a stream-ordered scratch array of lags
+    double *r_tmp = nullptr;
+    const size_t bytes = (size_t)n_frames * (order + 1) * sizeof(double);
+    if (hipMallocAsync((void **)&r_tmp, bytes, (hipStream_t)stream) == hipSuccess) {
+      if (alz::launch_acorr_dense(sig_dev, n_frames, frame_len, hop, order, r_tmp, (hipStream_t)stream, &rc)) {
+        if (rc == ALZ_OK) {
+          hipLaunchKernelGGL(alz::k_levinson_lane, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0,
+                             (hipStream_t)stream, r_tmp, n_frames, order + 1, order, coefs_dev, err_dev,
+                             status_dev);
+          if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_levinson_lane launch failed");
+        }
+        done = true;
+      }
+      (void)hipFreeAsync(r_tmp, (hipStream_t)stream);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (!done)
+    rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, order, coefs_dev, err_dev, status_dev,
+                         nullptr, 0, (hipStream_t)stream);
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }
@@ -142,8 +336,17 @@ int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int orde
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
-  int rc = alz::launch_lpc(r_dev, n_frames, n_lags, n_lags, order, coefs_dev, err_dev, status_dev,
-                           nullptr, 1, (hipStream_t)stream);
+  int rc = ALZ_OK;
+  if (order <= alz::kLevMax) {
+    if (n_frames > 0) {
+      hipLaunchKernelGGL(alz::k_levinson_lane, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0,
+                         (hipStream_t)stream, r_dev, n_frames, n_lags, order, coefs_dev, err_dev, status_dev);
+      if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_levinson_lane launch failed");
+    }
+  } else {
+    rc = alz::launch_lpc(r_dev, n_frames, n_lags, n_lags, order, coefs_dev, err_dev, status_dev, nullptr, 1,
+                         (hipStream_t)stream);
+  }
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }
@@ -154,8 +357,11 @@ int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
-  int rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, max_lag, nullptr, nullptr, nullptr,
-                           r_dev, 0, (hipStream_t)stream);
+  int rc = ALZ_OK;
+  if (n_frames <= 0 || !alz::launch_acorr_dense(sig_dev, n_frames, frame_len, hop, max_lag, r_dev,
+                                                (hipStream_t)stream, &rc))
+    rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, max_lag, nullptr, nullptr, nullptr, r_dev, 0,
+                         (hipStream_t)stream);
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }

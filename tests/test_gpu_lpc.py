@@ -111,3 +111,30 @@ def test_reference_operator_surface(lpc):
     alz.lpc.kautocor([0.] * 32, 4)
   with pytest.raises(ZeroDivisionError):
     alz.levinson_durbin([0., 0., 0.])
+
+
+def test_large_batch_lane_kernels_bit_exact_acorr(lpc):
+  """>= 16384 frames take the lane-per-frame kernels (k_acorr_lane / k_levinson_lane): acorr must
+  still be bit-identical to the oracle's left-to-right sums, including overlapping frames."""
+  from oracle import oracle
+  rng = np.random.default_rng(123)
+  L, hop, order, F = 480, 240, 16, 20000
+  sig = rng.uniform(-1, 1, (F - 1) * hop + L)
+  sig[5 * hop: 5 * hop + L] = 0.0
+  r = lpc.acorr_frames(sig, L, order, hop=hop)
+  pick = [0, 1, 5, 777, F - 1]
+  for f in pick:
+    assert np.array_equal(r[f].view(np.uint64), oracle.acorr(sig[f * hop: f * hop + L], order).view(np.uint64))
+  c, e, st = lpc.kautocor_frames(sig, L, order, hop=hop)
+  rc, re, rst = oracle.kautocor_frames(sig, F, L, hop, order)
+  assert st[5] == -4 and rst[5] == -4
+  ok = rst == 0
+  assert np.array_equal(st == 0, ok)
+  assert (np.abs(c[ok] - rc[ok]).max(axis=1) / np.abs(rc[ok]).max(axis=1)).max() <= TOL
+  assert (np.abs(e[ok] - re[ok]) / np.abs(re[ok])).max() <= TOL
+  # a short frame length (tail loop only) and an odd order that has no lane instantiation
+  sig2 = rng.uniform(-1, 1, 17000 * 40)
+  r2 = lpc.acorr_frames(sig2, 40, 16)
+  assert np.array_equal(r2[16999].view(np.uint64), oracle.acorr(sig2[16999 * 40:], 16).view(np.uint64))
+  r3 = lpc.acorr_frames(sig2, 40, 7)
+  assert np.array_equal(r3[3].view(np.uint64), oracle.acorr(sig2[120:160], 7).view(np.uint64))
