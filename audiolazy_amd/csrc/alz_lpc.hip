@@ -14,6 +14,10 @@
 // recursion, mathematically the reference's update
 //   A -= inner(A, z**-m) / inner(B, B) * B      (lazy_lpc.py:128-131)
 // with inner(B, B) carried as the running prediction error.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "alz_common.h"
 
 namespace alz {
@@ -183,7 +187,127 @@ __global__ __launch_bounds__(64) void k_acorr_lane(const double *__restrict__ si
   }
 }
 
+// k_acorr_stage<P>: the same lane-per-frame sums, with the samples staged through LDS so that
+// HBM/L2 see full 128-byte rows: a wave owns 64 frames and walks them in chunks of 16 samples;
+// each chunk (64 frames x 128 B) arrives as eight 1 KiB global_load_lds DMA transfers into a
+// 3-slot ring, XOR-swizzled on the global side so the lanes (one per frame) read their 16-byte
+// pieces from distinct banks.  Products are formed "by later index" -- a new sample x[m] meets
+// x[m-i] for every lag i -- which adds each lag's terms in the same ascending order as the
+// reference (bit-exact) and needs only the previous chunk(s) as history, all statically indexed.
+// Needs frame starts on 16-byte boundaries (even hop) and P <= 33.
+__device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
+                                                     int frame_len, int64_t hop, double *__restrict__ r_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = (P - 1 + 15) / 16;       // chunks of history needed (1 for P <= 17, 2 for P <= 33)
+  const int lane = threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.x * 64;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const int L = frame_len;
+  const int nchunks = (L + 15) / 16;
+  // DMA source of this lane for transfer j of chunk c: frame f0 + 8j + lane/8, piece (lane%8)^(frame%8)
+  // (frames past the end are clamped to the last one: loaded, never stored)
+  auto src_of = [&](int j, int c) -> const double * {
+    int64_t fr = f0 + 8 * j + lane / 8;
+    if (fr > n_frames - 1) fr = n_frames - 1;
+    const int piece = (lane % 8) ^ (int)((8 * j + lane / 8) & 7);
+    int64_t s0 = (int64_t)16 * c + 2 * piece;
+    if (s0 > L - 2) s0 = (L >= 2) ? ((L - 2) & ~1) : 0;   // keep the (aligned) 16-byte read inside the frame
+    return sig + fr * hop + s0;
+  };
+  auto queue = [&](int c) {
+    const unsigned slot = lds0 + (unsigned)(c % 3) * 8192u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lpc_dma16(src_of(j, c), slot + j * 1024);
+  };
+  const int64_t f = f0 + lane;
+  const bool live = f < n_frames;
+  double acc[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) acc[i] = 0.0;
+  double hist[H * 16];                        // hist[k] = x[16*c - 1 - k] ... kept as previous chunks
+#pragma unroll
+  for (int k = 0; k < H * 16; ++k) hist[k] = 0.0;
+
+  queue(0);
+  if (nchunks > 1) queue(1);
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 2 < nchunks) queue(c + 2);
+    // transfers issued after chunk c's: chunks c+1, c+2 (those that exist)
+    const int after = (nchunks - 1 - c < 2) ? (nchunks - 1 - c) : 2;
+    if (after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char *slot = smem + (c % 3) * 8192 + lane * 128;
+    double cur[16];
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const d2 v = *reinterpret_cast<const d2 *>(slot + ((pc ^ (lane & 7)) * 16));
+      cur[2 * pc] = v.x;
+      cur[2 * pc + 1] = v.y;
+    }
+    const int valid = L - 16 * c;             // samples of this chunk inside the frame (>= 1)
+    // x[m - i] is inside this chunk (u >= i) or in the history (hist[k] = x[16c - 1 - k]); only the
+    // first H chunks have lags that reach before the start of the frame (checked form)
+    auto chunk = [&](auto checked) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (u < valid) {
+          const double xm = cur[u];
+#pragma unroll
+          for (int i = 0; i < P; ++i) {
+            const double xe = (u - i >= 0) ? cur[u - i >= 0 ? u - i : 0] : hist[(i - u - 1) < H * 16 ? (i - u - 1) : 0];
+            if constexpr (decltype(checked)::value) {
+              if (u - i >= 0 || 16 * c + u - i >= 0) acc[i] = acc[i] + xe * xm;
+            } else {
+              acc[i] = acc[i] + xe * xm;
+            }
+          }
+        }
+      }
+    };
+    if (c < H) chunk(std::true_type{});
+    else chunk(std::false_type{});
+    // history for the next chunk
+#pragma unroll
+    for (int k = H * 16 - 1; k >= 16; --k) hist[k] = hist[k - 16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hist[k] = cur[15 - k];
+  }
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) r_out[f * P + i] = acc[i];
+  }
+}
+
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
+static acorr_lane_fn pick_acorr_stage(int P) {
+  switch (P) {
+    case 9: return k_acorr_stage<9>;
+    case 11: return k_acorr_stage<11>;
+    case 13: return k_acorr_stage<13>;
+    case 17: return k_acorr_stage<17>;
+    case 21: return k_acorr_stage<21>;
+    case 25: return k_acorr_stage<25>;
+    case 33: return k_acorr_stage<33>;
+    default: return nullptr;
+  }
+}
+
 static acorr_lane_fn pick_acorr_lane(int P) {
   switch (P) {
     case 9: return k_acorr_lane<9>;
@@ -244,6 +368,14 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   *rc = ALZ_OK;
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
+  static const int stage_env = getenv("ALZ_LPC_STAGE") ? atoi(getenv("ALZ_LPC_STAGE")) : 1;
+  if (acorr_lane_fn st_fn = (stage_env && n_frames >= 16384 && frame_len >= 32 && (hop % 2) == 0 &&
+                             ((uintptr_t)sig & 15) == 0) ? pick_acorr_stage(P) : nullptr) {
+    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, st, sig, n_frames,
+                       frame_len, hop, r_out);
+    if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
+    return true;
+  }
   if (acorr_lane_fn lane_fn = (n_frames >= 16384 && frame_len >= 2 * P) ? pick_acorr_lane(P) : nullptr) {
     hipLaunchKernelGGL(lane_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, sig, n_frames,
                        frame_len, hop, r_out);
