@@ -228,6 +228,24 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
       if (nz && k > 32) d.present_a |= 0x80000000u;
     }
     for (int64_t q = 0; q < n_sets; ++q) d.any_div |= a_host[q * ta + aoff] != 1.0;
+    d.n_ff = d.n_fb = 0;
+    for (int j = 0; j < 8; ++j) d.tap_b[j] = d.tap_a[j] = 0;
+    for (int k = 0; k < nb[s]; ++k) {
+      bool nz = false;
+      for (int64_t q = 0; q < n_sets && !nz; ++q) nz = b_host[q * tb + boff + k] != 0.0;
+      if (nz) {
+        if (d.n_ff >= 0 && d.n_ff < 8) d.tap_b[d.n_ff++] = k;
+        else d.n_ff = -1;
+      }
+    }
+    for (int k = 1; k < na[s]; ++k) {
+      bool nz = false;
+      for (int64_t q = 0; q < n_sets && !nz; ++q) nz = a_host[q * ta + aoff + k] != 0.0;
+      if (nz) {
+        if (d.n_fb >= 0 && d.n_fb < 8) d.tap_a[d.n_fb++] = k;
+        else d.n_fb = -1;
+      }
+    }
     h->sec.push_back(d);
     boff += nb[s];
     aoff += na[s];

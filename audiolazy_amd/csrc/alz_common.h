@@ -35,6 +35,10 @@ struct SectionDev {
   bool uniform;        // every set has the same zero pattern
   bool any_div;        // some a_0 != 1
   bool shared_sets;    // n_sets == 1
+  // sparse view: delays of the taps that are non-zero for at least one set (ascending);
+  // n_ff / n_fb = -1 when there are more than 8 of them
+  int n_ff, n_fb;
+  int tap_b[8], tap_a[8];
 };
 
 // Block description handed to the launchers.
@@ -60,6 +64,10 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
 // samples / channels it covered (full 16-sample tiles of full 64-channel groups)
 int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
                    int64_t *done_samples, int64_t *done_channels, const char **kernel_name);
+// alz_comb.hip: sparse sections whose feedback delays are all long (comb filters), time-major,
+// x != y; *taken says whether the shape was this kernel's
+int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
+                  const char **kernel_name);
 // alz_fir.hip: long feedback-free sections on time-major blocks (x != y); *taken says whether
 // the shape was this kernel's
 int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,

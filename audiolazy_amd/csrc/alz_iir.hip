@@ -307,7 +307,10 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   } else {
     if (io.x == io.y) return fail(ALZ_E_ARG, "k_fir / k_generic cannot run in place");
     bool taken = false;
-    int rc = launch_fir(sec, io, stream, &taken, kernel_name);
+    int rc = launch_sparse(sec, io, stream, &taken, kernel_name);
+    if (rc) return rc;
+    if (taken) return ALZ_OK;
+    rc = launch_fir(sec, io, stream, &taken, kernel_name);
     if (rc) return rc;
     if (taken) return ALZ_OK;
     const int64_t nx = (int64_t)(sec.nb - 1) * io.channels;

@@ -355,3 +355,32 @@ def test_fir_config3_width_properties(alz):
   bank.reset()
   h = bank.process(imp)[:, 123].cpu().numpy()
   assert np.array_equal(h[:256], np.array(hamming_sinc())) and np.all(h[256:] == 0)
+
+
+@pytest.mark.parametrize("D,alpha", [(16, 0.5), (109, 0.97), (441, -0.9)])
+def test_long_feedback_combs_use_the_sparse_kernel(alz, oracle, D, alpha):
+  """comb.fb / comb.tau with long delays (lazy_filters.py:1090-1147) and a linearize()d-style
+  two-tap feedback: the delay line is the block itself; bit-exact, state carried across blocks."""
+  rng = np.random.default_rng(D)
+  C, N = 80, 3 * D + 37
+  x = rng.uniform(-1, 1, (N, C))
+  a = np.zeros(D + 2)
+  a[0], a[D], a[D + 1] = 1.0, -alpha * 0.75, -alpha * 0.25     # two adjacent feedback taps
+  b = np.array([1.0, 0.0, 0.5])
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  mem = rng.uniform(-1, 1, D + 1).tolist()
+  bank.reset(memory=mem, zero=0.0)
+  y = bank.process(x)
+  assert bank.last_kernel == "k_sparse"
+  yh = np.tile(np.array(mem), (C, 1))
+  ref = oracle.bank([3], [D + 2], b, a, x, xh=np.zeros((C, 2)), yh=yh.copy())
+  assert same_bits(y, ref)
+  x2 = rng.uniform(-1, 1, (D // 2 + 3, C))       # a block shorter than the delay line
+  whole = oracle.bank([3], [D + 2], b, a, np.concatenate([x, x2]), xh=np.zeros((C, 2)), yh=yh.copy())
+  assert same_bits(bank.process(x2), whole[N:])
+  # per-channel coefficients
+  al = rng.uniform(0.5, 0.99, C)
+  a2 = np.zeros((C, D + 1)); a2[:, 0] = 1.0; a2[:, D] = -al
+  bank2 = alz.FilterBank([(np.ones((C, 1)), a2)], n_inputs=C)
+  bank2.reset()
+  assert same_bits(bank2.process(x), oracle.bank([1], [D + 1], np.ones((C, 1)), a2, x)) and bank2.last_kernel == "k_sparse"
