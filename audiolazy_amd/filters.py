@@ -69,6 +69,25 @@ class LinearFilter(object):
   def copy(self):
     return type(self)(self.numpoly.copy(), self.denpoly.copy())
 
+  def linearize(self):
+    """Replace every fractional delay by the linear interpolation of its two integer
+    neighbours: ``z ** -4.3`` becomes ``0.7 * z ** -4 + 0.3 * z ** -5`` (reference :339-373);
+    this is what makes a ``comb`` at a non-integer period (``karplus_strong``) executable."""
+    sides = []
+    for poly in (self.numpoly, self.denpoly):
+      out = {}
+      for k, v in poly.terms():
+        if isinstance(k, int) or (isinstance(k, float) and k.is_integer()):
+          parts = [(int(k), v)]
+        else:
+          lo = int(k)
+          w_hi = k - lo
+          parts = [(lo, v * (1. - w_hi)), (lo + 1, v * w_hi)]
+        for key, val in parts:
+          out[key] = out[key] + val if key in out else val
+      sides.append(out)
+    return type(self)(*sides)
+
   def __eq__(self, other):
     return isinstance(other, LinearFilter) and self.numpoly == other.numpoly \
         and self.denpoly == other.denpoly

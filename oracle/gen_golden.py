@@ -276,6 +276,22 @@ def blocks_cases():
   return out
 
 
+# --------------------------------------------------------------------------
+# 8. karplus_strong (lazy_synth.py:624-657): comb.tau at a fractional period, linearize(),
+#    callable memory (white_noise) -- seeded so the noise is reproducible
+# --------------------------------------------------------------------------
+def karplus_case():
+  from audiolazy import karplus_strong
+  out = []
+  for seed, f, tau in ((77, 440., 2e4), (5, 1234.5, 3000.)):
+    random.seed(seed)
+    ks = karplus_strong(f * Hz, tau)
+    y = ks.take(1500)
+    filt = comb.tau(2 * 3.141592653589793 / (f * Hz), tau).linearize()
+    out.append(dict(seed=seed, freq=hx(f * Hz), tau=hx(tau), b=hx(filt.numlist), a=hx(filt.denlist), y=hx(y)))
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   dump("filters.json", filt_cases())
@@ -286,3 +302,4 @@ if __name__ == "__main__":
   dump("multichannel.json", multichannel_case())
   dump("lpc.json", lpc_cases())
   dump("blocks.json", blocks_cases())
+  dump("karplus.json", karplus_case())

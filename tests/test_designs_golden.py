@@ -95,3 +95,13 @@ def test_erb_and_constants():
   assert erb(3000.) == pytest.approx(348.517, abs=5e-4)
   with pytest.raises(ValueError):
     erb(3.)                                    # "Frequency out of range", lazy_auditory.py:65-67
+
+
+def test_linearize_and_karplus_filter_coefficients():
+  import math
+  f = (z ** -4.3).linearize()                       # lazy_filters.py:350-352
+  np.testing.assert_allclose(f.numlist, [0, 0, 0, 0, 0.7, 0.3], atol=1e-15)
+  for case in load_golden("karplus.json"):
+    filt = comb.tau(2 * math.pi / unhex(case["freq"]), unhex(case["tau"])).linearize()
+    assert bits(filt.numlist) == bits(unhex(case["b"]))
+    assert bits(filt.denlist) == bits(unhex(case["a"]))

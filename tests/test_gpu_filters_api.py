@@ -176,3 +176,14 @@ def test_fused_diagonal_cascade_of_biquads(al):
   ref = oracle.bank([3, 3], [3, 3], np.concatenate([b1, b2], axis=1), np.concatenate([a1, a2], axis=1), x,
                     xh=np.full((C, 4), 0.125), yh=yh, zero=0.125)
   assert same_bits(y, ref)
+
+
+def test_karplus_strong_golden(al):
+  """lazy_synth.py:624-657 end to end: seeded white_noise memory (a callable), fractional-period
+  comb linearized to two feedback taps, endless input of zeros -- bit-exact with the reference."""
+  import random
+  for case in load_golden("karplus.json"):
+    random.seed(case["seed"])
+    ks = al.karplus_strong(unhex(case["freq"]), unhex(case["tau"]))
+    y = ks.take(1500)
+    assert same_bits(y, unhex(case["y"]))
