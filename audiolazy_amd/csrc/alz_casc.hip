@@ -252,14 +252,14 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
 // Section order, term order and rounding are unchanged: stage s+1 consumes exactly the doubles
 // stage s produced.
 // ---------------------------------------------------------------------------
-static constexpr int kPXRing = 3;
-static constexpr int kPSlots = kPXRing + 2 + 2 + 2 + 2;   // x ring, q1, q2, q3, y rings
+static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per workgroup (a tile is only 16 steps long)
 
-template <bool CM, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
-          unsigned PB3, unsigned PA3>
-__global__ __launch_bounds__(320) void k_pipe(CArgs p) {
+// SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
+template <bool CM, int SPW, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
+          unsigned PA2, unsigned PB3, unsigned PA3>
+__global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int G = 64, T = 16;
+  constexpr int G = 64, T = 16, NW = 4 / SPW;
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -272,17 +272,17 @@ __global__ __launch_bounds__(320) void k_pipe(CArgs p) {
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   char *xring = smem;
-  char *qring = smem + kPXRing * kCSlot;                 // q1 | q2 | q3 : 2 slots each
-  char *yring = qring + 6 * kCSlot;
-  // DMA-layout element offsets (x ring and y ring), as in k_casc
+  char *qring = smem + kPXRing * kCSlot;                 // NW-1 hand-off rings, 2 slots each
+  char *yring = qring + (NW - 1) * 2 * kCSlot;
   const int lane_off = CM ? (lane / 8) * 1040 + (lane % 8) * 128 : lane * 8;
   int swz[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
 #define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
 
-  if (wave == 4) {
-    // ------------------------------ AUX ------------------------------
+  if (wave >= NW) {
+    // ---------------- helpers: wave NW queues the tile DMA, wave NW+1 stores finished tiles ----------------
+    // (two waves, because loads and stores of one wave share one in-order vmcnt counter of 63)
     int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
     if (!CM) {
       const int row = lane / 32, cp = lane % 32;
@@ -299,67 +299,88 @@ __global__ __launch_bounds__(320) void k_pipe(CArgs p) {
     }
     const double *xg = p.x + x_off;
     double *yg = p.y + y_off;
-    auto queue_tile = [&](int64_t t) {
-      const int s = (int)(t % kPXRing);
+    constexpr int D = kPXRing - 1;                          // tiles queued ahead
+    if (wave == NW) {
+      auto queue_tile = [&](int64_t t) {
+        const int s = (int)(t % kPXRing);
 #pragma unroll
-      for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kCSlot + j * 1040);
-    };
-    auto store_tile = [&](int64_t t) {
-      const char *ys = yring + (int)(t % 2) * kCSlot;
-      double *yt = yg + t * y_tile;
-      cdbl2 w[kCChunks];
-#pragma unroll
-      for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
-#pragma unroll
-      for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
-    };
-    if (!(p.dbg & 1)) queue_tile(0);
-    if (nt > 1 && !(p.dbg & 1)) queue_tile(1);
-    c_wait_vm((nt > 1 && !(p.dbg & 1)) ? 8 : 0);                              // tile 0 has landed
-    __builtin_amdgcn_s_barrier();
-    for (int64_t t = 0; t < nt + 4; ++t) {
-      const bool st = t >= 4 && t - 4 < nt;
-      const bool ld = t + 2 < nt;
-      if (st && !(p.dbg & 4)) store_tile(t - 4);
-      if (ld && !(p.dbg & 1)) queue_tile(t + 2);
-      if (t + 1 < nt) c_wait_vm((p.dbg & 5) ? 0 : ((st ? 1 : 0) + (ld ? 1 : 0)) * 8);   // tile t+1 has landed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kCSlot + j * 1040);
+      };
+      const bool on = !(p.dbg & 1);
+      for (int t = 0; t < D && t < nt && on; ++t) queue_tile(t);
+      {
+        const int64_t after = ((nt < D ? nt : D) - 1);
+        c_wait_vm(on ? (int)(after > 5 ? 5 : after) * 8 : 0);   // tile 0 has landed
+      }
       __builtin_amdgcn_s_barrier();
+      for (int64_t t = 0; t < nt + NW; ++t) {
+        if (t + D < nt && on) queue_tile(t + D);
+        if (t + 1 < nt) {
+          const int64_t last = (t + D < nt - 1) ? t + D : nt - 1;
+          c_wait_vm(on ? (int)(last - (t + 1)) * 8 : 0);     // tile t+1 has landed
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      __builtin_amdgcn_s_barrier();
+      for (int64_t t = 0; t < nt + NW; ++t) {
+        if (t >= NW && t - NW < nt && !(p.dbg & 4)) {
+          const int64_t tt = t - NW;
+          const char *ys = yring + (int)(tt % 2) * kCSlot;
+          double *yt = yg + tt * y_tile;
+          cdbl2 w[kCChunks];
+#pragma unroll
+          for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
+#pragma unroll
+          for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    // --------------------------- section `wave` ---------------------------
-    double bc[8], na1 = 0, na2 = 0, dx[7], m1, m2;
-    int nbv = 1, nav = 1;
-    unsigned pbv = 0, pav = 0;
+    // ------------------ stage `wave`: sections wave*SPW .. wave*SPW + SPW - 1 ------------------
+    double bc[SPW][8], na1[SPW], na2[SPW], dx[SPW][7], m1[SPW], m2[SPW];
+    int nbv[SPW], nav[SPW];
+    const double *bsrc[SPW], *asrc[SPW];
+    double *xhs[SPW], *yhs[SPW];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (wave == s) { pbv = PBS[s]; pav = PAS[s]; nbv = p.nb[s]; nav = p.na[s]; }
-    const double *bsrc = p.b[0], *asrc = p.a[0];
-    double *xhs = p.xh[0], *yhs = p.yh[0];
+    for (int j = 0; j < SPW; ++j) {
+      unsigned pbv = 0, pav = 0;
+      nbv[j] = 1; nav[j] = 1;
+      bsrc[j] = p.b[0]; asrc[j] = p.a[0]; xhs[j] = p.xh[0]; yhs[j] = p.yh[0];
 #pragma unroll
-    for (int s = 1; s < 4; ++s)
-      if (wave == s) { bsrc = p.b[s]; asrc = p.a[s]; xhs = p.xh[s]; yhs = p.yh[s]; }
+      for (int s = 0; s < 4; ++s)
+        if (wave * SPW + j == s) {
+          pbv = PBS[s]; pav = PAS[s]; nbv[j] = p.nb[s]; nav[j] = p.na[s];
+          bsrc[j] = p.b[s]; asrc[j] = p.a[s]; xhs[j] = p.xh[s]; yhs[j] = p.yh[s];
+        }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bc[k] = ((pbv >> k) & 1u) ? bsrc[(int64_t)k * p.n_sets + set] : 0.0;
-    if (pav & 1u) na1 = -asrc[1 * p.n_sets + set];
-    if (pav & 2u) na2 = -asrc[2 * p.n_sets + set];
+      for (int k = 0; k < 8; ++k) bc[j][k] = ((pbv >> k) & 1u) ? bsrc[j][(int64_t)k * p.n_sets + set] : 0.0;
+      na1[j] = (pav & 1u) ? -asrc[j][1 * p.n_sets + set] : 0.0;
+      na2[j] = (pav & 2u) ? -asrc[j][2 * p.n_sets + set] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) dx[k] = (k < nbv - 1) ? xhs[(int64_t)k * p.channels + c] : 0.0;
-    m1 = (nav > 1) ? yhs[0 * p.channels + c] : 0.0;
-    m2 = (nav > 2) ? yhs[1 * p.channels + c] : 0.0;
-    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
+      for (int k = 0; k < 7; ++k) dx[j][k] = (k < nbv[j] - 1) ? xhs[j][(int64_t)k * p.channels + c] : 0.0;
+      m1[j] = (nav[j] > 1) ? yhs[j][0 * p.channels + c] : 0.0;
+      m2[j] = (nav[j] > 2) ? yhs[j][1 * p.channels + c] : 0.0;
+    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bc[k]));
+    for (int j = 0; j < SPW; ++j) {
+      asm volatile("" : "+v"(na1[j]), "+v"(na2[j]), "+v"(m1[j]), "+v"(m2[j]));
 #pragma unroll
-    for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(dx[k]));
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(bc[j][k]));
+#pragma unroll
+      for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(dx[j][k]));
+    }
 
     __builtin_amdgcn_s_barrier();
-    for (int64_t t = 0; t < nt + 4; ++t) {
+    for (int64_t t = 0; t < nt + NW; ++t) {
       const int64_t tile = t - wave;
       if (tile >= 0 && tile < nt) {
         double v[16];
-        // input: section 0 reads the DMA layout, the others the lane-private hand-off layout
+        // input: stage 0 reads the DMA layout, the others the lane-private hand-off layout
         if (wave == 0) {
           const char *src = xring + (int)(tile % kPXRing) * kCSlot + lane_off;
 #pragma unroll
@@ -373,12 +394,17 @@ __global__ __launch_bounds__(320) void k_pipe(CArgs p) {
             v[2 * j + 1] = w.y;
           }
         }
-        if (p.dbg & 2) { m1 = v[3]; }
-        else if (wave == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc, na1, na2, dx, m1, m2);
-        else if (wave == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc, na1, na2, dx, m1, m2);
-        else if (wave == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc, na1, na2, dx, m1, m2);
-        else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc, na1, na2, dx, m1, m2);
-        if (wave == 3) {
+        if (!(p.dbg & 2)) {
+#pragma unroll
+          for (int j = 0; j < SPW; ++j) {
+            const int s = wave * SPW + j;
+            if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+          }
+        }
+        if (wave == NW - 1) {
           char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
 #pragma unroll
           for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
@@ -397,10 +423,13 @@ __global__ __launch_bounds__(320) void k_pipe(CArgs p) {
       __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-      if (k < nbv - 1) xhs[(int64_t)k * p.channels + c] = dx[k];
-    if (nav > 1) yhs[0 * p.channels + c] = m1;
-    if (nav > 2) yhs[1 * p.channels + c] = m2;
+    for (int j = 0; j < SPW; ++j) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        if (k < nbv[j] - 1) xhs[j][(int64_t)k * p.channels + c] = dx[j][k];
+      if (nav[j] > 1) yhs[j][0 * p.channels + c] = m1[j];
+      if (nav[j] > 2) yhs[j][1 * p.channels + c] = m2[j];
+    }
   }
 #undef ALZ_COFF
 }
@@ -423,12 +452,12 @@ static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
   return nullptr;
 }
 
-template <bool CM>
+template <bool CM, int SPW>
 static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
 #define ALZ_PIPE(B0, A0, B1, A1, B2, A2, B3, A3)                                                 \
   if (pb[0] == B0 && pa[0] == A0 && pb[1] == B1 && pa[1] == A1 && pb[2] == B2 && pa[2] == A2 &&  \
       pb[3] == B3 && pa[3] == A3)                                                                \
-    return (casc_fn)k_pipe<CM, B0, A0, B1, A1, B2, A2, B3, A3>;
+    return (casc_fn)k_pipe<CM, SPW, B0, A0, B1, A1, B2, A2, B3, A3>;
   ALZ_PIPE(3, 3, 3, 3, 3, 3, 3, 3)        // gammatone.slaney
   ALZ_PIPE(5, 3, 1, 3, 5, 3, 1, 3)        // gammatone.klapuri
   ALZ_PIPE(0xFE, 3, 1, 3, 1, 3, 1, 3)     // gammatone.sampled
@@ -462,8 +491,12 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0) return ALZ_OK;  // a wave = one band
   const int64_t groups = io.channels / 64, tiles = io.n / 16;
   if (groups == 0 || tiles == 0) return ALZ_OK;
-  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
-  casc_fn pipe = (nsec == 4 && pipe_env) ? (cm ? pick_pipe<true>(pb, pa) : pick_pipe<false>(pb, pa)) : nullptr;
+  // ALZ_PIPE: 0 = single-wave k_casc, 1 = one section per stage wave, 2 = two sections per stage wave
+  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 2;
+  casc_fn pipe = nullptr;
+  if (nsec == 4 && pipe_env == 1) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
+  if (nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
+  const int pipe_waves = pipe_env == 2 ? 4 : 6;   // stage waves + loader + storer
   casc_fn fn = pipe ? pipe : (cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
   if (!fn) return ALZ_OK;
   CArgs p;
@@ -476,16 +509,16 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
   }
-  const size_t lds = pipe ? (size_t)kPSlots * kCSlot : (size_t)kCRing * kCSlot;
+  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * kCSlot : (size_t)kCRing * kCSlot;
   if (pipe) {
-    static bool attr[2][3] = {};
+    static bool attr[2][3][3] = {};
     const int pi = pb[0] == 3 ? 0 : pb[0] == 5 ? 1 : 2;
-    if (!attr[cm][pi]) {
+    if (!attr[cm][pi][pipe_env]) {
       ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr[cm][pi] = true;
+      attr[cm][pi][pipe_env] = true;
     }
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 320 : 64), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 64 * pipe_waves : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * 16;
   *done_channels = groups * 64;
