@@ -4,7 +4,8 @@ import torch, numpy as np
 import audiolazy_amd as alz
 from audiolazy_amd import _ffi
 L = _ffi.load()
-F, N, order = 65536, 480, 16
+import os
+F, N, order = int(os.environ.get("LPC_FRAMES", "65536")), 480, 16
 sig = torch.rand(F * N, dtype=torch.float64, device='cuda') * 2 - 1
 coefs = torch.empty((F, order + 1), dtype=torch.float64, device='cuda')
 err = torch.empty(F, dtype=torch.float64, device='cuda'); st = torch.empty(F, dtype=torch.int32, device='cuda')
