@@ -384,3 +384,53 @@ def test_long_feedback_combs_use_the_sparse_kernel(alz, oracle, D, alpha):
   bank2 = alz.FilterBank([(np.ones((C, 1)), a2)], n_inputs=C)
   bank2.reset()
   assert same_bits(bank2.process(x), oracle.bank([1], [D + 1], np.ones((C, 1)), a2, x)) and bank2.last_kernel == "k_sparse"
+
+
+def test_random_structure_sweep(alz, oracle):
+  """Seeded sweep over filter structures: random orders, random zero taps (uniform or per
+  channel), gains, cascades of 1-3 sections, both layouts, ragged sizes -- whatever kernel the
+  dispatcher picks, the result must be the oracle's, bit for bit."""
+  rng = np.random.default_rng(20260924)
+  kernels = set()
+  for trial in range(60):
+    C = int(rng.choice([1, 5, 16, 33, 64, 80, 130]))
+    N = int(rng.choice([1, 9, 64, 65, 200, 517]))
+    nsec = int(rng.choice([1, 1, 2, 3]))
+    layout = "time" if rng.random() < 0.6 else "chan"
+    per_channel = rng.random() < 0.6
+    secs, nbs, nas = [], [], []
+    for _ in range(nsec):
+      nb = int(rng.choice([1, 2, 3, 3, 5, 9, 20]))
+      na = int(rng.choice([1, 2, 3, 3, 3, 4, 7]))
+      rows = C if per_channel else 1
+      b = rng.uniform(-1, 1, (rows, nb))
+      a = np.concatenate([np.ones((rows, 1)), rng.uniform(-1, 1, (rows, na - 1)) * (0.6 / max(na - 1, 1))], axis=1)
+      if rng.random() < 0.5:                       # zero a whole tap column (uniform pattern)
+        b[:, rng.integers(nb)] = 0.0
+      if rng.random() < 0.3 and per_channel:       # zero taps on some channels only (mixed pattern)
+        b[::2, rng.integers(nb)] = 0.0
+      if na > 1 and rng.random() < 0.3:
+        a[:, 1 + rng.integers(na - 1)] = 0.0
+      if rng.random() < 0.25:
+        a[:, 0] = rng.uniform(0.5, 2.0, rows) * rng.choice([-1.0, 1.0])
+      if not np.any(b) and not np.any(a[:, 1:]):
+        b[:, 0] = 0.5
+      secs.append((b if per_channel else b[0], a if per_channel else a[0]))
+      nbs.append(nb); nas.append(na)
+    zero = float(rng.choice([0.0, 0.0, 0.25]))
+    mem = None if rng.random() < 0.5 else rng.uniform(-1, 1, 3).tolist()
+    x = rng.uniform(-1, 1, (N, C) if layout == "time" else (C, N))
+    bank = alz.FilterBank(secs, n_inputs=C)
+    bank.reset(memory=mem, zero=zero)
+    y = bank.process(x, layout=layout)
+    kernels.update(bank.last_kernel.split("+"))
+    bcat = np.concatenate([np.atleast_2d(s[0]) for s in secs], axis=1)
+    acat = np.concatenate([np.atleast_2d(s[1]) for s in secs], axis=1)
+    if not per_channel:
+      bcat, acat = bcat[0], acat[0]
+    xh = np.full((C, max(sum(n - 1 for n in nbs), 1)), zero)
+    yh = np.concatenate([np.array(alz.memory_to_hist(mem, n - 1, zero), dtype=float) for n in nas])
+    yh = np.tile(yh, (C, 1)) if yh.size else np.zeros((C, 1))
+    ref = oracle.bank(nbs, nas, bcat, acat, x, layout=layout, xh=xh, yh=np.ascontiguousarray(yh), zero=zero)
+    assert same_bits(y, ref), (trial, C, N, nbs, nas, layout, per_channel, bank.last_kernel)
+  assert len(kernels) >= 4, kernels      # the sweep really exercised several kernel families
