@@ -217,6 +217,13 @@ class FilterBank(object):
     _ffi.check(self._L.alz_bank_get_state(self._h, xh.ctypes.data_as(_dp), yh.ctypes.data_as(_dp)))
     return xh[:, :self.thx], yh[:, :self.thy]
 
+  def set_fused(self, on=True):
+    """Opt into FMA contraction in the streaming biquad kernel: faster (the recurrence chain is
+    two fused ops instead of four), no longer bit-identical to the reference (differences around
+    1e-13 normalised; the contract is 1e-6).  Off by default."""
+    _ffi.check(self._L.alz_bank_set_fused(self._h, 1 if on else 0))
+    return self
+
   @property
   def last_kernel(self):
     return self._L.alz_bank_last_kernel(self._h).decode()

@@ -34,6 +34,7 @@ struct alz_bank {
   double *xh_dev = nullptr, *yh_dev = nullptr;  // 2x capacity (k_generic's new-state copy)
   std::vector<alz::SectionDev> sec;
   double zero = 0.0;
+  int fused = 0;
   // staging for process_host and for out-of-place generic sections
   double *stage_x = nullptr, *stage_y = nullptr, *scratch = nullptr;
   uint64_t stage_x_bytes = 0, stage_y_bytes = 0, scratch_bytes = 0;
@@ -362,6 +363,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   io.n_sets = h->n_sets;
   io.mode = h->mode;
   io.zero = h->zero;
+  io.fused = h->fused;
   const int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
   // extent of y in elements, for the out-of-place copy some sections need
@@ -481,6 +483,12 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   ALZ_HIP_CHECK(hipStreamSynchronize(nullptr));
   ALZ_HIP_CHECK(hipMemcpy2D(y_host, (size_t)ldy * 8, h->stage_y, (size_t)lsy * 8, (size_t)out_cols * 8,
                             (size_t)out_rows, hipMemcpyDeviceToHost));
+  return ALZ_OK;
+}
+
+int alz_bank_set_fused(alz_bank_t *h, int on) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  h->fused = on ? 1 : 0;
   return ALZ_OK;
 }
 

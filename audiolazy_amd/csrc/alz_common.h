@@ -55,6 +55,7 @@ struct BlockIO {
   int mode;           // ALZ_BANK_DIAGONAL / ALZ_BANK_OUTER
   int map_input;      // OUTER mode: this launch reads the n_inputs input channels
   double zero;        // what an all-zero section yields (lazy_filters.py:227-231)
+  int fused;          // opt-in FMA contraction in the streaming kernels (not bit-exact)
 };
 
 // alz_iir.hip: any section shape, channels [c_first, c_first + c_count)

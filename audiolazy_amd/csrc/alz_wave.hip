@@ -318,7 +318,10 @@ static constexpr int kXRing = 4, kPRing = 3, kYRing = 2;
 // value each lane has just computed stores four rows: no per-step 18-cycle LDS write and no
 // row-select moves either.  y goes to its own small ring (p must stay readable for the lagging
 // groups across the tile boundary).  Group 0 is never behind, so it owns the final state.
-template <bool CM, unsigned PB, unsigned PA>
+// FMA = true is the opt-in fused mode (alz_bank_set_fused): v_fma_f64 instead of separately rounded
+// mul + add -- half the recurrence chain, NOT bit-identical to the reference (differences at the
+// 1e-13 level, far inside the 1e-6 contract).
+template <bool CM, unsigned PB, unsigned PA, bool FMA>
 __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
@@ -397,8 +400,16 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         double acc = 0.0;
         bool first = true;
         if constexpr (PB & 1u) { acc = b0 * xv[j + 2]; first = false; }
-        if constexpr (PB & 2u) { const double v = b1 * xv[j + 1]; acc = first ? v : acc + v; first = false; }
-        if constexpr (PB & 4u) { const double v = b2 * xv[j]; acc = first ? v : acc + v; first = false; }
+        if constexpr (PB & 2u) {
+          if (FMA && !first) acc = __builtin_fma(b1, xv[j + 1], acc);
+          else { const double v = b1 * xv[j + 1]; acc = first ? v : acc + v; }
+          first = false;
+        }
+        if constexpr (PB & 4u) {
+          if (FMA && !first) acc = __builtin_fma(b2, xv[j], acc);
+          else { const double v = b2 * xv[j]; acc = first ? v : acc + v; }
+          first = false;
+        }
         *reinterpret_cast<double *>(ps + (16 * q + j) * kStep) = acc;
       }
     };
@@ -472,8 +483,13 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           double acc = pr[k % 3][u];
-          if constexpr (PA & 1u) acc = acc + na1 * m1;
-          if constexpr (PA & 2u) acc = acc + na2 * m2;
+          if constexpr (FMA) {
+            if constexpr (PA & 1u) acc = __builtin_fma(na1, m1, acc);
+            if constexpr (PA & 2u) acc = __builtin_fma(na2, m2, acc);
+          } else {
+            if constexpr (PA & 1u) acc = acc + na1 * m1;
+            if constexpr (PA & 2u) acc = acc + na2 * m2;
+          }
           if (k == 0 && u < 3 && i == 0) {
             // start of the stream: group q has nothing to do before step q; hold its state
             const bool on = u >= q;
@@ -520,10 +536,10 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   return nullptr;
 }
 
-template <bool CM>
+template <bool CM, bool FMA>
 static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
@@ -562,9 +578,15 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   if (groups == 0 || tiles == 0) return ALZ_OK;
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
-  wave_fn duo = (g == 16 && duo_env) ? (cm ? pick_duo_pattern<true>(sec.present_b, sec.present_a)
-                                           : pick_duo_pattern<false>(sec.present_b, sec.present_a))
-                                     : nullptr;
+  wave_fn duo = nullptr;
+  if (g == 16 && duo_env) {
+    if (io.fused)
+      duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
+               : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
+    else
+      duo = cm ? pick_duo_pattern<true, false>(sec.present_b, sec.present_a)
+               : pick_duo_pattern<false, false>(sec.present_b, sec.present_a);
+  }
   wave_fn fn = duo ? duo : pick_wave(g, cm, sec.present_b, sec.present_a);
   if (!fn) return ALZ_OK;
 
@@ -579,8 +601,8 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)(kXRing + kPRing + kYRing) * kSlotBytes : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
-  static bool attr_set[4][2][64] = {};
-  const int gi = duo ? 3 : g == 16 ? 0 : g == 32 ? 1 : 2;
+  static bool attr_set[5][2][64] = {};
+  const int gi = duo ? (io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
   const unsigned key = (sec.present_b << 2 | sec.present_a) & 63;
   if (!attr_set[gi][cm][key]) {
     ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -591,7 +613,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
   *done_channels = groups * g;
-  *kernel_name = duo ? "k_duo<16>" : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  *kernel_name = duo ? (io.fused ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
   return ALZ_OK;
 }
 

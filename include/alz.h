@@ -107,6 +107,10 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev,
 int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host,
                           int64_t n, int layout, int64_t ldx, int64_t ldy);
 int alz_bank_sync(alz_bank_t *h);
+/* Opt-in fused mode: allow v_fma_f64 contraction in the streaming biquad kernel.  Results are then
+ * NOT bit-identical to the reference generator (normalised differences ~1e-13, contract 1e-6);
+ * default off.  No reference counterpart (CPython floats never fuse).                      */
+int alz_bank_set_fused(alz_bank_t *h, int on);
 
 /* Name of the kernel variant the last process call dispatched to (diagnostic;
  * tests use it to prove the fast paths are the ones exercised).              */

@@ -434,3 +434,26 @@ def test_random_structure_sweep(alz, oracle):
     ref = oracle.bank(nbs, nas, bcat, acat, x, layout=layout, xh=xh, yh=np.ascontiguousarray(yh), zero=zero)
     assert same_bits(y, ref), (trial, C, N, nbs, nas, layout, per_channel, bank.last_kernel)
   assert len(kernels) >= 4, kernels      # the sweep really exercised several kernel families
+
+
+def test_fused_mode_is_opt_in_and_within_contract(alz, oracle):
+  """alz_bank_set_fused: FMA contraction in the streaming kernel.  Floating-point parity only:
+  per channel max|y - y_ref| / max|y_ref| <= 1e-9 (the north star's contract is 1e-6); the
+  default mode stays bit-exact."""
+  rng = np.random.default_rng(31)
+  C, N = 256, 8192
+  b, a = resonator_bank(C)
+  x = rng.uniform(-1, 1, (N, C))
+  ref = oracle.bank([3], [3], b, a, x)
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset()
+  assert same_bits(bank.process(x), ref)                 # default: exact
+  bank.set_fused(True)
+  bank.reset()
+  y = bank.process(x)
+  assert "fma" in bank.last_kernel
+  nerr = (np.abs(y - ref).max(axis=0) / np.abs(ref).max(axis=0)).max()
+  assert nerr <= 1e-9
+  bank.set_fused(False)
+  bank.reset()
+  assert same_bits(bank.process(x), ref)
