@@ -208,9 +208,13 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-template <int P>
+// LEV = true: Levinson-Durbin runs right away on the lane's P lags (still in registers) and the
+// kernel writes coefficients / error / status instead of the lags: lpc.kautocor in one launch.
+template <int P, bool LEV>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
-                                                     int frame_len, int64_t hop, double *__restrict__ r_out) {
+                                                     int frame_len, int64_t hop, double *__restrict__ r_out,
+                                                     double *__restrict__ coefs, double *__restrict__ err,
+                                                     int *__restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = (P - 1 + 15) / 16;       // chunks of history needed (1 for P <= 17, 2 for P <= 33)
   const int lane = threadIdx.x;
@@ -288,24 +292,63 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
 #pragma unroll
     for (int k = 0; k < 16; ++k) hist[k] = cur[15 - k];
   }
-  if (live) {
+  if constexpr (!LEV) {
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) r_out[f * P + i] = acc[i];
+      for (int i = 0; i < P; ++i) r_out[f * P + i] = acc[i];
+    }
+  } else {
+    constexpr int order = P - 1;
+    double a[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) a[i] = 0.0;
+    a[0] = 1.0;
+    double E = acc[0];
+    int st = ALZ_OK;
+#pragma unroll
+    for (int m = 1; m <= order; ++m) {
+      double num = acc[m];
+#pragma unroll
+      for (int i = 1; i < m; ++i) num = num + a[i] * acc[m - i];
+      if (E == 0.0) st = ALZ_E_PARCOR;               // inner(B, B) == 0, lazy_lpc.py:132-133
+      const double k = (st == ALZ_OK) ? -(num / E) : 0.0;
+#pragma unroll
+      for (int i = 1; 2 * i <= m; ++i) {
+        const double ai = a[i], aj = a[m - i];
+        a[i] = ai + k * aj;
+        if (2 * i != m) a[m - i] = aj + k * ai;
+      }
+      a[m] = k;
+      E = E * (1.0 - k * k);
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) coefs[f * P + i] = a[i];
+      err[f] = E;
+      status[f] = st;
+    }
   }
 }
 
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
-static acorr_lane_fn pick_acorr_stage(int P) {
+typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
+template <bool LEV>
+static acorr_stage_fn pick_acorr_stage(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9>;
-    case 11: return k_acorr_stage<11>;
-    case 13: return k_acorr_stage<13>;
-    case 17: return k_acorr_stage<17>;
-    case 21: return k_acorr_stage<21>;
-    case 25: return k_acorr_stage<25>;
-    case 33: return k_acorr_stage<33>;
+    case 9: return k_acorr_stage<9, LEV>;
+    case 11: return k_acorr_stage<11, LEV>;
+    case 13: return k_acorr_stage<13, LEV>;
+    case 17: return k_acorr_stage<17, LEV>;
+    case 21: return k_acorr_stage<21, LEV>;
+    case 25: return k_acorr_stage<25, LEV>;
+    case 33: return k_acorr_stage<33, LEV>;
     default: return nullptr;
   }
+}
+
+static bool stage_ok(const double *sig, int64_t n_frames, int frame_len, int64_t hop) {
+  static const int stage_env = getenv("ALZ_LPC_STAGE") ? atoi(getenv("ALZ_LPC_STAGE")) : 1;
+  return stage_env && n_frames >= 16384 && frame_len >= 32 && (hop % 2) == 0 && ((uintptr_t)sig & 15) == 0;
 }
 
 static acorr_lane_fn pick_acorr_lane(int P) {
@@ -368,11 +411,9 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   *rc = ALZ_OK;
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
-  static const int stage_env = getenv("ALZ_LPC_STAGE") ? atoi(getenv("ALZ_LPC_STAGE")) : 1;
-  if (acorr_lane_fn st_fn = (stage_env && n_frames >= 16384 && frame_len >= 32 && (hop % 2) == 0 &&
-                             ((uintptr_t)sig & 15) == 0) ? pick_acorr_stage(P) : nullptr) {
+  if (acorr_stage_fn st_fn = stage_ok(sig, n_frames, frame_len, hop) ? pick_acorr_stage<false>(P) : nullptr) {
     hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, st, sig, n_frames,
-                       frame_len, hop, r_out);
+                       frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
     return true;
   }
@@ -435,7 +476,16 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
   bool done = false;
-  if (order <= alz::kLevMax && n_frames > 0) {
+  if (n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
+    // one launch: autocorrelation and Levinson-Durbin in the same lane
+    if (alz::acorr_stage_fn fn = alz::pick_acorr_stage<true>(order + 1)) {
+      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, (hipStream_t)stream,
+                         sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
+      if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
+      done = true;
+    }
+  }
+  if (!done && order <= alz::kLevMax && n_frames > 0) {
     // two passes through a stream-ordered scratch array of lags
     double *r_tmp = nullptr;
     const size_t bytes = (size_t)n_frames * (order + 1) * sizeof(double);

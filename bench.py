@@ -139,7 +139,7 @@ def side_workload(args, alz, torch, dev, rank, world, local):
       "metric": metric, "value": world * units * args.steps / elapsed / 1e9, "unit": unit_name,
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_acorr_stage+k_levinson_lane"},
+      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)"},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms_avg": k_ms,
                    "algorithmic_bytes_per_launch": alg_bytes}}))
