@@ -113,6 +113,82 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
   }
 }
 
+// Two consecutive sections over a chunk in ONE loop: step u of section B only needs step u of
+// section A, so step u+1 of A and step u of B are independent chains and the in-order wave can
+// fill one recurrence's result latency with the other's ops (twice the ILP of running the two
+// sections back to back).  Same operations in the same order per section: identical doubles.
+template <int W, int NBA, unsigned PBA, unsigned PAA, int NBB, unsigned PBB, unsigned PAB>
+__device__ __forceinline__ void section_pair_chunk(double (&v)[W], const double (&bA)[8], double na1A,
+                                                   double na2A, double (&dxA)[7], double &m1A, double &m2A,
+                                                   const double (&bB)[8], double na1B, double na2B,
+                                                   double (&dxB)[7], double &m1B, double &m2B) {
+  double pA[W];
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    double acc = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < NBA; ++k) {
+      if ((PBA >> k) & 1u) {
+        const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dxA[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
+        const double t = bA[k] * xv;
+        acc = first ? t : acc + t;
+        first = false;
+      }
+    }
+    pA[u] = acc;
+  }
+  double ndx[7];
+#pragma unroll
+  for (int k = 0; k < NBA - 1; ++k) ndx[k] = (W - 1 - k >= 0) ? v[W - 1 - k < 0 ? 0 : W - 1 - k] : dxA[k - W < 0 ? 0 : k - W];
+#pragma unroll
+  for (int k = 0; k < NBA - 1; ++k) dxA[k] = ndx[k];
+  double av[W];
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    // section A, step u
+    double a = pA[u];
+    if constexpr (PBA != 0u) {
+      if constexpr (PAA & 1u) a = a + na1A * m1A;
+      if constexpr (PAA & 2u) a = a + na2A * m2A;
+    } else {
+      bool first = true;
+      if constexpr (PAA & 1u) { a = na1A * m1A; first = false; }
+      if constexpr (PAA & 2u) { const double t = na2A * m2A; a = first ? t : a + t; }
+    }
+    av[u] = a;
+    m2A = m1A;
+    m1A = a;
+    // section B, step u (its inputs are av[u], av[u-1], ... or its history)
+    double b = 0.0;
+    bool firstb = true;
+#pragma unroll
+    for (int k = 0; k < NBB; ++k) {
+      if ((PBB >> k) & 1u) {
+        const double xv = (u - k >= 0) ? av[u - k < 0 ? 0 : u - k] : dxB[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
+        const double t = bB[k] * xv;
+        b = firstb ? t : b + t;
+        firstb = false;
+      }
+    }
+    if constexpr (PBB != 0u) {
+      if constexpr (PAB & 1u) b = b + na1B * m1B;
+      if constexpr (PAB & 2u) b = b + na2B * m2B;
+    } else {
+      bool first = true;
+      if constexpr (PAB & 1u) { b = na1B * m1B; first = false; }
+      if constexpr (PAB & 2u) { const double t = na2B * m2B; b = first ? t : b + t; }
+    }
+    v[u] = b;
+    m2B = m1B;
+    m1B = b;
+  }
+#pragma unroll
+  for (int k = 0; k < NBB - 1; ++k) ndx[k] = (W - 1 - k >= 0) ? av[W - 1 - k < 0 ? 0 : W - 1 - k] : dxB[k - W < 0 ? 0 : k - W];
+#pragma unroll
+  for (int k = 0; k < NBB - 1; ++k) dxB[k] = ndx[k];
+}
+
 constexpr int nb_of(unsigned pb) {
   int n = 1;
   for (int k = 0; k < 8; ++k)
@@ -395,13 +471,22 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
           }
         }
         if (!(p.dbg & 2)) {
+          if constexpr (SPW == 2) {
+            if (wave == 0)
+              section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1>(
+                  v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
+            else
+              section_pair_chunk<16, nb_of(PB2), PB2, PA2, nb_of(PB3), PB3, PA3>(
+                  v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < SPW; ++j) {
-            const int s = wave * SPW + j;
-            if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            for (int j = 0; j < SPW; ++j) {
+              const int s = wave * SPW + j;
+              if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+              else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+              else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+              else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            }
           }
         }
         if (wave == NW - 1) {
