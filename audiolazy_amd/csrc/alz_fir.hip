@@ -56,6 +56,14 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
   }
   const double a0 = p.a[set];
   const int64_t tb0 = (int64_t)blockIdx.y * kFirTB;
+  // shared taps are staged once in LDS, zero-padded to a multiple of the tap block: every later
+  // tap read is one broadcast ds_read with no bounds test (a zero tap is skipped anyway)
+  extern __shared__ __attribute__((aligned(16))) double tap_lds[];
+  if constexpr (SHARED) {
+    const int padded = ((p.nb + kFirK - 1) / kFirK) * kFirK;
+    for (int k = lane; k < padded; k += 64) tap_lds[k] = (k < p.nb) ? p.b[k] : 0.0;
+    __syncthreads();
+  }
   bool all_zero = false;
   if constexpr (!SHARED) {   // a channel whose taps are all zero yields `zero`
     int nz = 0;
@@ -97,9 +105,9 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
         for (int j = 0; j < kFirK; ++j) xw[j] = load_row(tb + j);
       }
       if constexpr (SHARED) {
-        double bk[kFirK];                                   // wave-uniform taps: scalar loads
+        double bk[kFirK];                                   // wave-uniform taps: broadcast LDS reads
 #pragma unroll
-        for (int kk = 0; kk < kFirK; ++kk) bk[kk] = (kb + kk < p.nb) ? p.b[kb + kk] : 0.0;
+        for (int kk = 0; kk < kFirK; ++kk) bk[kk] = tap_lds[kb + kk];
 #pragma unroll
         for (int kk = 0; kk < kFirK; ++kk) {
           if (bk[kk] == 0.0) continue;                      // absent from the reference's sum
@@ -167,8 +175,10 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const unsigned gy = (unsigned)((io.n + kFirTB - 1) / kFirTB);
   if (gy > 65535u) return ALZ_OK;  // block longer than the grid's y range: caller falls back
+  const size_t tap_bytes = (size_t)((sec.nb + kFirK - 1) / kFirK) * kFirK * sizeof(double);
+  if (sec.shared_sets && tap_bytes > 48 * 1024) return ALZ_OK;   // absurdly long: let k_generic have it
   if (sec.shared_sets)
-    hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
   else
     hipLaunchKernelGGL(k_fir<false>, dim3(gx, gy), dim3(64), 0, stream, p);
   // histories: into the spare half of the state slab, then over the live half
