@@ -57,7 +57,11 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
+#ifdef ALZ_NT_LOADS
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+#else
       "global_load_lds_dwordx4 %1, off\n\t"
+#endif
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
@@ -70,7 +74,11 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
 // s_nop covers the "VMEM store of more than 8 bytes, then overwrite of its data VGPRs" hazard.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
+#ifdef ALZ_NT_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+#else
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+#endif
 }
 
 // wait until at most `n` vector-memory operations of this wave are outstanding.
