@@ -577,9 +577,13 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
   if ((ldx | ldy) & 1) return ALZ_OK;
   // group width: keep at least ~256 waves in flight for small banks
+  // measured on MI355X (gpurun_out/sizes.log): the two-wave kernel (G = 16) wins below ~12k
+  // channels, the single-wave kernel with 64 real lanes from 16k up
   int g = 64;
   if (io.channels < 64 * 256) g = 32;
-  if (io.channels < 32 * 256) g = 16;
+  if (io.channels < 48 * 256) g = 16;
+  static const int g_env = getenv("ALZ_G") ? atoi(getenv("ALZ_G")) : 0;   // tuning override
+  if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
   const int64_t groups = io.channels / g;
   const int t = 8192 / (8 * g);
   const int64_t tiles = io.n / t;
