@@ -42,6 +42,8 @@ struct WArgs {
   int64_t n_tiles;        // full tiles to process
   int64_t channels;       // state array stride
   int64_t c_first;        // first channel handled by this launch
+  int64_t n_inputs;       // OUTER banks: channel = set * n_inputs + input (0: diagonal bank)
+  int map_input;          // OUTER, first section: x is indexed by input, not by channel
   int64_t n_sets;
   int nb, na;
   const double *b, *a;
@@ -116,6 +118,8 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   constexpr int T = 8192 / (8 * G);          // samples per channel per tile
   const int lane = threadIdx.x;
   const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
+  // OUTER bank (n_inputs % G == 0): the G channels of a wave are G adjacent inputs of one set
+  const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;  // low 32 bits of the flat address == LDS offset
 
   // per-lane source/destination offsets (in elements) of the lane's piece in chunk 0 of tile 0,
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     // chunk j holds rows j*R8 .. j*R8+R8-1 with R8 = 128/G rows, each row G ch = G/2 pieces
     constexpr int PPR = G / 2;               // pieces per row
     const int row = lane / PPR, cp = lane % PPR;
-    x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
+    x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
     y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
     x_chunk = (int64_t)(64 / PPR) * p.ldx;
     y_chunk = (int64_t)(64 / PPR) * p.ldy;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     // chunk j holds channels j*C8 .. with C8 = 128/T channels, each channel T samples = T/2 pieces
     constexpr int PPC = T / 2;               // pieces per channel
     const int ch = lane / PPC, sp = lane % PPC;
-    x_off = (c0 + ch) * p.ldx + 2 * sp;
+    x_off = (in0 + ch) * p.ldx + 2 * sp;
     y_off = (c0 + ch) * p.ldy + 2 * sp;
     x_chunk = (int64_t)(64 / PPC) * p.ldx;
     y_chunk = (int64_t)(64 / PPC) * p.ldy;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   const int cl = lane & (G - 1);
   const bool real = lane < G;
   const int64_t c = c0 + cl;
-  const int64_t set = (p.n_sets == 1) ? 0 : c;
+  const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   double b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0;
   if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
   if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
@@ -338,7 +342,8 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   const int cl = lane & 15, q = lane >> 4;
   const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
   const int64_t c = c0 + cl;
-  const int64_t set = (p.n_sets == 1) ? 0 : c;
+  const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
+  const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   char *xring = smem;
   char *pring = smem + kXRing * kSlotBytes;
@@ -358,13 +363,13 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
     if (!CM) {
       const int row = lane / 8, cp = lane % 8;
-      x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
+      x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
       y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
       x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
       x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
     } else {
       const int ch = lane / 32, sp = lane % 32;
-      x_off = (c0 + ch) * p.ldx + 2 * sp;
+      x_off = (in0 + ch) * p.ldx + 2 * sp;
       y_off = (c0 + ch) * p.ldy + 2 * sp;
       x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
       x_tile = T; y_tile = T;
@@ -568,7 +573,6 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   *done_samples = 0;
   *done_channels = 0;
   if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform && !sec.any_div)) return ALZ_OK;
-  if (io.mode == ALZ_BANK_OUTER) return ALZ_OK;  // set index needs c / n_inputs: k_small handles it
   const bool cm = io.sxn == 1 && io.syn == 1 && !(io.sxc == 1 && io.syc == 1);
   const bool tm = io.sxc == 1 && io.syc == 1;
   if (!cm && !tm) return ALZ_OK;
@@ -584,6 +588,13 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   if (io.channels < 48 * 256) g = 16;
   static const int g_env = getenv("ALZ_G") ? atoi(getenv("ALZ_G")) : 0;   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
+  const bool outer = io.mode == ALZ_BANK_OUTER;
+  if (outer) {
+    // a wave's channels must be adjacent inputs of ONE coefficient set; later cascade sections of
+    // an OUTER bank (map_input == 0) read y with the channel's own index, i.e. like a diagonal bank
+    while (g > 16 && io.n_inputs % g) g /= 2;
+    if (io.n_inputs % g) return ALZ_OK;
+  }
   const int64_t groups = io.channels / g;
   const int t = 8192 / (8 * g);
   const int64_t tiles = io.n / t;
@@ -605,6 +616,8 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   WArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy;
   p.n_tiles = tiles; p.channels = io.channels; p.c_first = 0;
+  p.n_inputs = outer ? io.n_inputs : 0;
+  p.map_input = io.map_input;
   p.n_sets = io.n_sets;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   static const int dbg_env = getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0;

@@ -457,3 +457,31 @@ def test_fused_mode_is_opt_in_and_within_contract(alz, oracle):
   bank.set_fused(False)
   bank.reset()
   assert same_bits(bank.process(x), ref)
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_outer_bank_streaming_kernels(alz, oracle, layout):
+  """A single-section filterbank (every resonator on every stream) and a 3-section OUTER cascade
+  (not one of the fused shapes): the streaming kernels take OUTER banks when the stream count is
+  a multiple of the group width."""
+  rng = np.random.default_rng(8)
+  S, B, N = 48, 7, 1000
+  x = rng.uniform(-1, 1, (N, S))
+  xin = x if layout == "time" else np.ascontiguousarray(x.T)
+  bb, aa = resonator_bank(B)
+  fb = alz.FilterBank([(bb, aa)], n_inputs=S, mode="outer")
+  fb.reset()
+  y = fb.process(xin, layout=layout)
+  assert "k_duo" in fb.last_kernel or "k_wave" in fb.last_kernel
+  y = y if layout == "time" else y.T
+  for band in range(B):
+    assert same_bits(y[:, band * S:(band + 1) * S], oracle.bank([3], [3], bb[band], aa[band], x))
+  secs = [(bb, aa), (bb[:, :1] * 2.0, aa[:, :2]), (bb, aa)]
+  fb3 = alz.FilterBank(secs, n_inputs=S, mode="outer")
+  fb3.reset()
+  y3 = fb3.process(xin, layout=layout)
+  y3 = y3 if layout == "time" else y3.T
+  for band in (0, B - 1):
+    ref = oracle.bank([3, 1, 3], [3, 2, 3], np.concatenate([bb[band], bb[band, :1] * 2.0, bb[band]]),
+                      np.concatenate([aa[band], aa[band, :2], aa[band]]), x)
+    assert same_bits(y3[:, band * S:(band + 1) * S], ref)
