@@ -17,6 +17,7 @@ from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, c
 from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
 from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
 from .synth import white_noise, zeros, karplus_strong  # noqa: F401
+from .analysis import envelope, maverage  # noqa: F401
 
 
 def sHz(rate):

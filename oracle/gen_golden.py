@@ -292,6 +292,24 @@ def karplus_case():
   return out
 
 
+# --------------------------------------------------------------------------
+# 9. callers of the filter path: envelope (lazy_analysis.py:440-520), maverage (:569-616)
+# --------------------------------------------------------------------------
+def callers_case():
+  from audiolazy import envelope, maverage
+  x = noise(400, 2024)
+  out = dict(x=hx(x), cases=[])
+  for strat in ("rms", "abs", "squared"):
+    out["cases"].append(dict(fn="envelope", strategy=strat, arg=hx(0.05),
+                             y=hx(list(getattr(envelope, strat)(list(x), 0.05)))))
+  for strat in ("recursive", "fir"):
+    for size in (4, 25):
+      filt = getattr(maverage, strat)(size)
+      out["cases"].append(dict(fn="maverage", strategy=strat, arg=size, b=hx(filt.numlist),
+                               a=hx(filt.denlist), y=hx(list(filt(list(x))))))
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   dump("filters.json", filt_cases())
@@ -303,3 +321,4 @@ if __name__ == "__main__":
   dump("lpc.json", lpc_cases())
   dump("blocks.json", blocks_cases())
   dump("karplus.json", karplus_case())
+  dump("callers.json", callers_case())

@@ -187,3 +187,17 @@ def test_karplus_strong_golden(al):
     ks = al.karplus_strong(unhex(case["freq"]), unhex(case["tau"]))
     y = ks.take(1500)
     assert same_bits(y, unhex(case["y"]))
+
+
+def test_envelope_and_maverage_callers(al):
+  """lazy_analysis.py:440-520, 569-616: elementwise Stream stages around a GPU filter; bit-exact."""
+  data = load_golden("callers.json")
+  x = unhex(data["x"])
+  for c in data["cases"]:
+    if c["fn"] == "envelope":
+      y = list(getattr(al.envelope, c["strategy"])(x, unhex(c["arg"])))
+    else:
+      filt = getattr(al.maverage, c["strategy"])(c["arg"])
+      assert same_bits(filt.numlist, unhex(c["b"])) and same_bits(filt.denlist, unhex(c["a"]))
+      y = list(filt(x))
+    assert same_bits(y, unhex(c["y"])), (c["fn"], c["strategy"], c["arg"])
