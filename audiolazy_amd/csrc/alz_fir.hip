@@ -29,7 +29,8 @@ static constexpr int kFirTB = 256; // output rows per wave
 struct FArgs {
   const double *x;
   double *y;
-  int64_t n, sxn, syn;     // time-major: channel stride is 1
+  int64_t n, sxn, syn;     // time stride (1 for channel-major blocks)
+  int64_t sxc, syc;        // channel stride (1 for time-major blocks)
   int64_t channels, n_inputs, n_sets;
   int64_t c_first, c_end;
   int mode, map_input;
@@ -139,6 +140,98 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_fir_cm: the same FIR on channel-major blocks ([C, N], one Stream per row).  A wave owns ONE
+// channel and a run of 64 x 32 = 2048 outputs; lane l computes the 32 consecutive outputs
+// t0 + 32 l .. t0 + 32 l + 31.  The channel's input window (2048 + nb - 1 samples) is staged in LDS
+// by coalesced loads, padded by one double per 32 so that the lanes' 33-double stride is
+// conflict-free; the taps of the channel (shared or per channel -- a wave has one channel, so they
+// are wave-uniform either way) are staged too.  Per output the sum is the same ascending
+// left-to-right sum as k_fir / the reference; results go back through LDS so the stores are
+// coalesced rows again.
+// ---------------------------------------------------------------------------
+static constexpr int kCmOut = 64 * kFirR;          // outputs per wave
+
+__device__ __forceinline__ int cm_pad(int j) { return j + (j >> 5); }
+
+__global__ __launch_bounds__(64) void k_fir_cm(FArgs p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int64_t c = p.c_first + blockIdx.x;
+  int64_t in, set;
+  if (p.mode == ALZ_BANK_OUTER) {
+    in = p.map_input ? c % p.n_inputs : c;
+    set = c / p.n_inputs;
+  } else {
+    in = c;
+    set = (p.n_sets == 1) ? 0 : c;
+  }
+  const int64_t t0 = (int64_t)blockIdx.y * kCmOut;
+  const int hist = p.nb - 1;
+  const int padded_taps = ((p.nb + kFirK - 1) / kFirK) * kFirK;
+  double *taps = lds;                               // [padded_taps]
+  double *win = lds + padded_taps;                  // window: index j <-> time t0 - hist + j, padded
+  double *outb = win + cm_pad(kCmOut + hist) + 1;   // [kCmOut] padded, for the coalesced write-back
+  int nz = 0;
+  for (int k = lane; k < padded_taps; k += 64) {
+    const double bk = (k < p.nb) ? p.b[(int64_t)k * p.n_sets + set] : 0.0;
+    taps[k] = bk;
+    nz += bk != 0.0;
+  }
+  const bool all_zero = __ballot(nz != 0) == 0;     // wave-uniform: the channel has no taps at all
+  const double *xc = p.x + in * p.sxc;
+  for (int j = lane; j < kCmOut + hist; j += 64) {
+    int64_t t = t0 - hist + j;
+    double v = 0.0;
+    if (t >= p.n) t = p.n - 1;                      // past the block: never used
+    if (t >= 0) v = xc[t * p.sxn];
+    else v = p.xh[(-t - 1) * p.channels + c];       // before the stream: history row (-t-1 <= hist-1)
+    win[cm_pad(j)] = v;
+  }
+  __syncthreads();
+  const double a0 = p.a[set];
+
+  double acc[kFirR];
+#pragma unroll
+  for (int r = 0; r < kFirR; ++r) acc[r] = -0.0;
+  // window registers: xw[j] = x[t0 + 32 lane + j - kb - (K-1)], j = 0 .. R+K-2
+  double xw[kFirR + kFirK - 1];
+  const int base = hist + kFirR * lane - (kFirK - 1);       // window index of xw[0] at kb = 0
+#pragma unroll
+  for (int j = kFirK; j < kFirR + kFirK - 1; ++j) xw[j] = win[cm_pad(base + j)];
+  for (int kb = 0; kb < p.nb; kb += kFirK) {
+    if (kb > 0) {
+#pragma unroll
+      for (int j = kFirR + kFirK - 2; j >= kFirK; --j) xw[j] = xw[j - kFirK];
+    }
+#pragma unroll
+    for (int j = 0; j < kFirK; ++j) {
+      const int idx = base - kb + j;                        // may run before the window for k >= nb
+      xw[j] = win[cm_pad(idx < 0 ? 0 : idx)];
+    }
+    double bk[kFirK];
+#pragma unroll
+    for (int kk = 0; kk < kFirK; ++kk) bk[kk] = taps[kb + kk];
+#pragma unroll
+    for (int kk = 0; kk < kFirK; ++kk) {
+      if (bk[kk] == 0.0) continue;                          // absent from the reference's sum
+#pragma unroll
+      for (int r = 0; r < kFirR; ++r) acc[r] = acc[r] + bk[kk] * xw[r - kk + (kFirK - 1)];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kFirR; ++r) {
+    const double y = all_zero ? p.zero : (p.div ? acc[r] / a0 : acc[r]);
+    outb[cm_pad(kFirR * lane + r)] = y;
+  }
+  __syncthreads();
+  double *yc = p.y + c * p.syc;
+  for (int j = lane; j < kCmOut; j += 64) {
+    const int64_t t = t0 + j;
+    if (t < p.n) yc[t * p.syn] = outb[cm_pad(j)];
+  }
+}
+
 // new input history after the block: xh_new[k] = x[n-1-k], or the old history when the
 // block was shorter than the delay line
 __global__ void k_fir_state(FArgs p, double *xh_new) {
@@ -147,7 +240,7 @@ __global__ void k_fir_state(FArgs p, double *xh_new) {
   const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? c % p.n_inputs : c;
   for (int k = (int)blockIdx.y; k < p.nb - 1; k += (int)gridDim.y) {
     const int64_t t = p.n - 1 - k;
-    xh_new[(int64_t)k * p.channels + c] = (t >= 0) ? p.x[t * p.sxn + in] : p.xh[(-t - 1) * p.channels + c];
+    xh_new[(int64_t)k * p.channels + c] = (t >= 0) ? p.x[t * p.sxn + in * p.sxc] : p.xh[(-t - 1) * p.channels + c];
   }
 }
 
@@ -156,17 +249,22 @@ __global__ void k_copy_doubles(double *dst, const double *src, int64_t count) {
   if (i < count) dst[i] = src[i];
 }
 
+static int cm_pad_host(int j) { return j + (j >> 5); }
+
 // Feedback-free section with more taps than the register kernels take, time-major block,
 // x and y distinct.  Returns ALZ_OK with *taken = false when the shape is not this kernel's.
 int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
                const char **kernel_name) {
   *taken = false;
   if (sec.na != 1 || sec.nb < 2) return ALZ_OK;
-  if (!(io.sxc == 1 && io.syc == 1)) return ALZ_OK;        // time-major only
+  const bool tm = io.sxc == 1 && io.syc == 1;
+  const bool cm = !tm && io.sxn == 1 && io.syn == 1;
+  if (!tm && !cm) return ALZ_OK;
   if (io.x == io.y) return ALZ_OK;
   if ((sec.present_b) == 0) return ALZ_OK;                 // all-zero filter: k_generic yields `zero`
   FArgs p;
   p.x = io.x; p.y = io.y; p.n = io.n; p.sxn = io.sxn; p.syn = io.syn;
+  p.sxc = io.sxc; p.syc = io.syc;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
   p.c_first = io.c_first; p.c_end = io.c_first + io.c_count;
   p.mode = io.mode; p.map_input = io.map_input;
@@ -177,7 +275,14 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   if (gy > 65535u) return ALZ_OK;  // block longer than the grid's y range: caller falls back
   const size_t tap_bytes = (size_t)((sec.nb + kFirK - 1) / kFirK) * kFirK * sizeof(double);
   if (sec.shared_sets && tap_bytes > 48 * 1024) return ALZ_OK;   // absurdly long: let k_generic have it
-  if (sec.shared_sets)
+  if (cm) {
+    const int hist = sec.nb - 1;
+    const size_t lds = tap_bytes + (size_t)(cm_pad_host(kCmOut + hist) + 1 + cm_pad_host(kCmOut) + 1) * sizeof(double);
+    if (lds > 60 * 1024) return ALZ_OK;
+    const unsigned gyc = (unsigned)((io.n + kCmOut - 1) / kCmOut);
+    if (gyc > 65535u || io.c_count > 0x7fffffff) return ALZ_OK;
+    hipLaunchKernelGGL(k_fir_cm, dim3((unsigned)io.c_count, gyc), dim3(64), lds, stream, p);
+  } else if (sec.shared_sets)
     hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
   else
     hipLaunchKernelGGL(k_fir<false>, dim3(gx, gy), dim3(64), 0, stream, p);
@@ -197,7 +302,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   }
   ALZ_HIP_CHECK(hipGetLastError());
   *taken = true;
-  *kernel_name = sec.shared_sets ? "k_fir<shared>" : "k_fir<per-channel>";
+  *kernel_name = cm ? "k_fir_cm" : sec.shared_sets ? "k_fir<shared>" : "k_fir<per-channel>";
   return ALZ_OK;
 }
 

@@ -291,10 +291,12 @@ def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
                       xh=np.full((C, 255), 0.125), zero=0.125)
   assert same_bits(bank.process(x2), whole[N:N + 40])
   assert same_bits(bank.process(x3), whole[N + 40:])
-  # channel-major blocks take the catch-all kernel, same numbers
+  # channel-major blocks: one channel per wave, window staged in LDS -- same numbers
   bank.reset(zero=0.125)
   yc = bank.process(np.ascontiguousarray(x.T), layout="chan")
-  assert "k_generic" in bank.last_kernel and same_bits(yc, ref.T)
+  assert bank.last_kernel == "k_fir_cm" and same_bits(yc, ref.T)
+  x2c = np.ascontiguousarray(x2.T)
+  assert same_bits(bank.process(x2c, layout="chan"), whole[N:N + 40].T)
 
 
 def test_fir_per_channel_taps_zero_taps_and_gain(alz, oracle):
@@ -485,3 +487,20 @@ def test_outer_bank_streaming_kernels(alz, oracle, layout):
     ref = oracle.bank([3, 1, 3], [3, 2, 3], np.concatenate([bb[band], bb[band, :1] * 2.0, bb[band]]),
                       np.concatenate([aa[band], aa[band, :2], aa[band]]), x)
     assert same_bits(y3[:, band * S:(band + 1) * S], ref)
+
+
+def test_fir_channel_major_per_channel_taps_long_block(alz, oracle):
+  rng = np.random.default_rng(404)
+  C, N, nb = 37, 5000, 100                      # several 2048-output runs per channel, ragged end
+  b = rng.uniform(-1, 1, (C, nb))
+  b[::4, 7] = 0.0
+  b[3] = 0.0                                    # all-zero channel
+  a = rng.uniform(0.5, 2.0, (C, 1))
+  x = rng.uniform(-1, 1, (C, N))
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset(zero=0.5)
+  y = bank.process(x, layout="chan")
+  assert bank.last_kernel == "k_fir_cm"
+  ref = oracle.bank([nb], [1], b, a, x, layout="chan", xh=np.full((C, nb - 1), 0.5), zero=0.5)
+  assert same_bits(y, ref)
+  assert np.all(y[3] == 0.5)
