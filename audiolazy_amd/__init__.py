@@ -18,6 +18,7 @@ from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, e
 from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
 from .synth import white_noise, zeros, karplus_strong  # noqa: F401
 from .analysis import envelope, maverage  # noqa: F401
+from .pcm import WavStream, chunks, decode_pcm, encode_pcm  # noqa: F401
 
 
 def sHz(rate):

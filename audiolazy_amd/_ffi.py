@@ -7,6 +7,8 @@ loudly instead of falling back to anything else.
 import ctypes
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libalzhip.so")
 
@@ -47,6 +49,9 @@ SIGNATURES = {
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_acorr_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
+  "alz_mix_dev": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _int, _vp]),
+  "alz_pcm_decode_dev": (_int, [_vp, _int, _int, _i64, _vp, _int, _vp]),
+  "alz_pcm_encode_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp]),
 }
 
 
@@ -144,3 +149,30 @@ def require_gpu():
   if device_count() < 1:
     raise RuntimeError("audiolazy_amd: no HIP device visible; this engine has no CPU path (%s)"
                        % last_error())
+
+
+class DevBuf(object):
+  """Device allocation owned through the C ABI (no torch needed)."""
+
+  def __init__(self, nbytes, device=0):
+    self.device, self.nbytes = device, int(nbytes)
+    self.ptr = ctypes.c_void_p()
+    check(load().alz_malloc(device, max(self.nbytes, 8), ctypes.byref(self.ptr)))
+
+  def upload(self, arr):
+    arr = np.ascontiguousarray(arr)
+    check(load().alz_memcpy_h2d(self.device, self.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+    return self
+
+  def download(self, shape, dtype):
+    out = np.empty(shape, dtype=dtype)
+    check(load().alz_memcpy_d2h(self.device, out.ctypes.data_as(ctypes.c_void_p), self.ptr, out.nbytes))
+    return out
+
+  def __del__(self):
+    p, self.ptr = getattr(self, "ptr", None), None
+    if p:
+      try:
+        load().alz_free(self.device, p)
+      except Exception:
+        pass

@@ -80,6 +80,43 @@ def memory_to_hist(memory, lm, zero=0.0):
   return out
 
 
+def mix_sets(y, n_sets, n_inputs, layout="time", out=None, device=0):
+  """Ordered sum over the leading ``n_sets`` groups of ``n_inputs`` channels (alz_mix_dev)."""
+  L = _ffi.load()
+  lay = LAYOUTS[layout]
+  if _is_torch(y):
+    import torch
+    if not y.is_cuda or y.dtype != torch.float64 or not y.is_contiguous() or y.dim() != 2:
+      raise ValueError("torch input must be a contiguous 2-D float64 CUDA tensor")
+    n, ch = (tuple(y.shape) if lay == _ffi.TIME_MAJOR else tuple(y.shape)[::-1])
+    if ch != n_sets * n_inputs:
+      raise ValueError("block has %d channels, expected %d sets x %d inputs" % (ch, n_sets, n_inputs))
+    shape = (n, n_inputs) if lay == _ffi.TIME_MAJOR else (n_inputs, n)
+    res = torch.empty(shape, dtype=torch.float64, device=y.device) if out is None else out
+    ldy, ldo = (ch, n_inputs) if lay == _ffi.TIME_MAJOR else (n, n)
+    stream = torch.cuda.current_stream(y.device).cuda_stream
+    _ffi.check(L.alz_mix_dev(y.data_ptr(), n_sets, n_inputs, n, lay, ldy, ldo, res.data_ptr(),
+                             y.device.index or 0, ctypes.c_void_p(stream)))
+    return res
+  y = np.ascontiguousarray(y, dtype=np.float64)
+  n, ch = (y.shape if lay == _ffi.TIME_MAJOR else y.shape[::-1])
+  if ch != n_sets * n_inputs:
+    raise ValueError("block has %d channels, expected %d sets x %d inputs" % (ch, n_sets, n_inputs))
+  shape = (n, n_inputs) if lay == _ffi.TIME_MAJOR else (n_inputs, n)
+  if n == 0:
+    return np.empty(shape)
+  ldy, ldo = (ch, n_inputs) if lay == _ffi.TIME_MAJOR else (n, n)
+  d_y = _ffi.DevBuf(y.nbytes, device).upload(y)
+  d_o = _ffi.DevBuf(n * n_inputs * 8, device)
+  _ffi.check(L.alz_mix_dev(d_y.ptr, n_sets, n_inputs, n, lay, ldy, ldo, d_o.ptr, device, None))
+  _ffi.check(L.alz_device_sync(device))
+  res = d_o.download(shape, np.float64)
+  if out is not None:
+    out[...] = res
+    return out
+  return res
+
+
 class FilterBank(object):
   """``channels`` independent streams through per-channel cascades.
 
@@ -278,6 +315,16 @@ class FilterBank(object):
 
   def sync(self):
     _ffi.check(self._L.alz_bank_sync(self._h))
+
+  def mixdown(self, y, layout="time", out=None):
+    """Sum an OUTER bank's output block over its coefficient sets, ``((y_0 + y_1) + y_2) ...`` in
+    set order -- ParallelFilter's sum (reference lazy_filters.py:1048-1054), on the device.
+
+    y : [N, n_sets * n_inputs] / [n_sets * n_inputs, N] as returned by :meth:`process`.
+    Returns [N, n_inputs] / [n_inputs, N] (same array kind as ``y``)."""
+    if self.mode != "outer":
+      raise ValueError("mixdown sums over the coefficient sets of an OUTER bank")
+    return mix_sets(y, self.n_sets, self.n_inputs, layout=layout, out=out, device=self.device)
 
   def __call__(self, seq, memory=None, zero=0., block=4096):
     """The reference's filter call: any iterable in, a Stream out.

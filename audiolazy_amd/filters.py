@@ -288,16 +288,69 @@ class ParallelFilter(FilterList):
   (reference :1024-1084, call :1048-1054).  Runs as one OUTER bank on the GPU
   followed by the ordered sum; an empty list yields ``zero`` per input item."""
 
-  def __call__(self, seq, memory=None, zero=0.):
+  def __call__(self, seq, memory=None, zero=0., block=4096):
     from .stream import Stream
     if len(self) == 0:
       return Stream(zero for _ in seq)
+    if all(isinstance(f, LinearFilter) for f in self):
+      try:
+        return self._call_bank(seq, memory, zero, block)
+      except NotImplementedError:   # coefficients outside the engine's gate
+        pass
     data = list(seq)
     outs = [list(f(data, memory=memory, zero=zero)) for f in self]
     total = outs[0]
     for other in outs[1:]:
       total = [a + b for a, b in zip(total, other)]
     return Stream(total)
+
+  def _call_bank(self, seq, memory, zero, block):
+    """All filters as the coefficient sets of one OUTER bank over the single input, then the
+    ordered sum over the sets on the device (alz_mix_dev)."""
+    import itertools
+    import numpy as np
+    from .bank import FilterBank, memory_to_hist, sections_of
+    from .stream import Stream
+    for f in self:
+      if not f.is_causal():
+        raise ValueError("Non-causal filter")
+      if f.denpoly[0] == 0:
+        raise ZeroDivisionError("Invalid filter gain")
+    secs = [sections_of(f)[0] for f in self]
+    nb = max(max(len(b) for b, _ in secs), 1)
+    na = max(len(a) for _, a in secs)
+    b = np.zeros((len(secs), nb))
+    a = np.zeros((len(secs), na))
+    for i, (bi, ai) in enumerate(secs):   # zero taps are absent from the reference's sum anyway
+      b[i, :len(bi)] = bi
+      a[i, :len(ai)] = ai
+    bank = FilterBank([(b, a)], n_inputs=1, mode="outer")
+    # every filter receives the same memory / zero (reference :1053) but applies the padding rule
+    # with its own order, so the histories are built per filter
+    if callable(memory) and not hasattr(memory, "__iter__"):
+      items = None
+    else:
+      items = None if memory is None else list(itertools.islice(iter(memory), na - 1))
+    xh = np.full((len(secs), max(nb - 1, 1)), float(zero))
+    yh = np.full((len(secs), max(na - 1, 1)), float(zero))
+    for i, (_, ai) in enumerate(secs):
+      lm = len(ai) - 1
+      hist = memory_to_hist(memory if (memory is not None and items is None) else items, lm, zero)
+      yh[i, :lm] = hist
+    bank.reset(zero=float(zero))
+    bank.set_state(xh, yh)
+
+    def gen():
+      it = iter(seq)
+      while True:
+        chunk = list(itertools.islice(it, block))
+        if not chunk:
+          return
+        x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), 1)
+        y = bank.mixdown(bank.process(x, layout="time"), layout="time")
+        for v in y[:, 0].tolist():
+          yield v
+    return Stream(gen())
 
 
 # ---------------------------------------------------------------------------

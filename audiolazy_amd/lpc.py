@@ -13,33 +13,7 @@ from . import _ffi
 from ._ffi import ParCorError  # noqa: F401
 
 
-class _DevBuf(object):
-  """Device allocation owned through the C ABI (no torch needed)."""
-
-  def __init__(self, nbytes, device=0):
-    self.device, self.nbytes = device, int(nbytes)
-    self.ptr = ctypes.c_void_p()
-    _ffi.check(_ffi.load().alz_malloc(device, max(self.nbytes, 8), ctypes.byref(self.ptr)))
-
-  def upload(self, arr):
-    arr = np.ascontiguousarray(arr)
-    _ffi.check(_ffi.load().alz_memcpy_h2d(self.device, self.ptr, arr.ctypes.data_as(ctypes.c_void_p),
-                                          arr.nbytes))
-    return self
-
-  def download(self, shape, dtype):
-    out = np.empty(shape, dtype=dtype)
-    _ffi.check(_ffi.load().alz_memcpy_d2h(self.device, out.ctypes.data_as(ctypes.c_void_p), self.ptr,
-                                          out.nbytes))
-    return out
-
-  def __del__(self):
-    p, self.ptr = getattr(self, "ptr", None), None
-    if p:
-      try:
-        _ffi.load().alz_free(self.device, p)
-      except Exception:
-        pass
+_DevBuf = _ffi.DevBuf
 
 
 def _frame_count(n_samples, frame_len, hop):

@@ -47,8 +47,10 @@ class StrategyDict(object):
   def __setattr__(self, name, value):
     if name == "default":
       object.__setattr__(self, "_default", value)
-    else:
+    elif callable(value):
       self._by_name[name] = value
+    else:   # plain configuration values, e.g. chunks.size (reference lazy_io.py:45)
+      object.__setattr__(self, name, value)
 
   def __iter__(self):
     seen = []

@@ -138,6 +138,30 @@ int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int orde
 int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                   int64_t hop, int max_lag, double *r_dev, int device, void *stream);
 
+/* ---- either side of the path: mixdown and sample formats ---------------------------------- */
+/* ParallelFilter.__call__ (lazy_filters.py:1048-1054): the outputs of the filters fed with the
+ * same input summed ((y_0 + y_1) + y_2) ..., over the n_sets coefficient sets of an OUTER bank's
+ * output block y (channel = set * n_inputs + input, same layouts and pitches as
+ * alz_bank_process_dev) into out (n_inputs channels).  The order is the reference's, so the sum is
+ * bit-identical to it. */
+int alz_mix_dev(const double *y_dev, int64_t n_sets, int64_t n_inputs, int64_t n, int layout,
+                int64_t ldy, int64_t ldo, double *out_dev, int device, void *stream);
+/* WavStream's sample conversion (lazy_wav.py:58-61, 110-128): n_samples little-endian PCM items of
+ * 8 (unsigned), 16, 24 or 32 bits, in file order (interleaved channels = a time-major block), to
+ * float64: v / 2**(bits-1) with 8-bit data re-centred by -128, or the stored integer when keep != 0.
+ * raw_dev 4-byte aligned, out_dev 16-byte aligned. */
+int alz_pcm_decode_dev(const void *raw_dev, int bits, int keep, int64_t n_samples,
+                       double *out_dev, int device, void *stream);
+/* chunks (lazy_io.py:44-128): n float64 items packed as struct format character dfmt
+ * ('b' 'B' 'h' 'H' 'i' 'I' 'l' 'L' 'f' 'd'), little endian unless big_endian != 0.  *flags_dev
+ * (an int the caller zeroes) receives ALZ_PCM_NOT_INTEGER / ALZ_PCM_RANGE / ALZ_PCM_FLOAT_OVERFLOW
+ * bits for the items struct.pack would refuse (struct.error / OverflowError in the reference). */
+#define ALZ_PCM_NOT_INTEGER 1
+#define ALZ_PCM_RANGE 2
+#define ALZ_PCM_FLOAT_OVERFLOW 4
+int alz_pcm_encode_dev(const double *in_dev, int64_t n, int dfmt, int big_endian, void *out_dev,
+                       int *flags_dev, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

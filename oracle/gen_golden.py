@@ -18,6 +18,8 @@ Reference entry points exercised (paths relative to /root/reference/):
   audiolazy/lazy_analysis.py:277-312  acorr
   audiolazy/lazy_lpc.py:52-136,229-272 levinson_durbin, lpc.kautocor
   audiolazy/lazy_misc.py:74-129       blocks
+  audiolazy/lazy_wav.py:31-130        WavStream
+  audiolazy/lazy_io.py:44-94          chunks.struct
 """
 import json
 import os
@@ -310,6 +312,72 @@ def callers_case():
   return out
 
 
+# --------------------------------------------------------------------------
+# 11. formats either side of the path: WavStream, chunks; ParallelFilter memory rules
+# --------------------------------------------------------------------------
+def formats_cases():
+  import io
+  import tempfile
+  import wave
+  from audiolazy import WavStream, chunks
+  out = dict(wav=[], chunks=[], parallel=[])
+  rnd = random.Random(77)
+  for bits in (8, 16, 24, 32):
+    for channels in (1, 2):
+      frames = 37
+      raw = bytes(rnd.randrange(256) for _ in range(frames * channels * bits // 8))
+      # corner values first: most negative, most positive, zero, minus one
+      width = bits // 8
+      if bits == 8:
+        corners = [bytes([0]), bytes([255]), bytes([128]), bytes([127])]
+      else:
+        corners = [(-(1 << (bits - 1))).to_bytes(width, "little", signed=True),
+                   ((1 << (bits - 1)) - 1).to_bytes(width, "little", signed=True),
+                   (0).to_bytes(width, "little", signed=True), (-1).to_bytes(width, "little", signed=True)]
+      raw = b"".join(corners) + raw[4 * width:]
+      with tempfile.NamedTemporaryFile(suffix=".wav") as tmp:
+        w = wave.open(tmp.name, "wb")
+        w.setnchannels(channels)
+        w.setsampwidth(width)
+        w.setframerate(22050)
+        w.writeframes(raw)
+        w.close()
+        file_bytes = open(tmp.name, "rb").read()
+        ws = WavStream(tmp.name)
+        meta = dict(rate=ws.rate, channels=ws.channels, bits=ws.bits)
+        scaled = list(ws)
+        kept = list(WavStream(tmp.name, keep=True))
+      out["wav"].append(dict(meta, file=file_bytes.hex(), raw=raw.hex(), scaled=hx(scaled), kept=[int(v) for v in kept]))
+  x = noise(23, 5)
+  for dfmt, order, size, pad in (("f", None, 8, 0.), ("f", ">", 8, 0.), ("f", "<", 5, -1.), ("d", None, 8, 0.),
+                                 ("d", ">", 6, .25)):
+    got = list(chunks.struct(list(x), size=size, dfmt=dfmt, byte_order=order, padval=pad))
+    out["chunks"].append(dict(x=hx(x), dfmt=dfmt, byte_order=order, size=size, padval=hx(pad), ints=False,
+                              chunks=[c.hex() for c in got]))
+  xi = [rnd.randrange(-128, 128) for _ in range(19)]
+  for dfmt, order, size, pad, scale in (("b", None, 4, 0, 1), ("h", "<", 8, -3, 250), ("h", ">", 8, 0, 250),
+                                        ("i", None, 5, 7, 16000000), ("i", ">", 5, 0, 16000000),
+                                        ("B", None, 4, 0, None), ("H", ">", 4, 9, None)):
+    vals = [v * scale for v in xi] if scale else [abs(v) for v in xi]
+    got = list(chunks.struct(list(vals), size=size, dfmt=dfmt, byte_order=order, padval=pad))
+    out["chunks"].append(dict(x=vals, dfmt=dfmt, byte_order=order, size=size, padval=pad, ints=True,
+                              chunks=[c.hex() for c in got]))
+  # ParallelFilter: filters of different orders, memory shorter / longer than some of them,
+  # a0 != 1, a pure gain and a FIR among the branches (lazy_filters.py:1048-1054)
+  xs = noise(150, 31)
+  branches = [lowpass.pole(800 * Hz), resonator.z_exp(1500 * Hz, 80 * Hz), ZFilter([.2, .3, .4], [2., -.5, .25]),
+              ZFilter([.5]), 1 - .5 * z ** -3, resonator.poles_exp(300 * Hz, 20 * Hz)]
+  for memory, zero in ((None, 0.), ([.7], 0.), ([.7, -.2], .1), ([.1, .2, .3, .4], -.05)):
+    par = ParallelFilter(branches)
+    kw = dict(zero=zero)
+    if memory is not None:
+      kw["memory"] = list(memory)
+    out["parallel"].append(dict(sections=[dict(b=hx(f.numlist), a=hx(f.denlist)) for f in branches],
+                                x=hx(xs), memory=None if memory is None else hx(memory), zero=hx(zero),
+                                y=hx(list(par(list(xs), **kw)))))
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   dump("filters.json", filt_cases())
@@ -322,3 +390,4 @@ if __name__ == "__main__":
   dump("blocks.json", blocks_cases())
   dump("karplus.json", karplus_case())
   dump("callers.json", callers_case())
+  dump("formats.json", formats_cases())
