@@ -48,7 +48,7 @@ struct WArgs {
   int nb, na;
   const double *b, *a;
   double *xh, *yh;
-  int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores (wrong output!)
+  int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores, 8 no tile barriers (wrong output!)
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -84,7 +84,7 @@ __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
 }
 
 // wait until at most `n` vector-memory operations of this wave are outstanding.
-// n is a multiple of 8 in [0, 48]; s_waitcnt needs a literal.
+// n is a multiple of 8; anything above 56 waits for 56 (vmcnt is a 6-bit counter). s_waitcnt needs a literal.
 __device__ __forceinline__ void wait_vm(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -93,7 +93,8 @@ __device__ __forceinline__ void wait_vm(int n) {
     case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
     case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
     case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
   }
 }
 
@@ -445,14 +446,17 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       if (i >= 1 && !(p.dbg & 4)) store_tile(i - 1);
       if (i + kXRing - 1 < nt && !(p.dbg & 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
-        const int64_t last = (i + 3 < nt - 1) ? i + 3 : nt - 1;
+        // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
+        // of the kXRing-2 tiles finished since (a count above the 6-bit vmcnt range is clamped in
+        // wait_vm: waiting for a few more of the oldest operations is always safe)
+        const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
         const int64_t dma_after = last - (i + 1);
-        const int64_t stores_after = i < 2 ? i : 2;
+        const int64_t stores_after = i < kXRing - 2 ? i : kXRing - 2;
         wait_vm((p.dbg & 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
         if (!(p.dbg & 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
     }
     store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
@@ -470,13 +474,18 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
     double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
     asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
+    double t2 = na2 * m2;                                    // (-a2) * y[n-2] for the next step
     __builtin_amdgcn_s_barrier();                            // p of tile 0 is ready
     constexpr int NCH = T / 8;
+    int ps_cur = 0, ps_prv = kPRing - 1, ys_cur = 0;         // ring slots of tile i, rotated by hand
     for (int64_t i = 0; i < nt; ++i) {
       // this lane reads sample (u - q) of the tile; u - q < 0 lives in the previous tile's slot
-      const char *cur = pring + (int)(i % kPRing) * kSlotBytes + lane_off_p - q * kStep;
-      const char *prv = pring + (int)((i + kPRing - 1) % kPRing) * kSlotBytes + lane_off_p + (T - q) * kStep;
-      char *wr = yring + (int)(i % kYRing) * kSlotBytes + lane_off_p - q * kStep;
+      const char *cur = pring + ps_cur * kSlotBytes + lane_off_p - q * kStep;
+      const char *prv = pring + ps_prv * kSlotBytes + lane_off_p + (T - q) * kStep;
+      char *wr = yring + ys_cur * kSlotBytes + lane_off_p - q * kStep;
+      ps_prv = ps_cur;
+      ps_cur = (ps_cur + 1 == kPRing) ? 0 : ps_cur + 1;
+      ys_cur = (ys_cur + 1 == kYRing) ? 0 : ys_cur + 1;
       double pr[3][8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -496,9 +505,16 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           double acc = pr[k % 3][u];
+          double t2n = 0.0;
           if constexpr (FMA) {
             if constexpr (PA & 1u) acc = __builtin_fma(na1, m1, acc);
             if constexpr (PA & 2u) acc = __builtin_fma(na2, m2, acc);
+          } else if constexpr (PA == 3u) {
+            // the product with y[n-2] was formed one step ago (t2), so only mul -> add -> add
+            // sits on the serial chain and the other product fills the first latency slot
+            const double t1 = na1 * m1;
+            t2n = na2 * m1;
+            acc = (acc + t1) + t2;
           } else {
             if constexpr (PA & 1u) acc = acc + na1 * m1;
             if constexpr (PA & 2u) acc = acc + na2 * m2;
@@ -508,16 +524,18 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
             const bool on = u >= q;
             m2 = on ? m1 : m2;
             m1 = on ? acc : m1;
+            t2 = on ? t2n : t2;
           } else {
             m2 = m1;
             m1 = acc;
+            t2 = t2n;
           }
           if ((u & 3) == 3) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                          // y of tile i done, p of tile i+1 ready
+      if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();        // y of tile i done, p of tile i+1 ready
     }
     if (lane < G) {
       if (p.na > 1) p.yh[0 * p.channels + c] = m1;
