@@ -52,7 +52,15 @@ SIGNATURES = {
   "alz_mix_dev": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _int, _vp]),
   "alz_pcm_decode_dev": (_int, [_vp, _int, _int, _i64, _vp, _int, _vp]),
   "alz_pcm_encode_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp]),
+  "alz_tv_process_dev": (_int, [_int, _vp, _int, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp,
+                                ctypes.c_double, _int, _vp]),
 }
+
+
+class TvTap(ctypes.Structure):
+  """alz_tv_tap_t (include/alz.h)."""
+  _fields_ = [("value", ctypes.c_double), ("series_dev", ctypes.c_void_p),
+              ("stride_n", ctypes.c_int64), ("stride_c", ctypes.c_int64)]
 
 
 class ParCorError(ZeroDivisionError):

@@ -61,7 +61,8 @@ class LinearFilter(object):
     return dict(self.denpoly.terms())
 
   def is_lti(self):
-    return True   # Stream-valued coefficients never get in (reference :303-314)
+    """False when some coefficient is a Stream, i.e. varies in time (reference :303-314)."""
+    return not any(hasattr(v, "__iter__") for poly in (self.numpoly, self.denpoly) for _, v in poly.terms())
 
   def is_causal(self):
     return all(k >= 0 for k, _ in self.numpoly.terms())   # reference :316-325
@@ -120,6 +121,11 @@ class LinearFilter(object):
     """
     if any(k < 0 for k, _ in self.numpoly.terms()) or any(k < 0 for k, _ in self.denpoly.terms()):
       raise ValueError("Non-causal filter")
+    from . import timevar
+    if any(timevar.is_series(v) for _, v in self.numpoly.terms()) or \
+       any(timevar.is_series(v) for _, v in self.denpoly.terms()):
+      from .stream import Stream   # Stream coefficients: the time-varying kernel (reference :197-224)
+      return Stream(timevar.run(self.numlist, self.denlist, seq, memory=memory, zero=zero))
     if self.denpoly[0] == 0:
       raise ZeroDivisionError("Invalid filter gain")
     from .bank import FilterBank
@@ -251,7 +257,7 @@ class CascadeFilter(FilterList):
   linear filters runs as ONE fused bank on the GPU."""
 
   def __call__(self, seq, memory=None, zero=0.):
-    if self.is_linear():
+    if self.is_linear() and self.is_lti():
       from .bank import FilterBank, sections_of
       if len(self) == 0:
         from .stream import Stream
@@ -357,6 +363,26 @@ class ParallelFilter(FilterList):
 # designs.  Formulas re-derived from the reference's docstrings / math/ notes and
 # evaluated in the same operation order so that the doubles come out identical.
 # ---------------------------------------------------------------------------
+def _accepts_streams(design):
+  """Give a scalar design its Stream-argument form (the reference's designs take Streams and
+  return time-varying filters, :1179-1495): any iterable argument makes the coefficients Streams
+  of the scalar design evaluated sample by sample (see timevar.design_over_streams)."""
+  import functools
+
+  @functools.wraps(design)
+  def wrapper(*args, **kwargs):
+    from . import timevar
+    if kwargs:
+      import inspect
+      bound = inspect.signature(design).bind(*args, **kwargs)
+      bound.apply_defaults()
+      args = tuple(bound.arguments.values())
+    if any(timevar.is_series(a) for a in args):
+      return timevar.design_over_streams(design, *args)
+    return design(*args)
+  return wrapper
+
+
 comb = StrategyDict("comb")
 
 
@@ -383,6 +409,7 @@ resonator = StrategyDict("resonator")
 
 
 @resonator.strategy("poles_exp")
+@_accepts_streams
 def resonator(freq, bandwidth):
   """Two-pole resonator, 0 dB peak at the resonance (reference :1179-1209).
   ``freq`` and ``bandwidth`` in rad/sample; pole radius R = exp(-bandwidth / 2)."""
@@ -393,6 +420,7 @@ def resonator(freq, bandwidth):
 
 
 @resonator.strategy("freq_poles_exp")
+@_accepts_streams
 def resonator(freq, bandwidth):
   """Two-pole resonator with the poles exactly at ``freq`` (reference :1212-1242)."""
   R = math.exp(-bandwidth * .5)
@@ -401,6 +429,7 @@ def resonator(freq, bandwidth):
 
 
 @resonator.strategy("z_exp")
+@_accepts_streams
 def resonator(freq, bandwidth):
   """Two poles plus zeros at DC and Nyquist, 0 dB at ``freq`` (reference :1245-1276)."""
   R = math.exp(-bandwidth * .5)
@@ -410,6 +439,7 @@ def resonator(freq, bandwidth):
 
 
 @resonator.strategy("freq_z_exp")
+@_accepts_streams
 def resonator(freq, bandwidth):
   """As ``z_exp`` with the poles exactly at ``freq`` (reference :1279-1310)."""
   R = math.exp(-bandwidth * .5)
@@ -426,6 +456,7 @@ def _one_pole_radius(x):
 
 
 @lowpass.strategy("pole")
+@_accepts_streams
 def lowpass(cutoff):
   """One pole, exact -3 dB at ``cutoff`` rad/sample (reference :1370-1378)."""
   R = _one_pole_radius(2 - math.cos(cutoff))
@@ -433,6 +464,7 @@ def lowpass(cutoff):
 
 
 @highpass.strategy("pole")
+@_accepts_streams
 def highpass(cutoff):
   """One pole highpass, mirror of lowpass.pole (reference :1381-1389)."""
   R = _one_pole_radius(2 + math.cos(cutoff))
@@ -445,6 +477,7 @@ def _pole_zero_radius(num, cutoff):
 
 
 @lowpass.strategy("z")
+@_accepts_streams
 def lowpass(cutoff):
   """One pole and a zero at Nyquist (reference :1392-1405)."""
   R = _pole_zero_radius(math.sin(cutoff) - 1, cutoff)
@@ -453,6 +486,7 @@ def lowpass(cutoff):
 
 
 @highpass.strategy("z")
+@_accepts_streams
 def highpass(cutoff):
   """One pole and a zero at DC (reference :1408-1421)."""
   R = _pole_zero_radius(1 - math.sin(cutoff), cutoff)
@@ -461,6 +495,7 @@ def highpass(cutoff):
 
 
 @lowpass.strategy("pole_exp")
+@_accepts_streams
 def lowpass(cutoff):
   """Matched-Z one pole, R = e ** -cutoff (reference :1424-1437)."""
   R = math.exp(-cutoff)
@@ -468,6 +503,7 @@ def lowpass(cutoff):
 
 
 @highpass.strategy("pole_exp")
+@_accepts_streams
 def highpass(cutoff):
   """Matched-Z one pole highpass, R = e ** (cutoff - pi) (reference :1440-1454)."""
   R = math.exp(cutoff - math.pi)
@@ -475,6 +511,7 @@ def highpass(cutoff):
 
 
 @lowpass.strategy("z_exp")
+@_accepts_streams
 def lowpass(cutoff):
   """Matched-Z pole plus zero at Nyquist (reference :1457-1472)."""
   R = math.exp(cutoff - math.pi)
@@ -483,6 +520,7 @@ def lowpass(cutoff):
 
 
 @highpass.strategy("z_exp")
+@_accepts_streams
 def highpass(cutoff):
   """Matched-Z pole plus zero at DC (reference :1475-1490)."""
   R = math.exp(-cutoff)

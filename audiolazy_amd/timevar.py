@@ -1,0 +1,196 @@
+"""Time-varying linear filters: coefficients that are Streams, one value per output sample.
+
+Host side of the Stream-coefficient branch of the reference's ``LinearFilter.__call__``
+(audiolazy/lazy_filters.py:141-264): a coefficient that is an iterable contributes
+``next(b_k) * d_k`` / ``-next(a_k) * m_k`` to the same left-to-right sum as the constant terms
+(:197-224); a Stream ``a0`` is first normalised away by multiplying every other coefficient by
+``1 / a0`` sample by sample (:166-174).  The coefficient streams are pulled ``block`` values at a
+time -- exactly one value per input sample, like the reference's ``next`` calls -- uploaded, and
+the recurrence runs on the GPU (``alz_tv_process_dev``); results are bit-identical.
+
+``design_over_streams`` gives the reference's design functions their Stream-argument form
+(:1179-1495 accept Streams): the coefficient streams are the scalar design evaluated sample by
+sample, which is what the reference's elementwise Stream arithmetic computes.
+"""
+import ctypes
+import itertools
+
+import numpy as np
+
+from . import _ffi
+
+
+def is_series(v):
+  """True for a coefficient that varies in time (any iterable, like the reference's check
+  ``isinstance(coeff, Iterable)``, lazy_filters.py:202, :214)."""
+  return hasattr(v, "__iter__")
+
+
+def _pull(it, n):
+  return list(itertools.islice(it, n))
+
+
+def run(numlist, denlist, seq, memory=None, zero=0., block=4096, device=0):
+  """Generator of output samples for one input stream.
+
+  numlist / denlist : coefficients by delay (constants or iterables), denlist[0] = a0.
+  """
+  from .bank import memory_to_hist
+  L = _ffi.load()
+  b = list(numlist) or [0.]
+  a = list(denlist)
+  if not a:
+    raise ZeroDivisionError("Invalid filter gain")
+  nb, na = len(b), len(a)
+  b_it = [iter(v) if is_series(v) else None for v in b]
+  a_it = [iter(v) if is_series(v) else None for v in a]
+  if a_it[0] is None and a[0] == 0:
+    raise ZeroDivisionError("Invalid filter gain")
+  hist = memory_to_hist(memory, na - 1, zero)
+  xh = np.full((max(nb - 1, 1),), float(zero))
+  yh = np.array([float(v) for v in hist] + [0.0] * (1 if na == 1 else 0))
+  d_xh = _ffi.DevBuf(xh.nbytes, device).upload(xh)
+  d_yh = _ffi.DevBuf(yh.nbytes, device).upload(yh)
+  it = iter(seq)
+  while True:
+    chunk = _pull(it, block)
+    if not chunk:
+      return
+    n = len(chunk)
+    series = {}
+    for side, its in (("b", b_it), ("a", a_it)):
+      for k, src in enumerate(its):
+        if src is not None:
+          vals = _pull(src, n)
+          n = min(n, len(vals))      # a coefficient stream that ends, ends the output
+          series[(side, k)] = vals
+    if n == 0:
+      return
+    x = np.asarray(chunk[:n], dtype=np.float64)
+    cols = {key: np.asarray(vals[:n], dtype=np.float64) for key, vals in series.items()}
+    gain = a[0]
+    if ("a", 0) in cols:             # series a0: every other coefficient times 1 / a0 (:166-174)
+      inv = 1.0 / cols.pop(("a", 0))
+      for k in range(nb):
+        if ("b", k) in cols:
+          cols[("b", k)] = cols[("b", k)] * inv
+        elif b[k] != 0:
+          cols[("b", k)] = float(b[k]) * inv
+      for k in range(1, na):
+        if ("a", k) in cols:
+          cols[("a", k)] = cols[("a", k)] * inv
+        elif a[k] != 0:
+          cols[("a", k)] = float(a[k]) * inv
+      gain = 1.0
+    keys = sorted(cols)
+    packed = np.ascontiguousarray(np.stack([cols[k] for k in keys])) if keys else np.zeros((1, n))
+    d_coef = _ffi.DevBuf(packed.nbytes, device).upload(packed)
+    base = d_coef.ptr.value
+
+    def taps(side, count, consts):
+      arr = (_ffi.TvTap * count)()
+      for k in range(count):
+        if (side, k) in cols:
+          arr[k] = _ffi.TvTap(0.0, base + keys.index((side, k)) * n * 8, 1, 0)
+        else:
+          arr[k] = _ffi.TvTap(float(consts[k]), None, 0, 0)
+      return arr
+    tb = taps("b", nb, b)
+    ta = taps("a", na, [gain] + list(a[1:]))
+    d_x = _ffi.DevBuf(x.nbytes, device).upload(x)
+    d_y = _ffi.DevBuf(x.nbytes, device)
+    _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), 1,
+                                    d_x.ptr, d_y.ptr, n, _ffi.TIME_MAJOR, 1, 1, d_xh.ptr, d_yh.ptr,
+                                    float(zero), device, None))
+    _ffi.check(L.alz_device_sync(device))
+    for v in d_y.download((n,), np.float64).tolist():
+      yield v
+    if n < len(chunk):
+      return
+
+
+def process_block(b, a, x, xh=None, yh=None, zero=0., layout="time"):
+  """Array-level entry: one block of C channels through a time-varying filter.
+
+  b / a : per delay, a float or a float64 torch CUDA tensor of shape [N] (shared by all channels)
+          or matching ``x`` (per channel).  x : float64 CUDA tensor [N, C] ("time") or [C, N].
+  xh / yh : [nb-1, C] / [na-1, C] CUDA tensors, updated in place (None: zeros, not returned).
+  """
+  import torch
+  L = _ffi.load()
+  lay = _ffi.TIME_MAJOR if layout == "time" else _ffi.CHAN_MAJOR
+  if not x.is_cuda or x.dtype != torch.float64 or not x.is_contiguous() or x.dim() != 2:
+    raise ValueError("x must be a contiguous 2-D float64 CUDA tensor")
+  n, C = (tuple(x.shape) if lay == _ffi.TIME_MAJOR else tuple(x.shape)[::-1])
+  nb, na = len(b), len(a)
+  keep = []
+
+  def taps(coefs):
+    arr = (_ffi.TvTap * len(coefs))()
+    for k, v in enumerate(coefs):
+      if type(v).__module__.startswith("torch"):
+        if not v.is_cuda or v.dtype != torch.float64 or not v.is_contiguous():
+          raise ValueError("coefficient series must be contiguous float64 CUDA tensors")
+        keep.append(v)
+        if v.dim() == 1:
+          if v.numel() != n:
+            raise ValueError("a shared coefficient series needs one value per sample")
+          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), 1, 0)
+        elif tuple(v.shape) == tuple(x.shape):
+          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), *((C, 1) if lay == _ffi.TIME_MAJOR else (1, n)))
+        else:
+          raise ValueError("a per-channel coefficient series must have the shape of x")
+      else:
+        arr[k] = _ffi.TvTap(float(v), None, 0, 0)
+    return arr
+  tb, ta = taps(b), taps(a)
+  if xh is None:
+    xh = torch.full((max(nb - 1, 1), C), float(zero), dtype=torch.float64, device=x.device)
+  if yh is None:
+    yh = torch.full((max(na - 1, 1), C), float(zero), dtype=torch.float64, device=x.device)
+  y = torch.empty_like(x)
+  ld = C if lay == _ffi.TIME_MAJOR else n
+  stream = torch.cuda.current_stream(x.device).cuda_stream
+  _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), C,
+                                  x.data_ptr(), y.data_ptr(), n, lay, ld, ld, xh.data_ptr(), yh.data_ptr(),
+                                  float(zero), x.device.index or 0, ctypes.c_void_p(stream)))
+  return y
+
+
+def design_over_streams(design, *args):
+  """The Stream-argument form of a scalar design function: ``design(*scalars)`` must return a
+  filter with constant coefficients; the result is a ZFilter whose coefficients are Streams
+  holding that design evaluated for every sample of the argument streams (scalars among the
+  arguments are held constant; the stream ends with the shortest argument)."""
+  from .filters import ZFilter
+  from .stream import Stream
+  iters = [iter(a) if is_series(a) else itertools.repeat(a) for a in args]
+  probe_args = []
+  firsts = []
+  for it in iters:
+    first = next(it)
+    firsts.append(first)
+    probe_args.append(first)
+  first_filt = design(*probe_args)
+  nb, na = len(first_filt.numlist), len(first_filt.denlist)
+
+  def designs():
+    yield first_filt
+    for vals in zip(*iters):
+      yield design(*vals)
+  shared = itertools.tee(designs(), nb + na)
+
+  def coef(src, side, k):
+    for filt in src:
+      lst = filt.numlist if side == "b" else filt.denlist
+      yield lst[k] if k < len(lst) else 0.0
+  num = [Stream(coef(shared[k], "b", k)) for k in range(nb)]
+  den = [Stream(coef(shared[nb + k], "a", k)) for k in range(na)]
+  # structural constants stay constants (a0 = 1, absent taps), as in the reference's algebra
+  for k in range(nb):
+    if first_filt.numlist[k] == 0:
+      num[k] = 0.0
+  for k in range(na):
+    if first_filt.denlist[k] == 0 or (k == 0 and first_filt.denlist[0] == 1):
+      den[k] = first_filt.denlist[k]
+  return ZFilter(num, den)

@@ -162,6 +162,26 @@ int alz_pcm_decode_dev(const void *raw_dev, int bits, int keep, int64_t n_sample
 int alz_pcm_encode_dev(const double *in_dev, int64_t n, int dfmt, int big_endian, void *out_dev,
                        int *flags_dev, int device, void *stream);
 
+/* ---- time-varying filters ------------------------------------------------------------------ */
+/* One coefficient of a time-varying filter: a constant, or a series with one value per sample
+ * (lazy_filters.py:202-204, 214-216: ``next(b_k) * d_k`` / ``-next(a_k) * m_k``). */
+typedef struct alz_tv_tap {
+  double value;             /* the constant (ignored when series_dev != NULL); 0 = term absent */
+  const double *series_dev; /* coefficient value for sample n at series_dev[n*stride_n + c*stride_c] */
+  int64_t stride_n;
+  int64_t stride_c;         /* 0: one series shared by every channel */
+} alz_tv_tap_t;
+/* LinearFilter.__call__ with Stream coefficients (lazy_filters.py:141-264) on one block of
+ * `channels` independent streams: b[0..nb-1], a[0..na-1] (a[0] constant and non-zero: the
+ * reference normalises a series a0 away first, :166-174); nb, na <= 9.  xh_dev / yh_dev hold the
+ * input / output histories [k * channels + c] = x[-1-k] / y[-1-k] (nb-1 / na-1 rows) and are
+ * updated in place, so consecutive blocks continue one stream; `zero` is the output of a filter
+ * with no terms (:227-231).  Same layouts and pitches as alz_bank_process_dev. */
+int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t *a,
+                       int64_t channels, const double *x_dev, double *y_dev, int64_t n, int layout,
+                       int64_t ldx, int64_t ldy, double *xh_dev, double *yh_dev, double zero,
+                       int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -378,6 +378,57 @@ def formats_cases():
   return out
 
 
+# --------------------------------------------------------------------------
+# 12. time-varying filters: Stream coefficients (lazy_filters.py:166-174, 197-224) and the
+#     Stream-argument forms of the designs (:1179-1495)
+# --------------------------------------------------------------------------
+def timevar_cases():
+  out = dict(direct=[], designs=[])
+  rnd = random.Random(4242)
+  N = 200
+  x = [rnd.uniform(-1, 1) for _ in range(N)]
+  ser = lambda lo, hi: [rnd.uniform(lo, hi) for _ in range(N)]
+  b0, b2, a1, a2, a3, a0 = ser(.1, 1), ser(-1, 1), ser(-.9, .9), ser(-.4, .4), ser(-.2, .2), ser(.5, 2)
+
+  def coefspec(lst):
+    return [dict(series=hx(v)) if isinstance(v, list) else dict(const=hx(v)) for v in lst]
+
+  def run(b, a, **kw):
+    mk = lambda lst: [Stream(v) if isinstance(v, list) else v for v in lst]
+    y = list(ZFilter(mk(b), mk(a))(list(x), **kw))
+    out["direct"].append(dict(b=coefspec(b), a=coefspec(a), memory=hx(kw["memory"]) if "memory" in kw else None,
+                              zero=hx(kw.get("zero", 0.)), y=hx(y)))
+  run([b0], [1., a1])
+  run([b0, 0.25, b2], [1., a1, .3, a3], memory=[.1, .2, .3], zero=.05)
+  run([1., b2], [1., 0., a2], memory=[.7])
+  run([b0, 0., 1.], [2., a1])
+  run([b0, -1.], [-1., a1, a2], zero=-.1)
+  run([b0, .5], [a0, a1, .2], memory=[.3], zero=.01)
+  run([.5, b2, 0., 0., .1], [1., 0., 0., 0., a3])          # the wider register window (5 taps per side)
+  run([b0], [1.])                                            # no recurrence at all
+  # designs called with Streams
+  cut = [(300 + 40 * k) * Hz for k in range(N)]
+  frq = [(500 + 15 * k) * Hz for k in range(N)]
+  bws = [(40 + .5 * k) * Hz for k in range(N)]
+  specs = [("lowpass.pole", lowpass.pole, [cut]), ("lowpass.z", lowpass.z, [cut]),
+           ("highpass.pole", highpass.pole, [cut]), ("highpass.z", highpass.z, [cut]),
+           ("lowpass.pole_exp", lowpass.pole_exp, [cut]), ("highpass.z_exp", highpass.z_exp, [cut]),
+           ("resonator.z_exp", resonator.z_exp, [frq, 80 * Hz]),
+           ("resonator.poles_exp", resonator.poles_exp, [1000 * Hz, bws]),
+           ("resonator.freq_z_exp", resonator.freq_z_exp, [frq, bws]),
+           ("resonator.freq_poles_exp", resonator.freq_poles_exp, [frq, bws])]
+  for name, fn, args in specs:
+    mk = lambda: [Stream(v) if isinstance(v, list) else v for v in args]
+    filt = fn(*mk())
+    dump_coef = lambda lst: [dict(series=hx(list(v))) if isinstance(v, Stream) else dict(const=hx(v)) for v in lst]
+    b_spec, a_spec = dump_coef(filt.numlist), dump_coef(filt.denlist)
+    y = list(fn(*mk())(list(x)))
+    out["designs"].append(dict(name=name, args=[hx(v) if isinstance(v, list) else dict(const=hx(v)) for v in args],
+                               b=b_spec, a=a_spec, y=hx(y)))
+  out["x"] = hx(x)
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   dump("filters.json", filt_cases())
@@ -391,3 +442,4 @@ if __name__ == "__main__":
   dump("karplus.json", karplus_case())
   dump("callers.json", callers_case())
   dump("formats.json", formats_cases())
+  dump("timevar.json", timevar_cases())
