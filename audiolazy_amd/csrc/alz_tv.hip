@@ -11,8 +11,12 @@
 // Lane = channel; every lane walks the block serially with the last NB-1 inputs and NA-1 outputs
 // in registers.  The coefficient values of a batch of samples are loaded ahead of the dependent
 // steps (they do not depend on the recurrence); a shared series (stride_c == 0) is one broadcast
-// load per wave.  Arithmetic: separately rounded mul/add in the reference's order (bit-exact).
+// load per wave.  A single stream (channels == 1, the reference's own use) takes k_tv_one, where
+// the lanes prefetch in time instead.  Arithmetic: separately rounded mul/add in the reference's
+// order (bit-exact).
 #include "alz_common.h"
+
+#include <type_traits>
 
 namespace alz {
 
@@ -47,11 +51,16 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
   for (int k = 1; k < NB; ++k) d[k] = (k < p.nb) ? p.xh[(int64_t)(k - 1) * p.channels + c] : 0.0;
 #pragma unroll
   for (int k = 1; k < NA; ++k) m[k] = (k < p.na) ? p.yh[(int64_t)(k - 1) * p.channels + c] : 0.0;
+  // The tap descriptors are wave-uniform run-time values.  They are read once, and the step
+  // below picks constant / series / absent with selects: straight-line code, no branch per tap.
   double cb[NB], nca[NA];         // constants (denominator already negated)
+  bool b_on[NB], b_ser[NB], a_on[NA], a_ser[NA];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) cb[k] = p.b.value[k];
+  for (int k = 0; k < NB; ++k) { cb[k] = p.b.value[k]; b_on[k] = p.b.kind[k] != 0; b_ser[k] = p.b.kind[k] == 2; }
 #pragma unroll
-  for (int k = 0; k < NA; ++k) nca[k] = -p.a.value[k];
+  for (int k = 0; k < NA; ++k) { nca[k] = -p.a.value[k]; a_on[k] = k > 0 && p.a.kind[k] != 0; a_ser[k] = k > 0 && p.a.kind[k] == 2; }
+  const bool divide = p.gain_mode == 1, negate = p.gain_mode == 2, no_terms = p.n_terms == 0;
+  const double gain = p.gain, zero = p.zero;
   const double *xc = p.x + c * p.sxc;
   double *yc = p.y + c * p.syc;
 
@@ -63,7 +72,9 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
     for (int u = 0; u < B; ++u) xv[u] = (u < cnt) ? xc[(n0 + u) * p.sxn] : 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      if (p.b.kind[k] == 2) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) sb[k][u] = 0.0;
+      if (b_ser[k]) {
         const double *s = p.b.series[k] + c * p.b.sc[k];
 #pragma unroll
         for (int u = 0; u < B; ++u) sb[k][u] = (u < cnt) ? s[(n0 + u) * p.b.sn[k]] : 0.0;
@@ -71,30 +82,36 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
     }
 #pragma unroll
     for (int k = 1; k < NA; ++k) {
-      if (p.a.kind[k] == 2) {
+#pragma unroll
+      for (int u = 0; u < B; ++u) sa[k][u] = 0.0;
+      if (a_ser[k]) {
         const double *s = p.a.series[k] + c * p.a.sc[k];
 #pragma unroll
         for (int u = 0; u < B; ++u) sa[k][u] = (u < cnt) ? -s[(n0 + u) * p.a.sn[k]] : 0.0;
       }
     }
+    auto steps = [&](auto div_tag) {
+    constexpr bool DIV = decltype(div_tag)::value;   // keeps the long division sequence out of the common path
 #pragma unroll
     for (int u = 0; u < B; ++u) {
+      d[0] = xv[u];
+      double acc = -0.0;           // additive identity: the first present term initialises the sum
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double coef = b_ser[k] ? sb[k][u] : cb[k];
+        const double s = acc + coef * d[k];
+        acc = b_on[k] ? s : acc;
+      }
+#pragma unroll
+      for (int k = 1; k < NA; ++k) {
+        const double coef = a_ser[k] ? sa[k][u] : nca[k];
+        const double s = acc + coef * m[k];
+        acc = a_on[k] ? s : acc;
+      }
+      if constexpr (DIV) acc = acc / gain;
+      acc = negate ? -acc : acc;
+      acc = no_terms ? zero : acc;
       if (u < cnt) {
-        d[0] = xv[u];
-        double acc = -0.0;         // additive identity: the first present term initialises the sum
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          if (p.b.kind[k] == 1) acc = acc + cb[k] * d[k];
-          else if (p.b.kind[k] == 2) acc = acc + sb[k][u] * d[k];
-        }
-#pragma unroll
-        for (int k = 1; k < NA; ++k) {
-          if (p.a.kind[k] == 1) acc = acc + nca[k] * m[k];
-          else if (p.a.kind[k] == 2) acc = acc + sa[k][u] * m[k];
-        }
-        if (p.gain_mode == 1) acc = acc / p.gain;
-        else if (p.gain_mode == 2) acc = -acc;
-        if (p.n_terms == 0) acc = p.zero;
         yc[(n0 + u) * p.syn] = acc;
 #pragma unroll
         for (int k = NA - 1; k > 1; --k) m[k] = m[k - 1];
@@ -103,6 +120,9 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
         for (int k = NB - 1; k > 0; --k) d[k] = d[k - 1];
       }
     }
+    };
+    if (divide) steps(std::true_type{});
+    else steps(std::false_type{});
   }
 #pragma unroll
   for (int k = 1; k < NB; ++k)
@@ -110,6 +130,143 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
 #pragma unroll
   for (int k = 1; k < NA; ++k)
     if (k < p.na) p.yh[(int64_t)(k - 1) * p.channels + c] = m[k];
+}
+
+// ---------------------------------------------------------------------------
+// k_tv_one: a single stream.  One wave; the 64 lanes fetch 64 consecutive samples of x and of
+// every coefficient series with one coalesced load each, one batch ahead of the recurrence, so the
+// memory latency is off the serial path.  The recurrence itself is computed by all lanes alike
+// (the operands of step u are broadcast with v_readlane from lane u); lane u keeps y[u] and the
+// batch is stored with one coalesced store.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)bits, lane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// branch-free pick between two doubles with a wave-uniform all-ones / all-zeros mask
+__device__ __forceinline__ double pick(unsigned long long mask, double yes, double no) {
+  const unsigned long long a = (unsigned long long)__double_as_longlong(yes);
+  const unsigned long long b = (unsigned long long)__double_as_longlong(no);
+  return __longlong_as_double((long long)((a & mask) | (b & ~mask)));
+}
+
+// a load the compiler does not track: the wave waits for it by hand (wait_loaded) so that the
+// next batch can stay in flight across the whole recurrence of the current one
+__device__ __forceinline__ double load_untracked(const double *ptr) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+
+template <int NB, int NA>
+__global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
+  const int lane = threadIdx.x;
+  constexpr int kLoads = NB + NA;          // loads per batch: x, NB numerator and NA-1 denominator series
+  double d[NB], m[NA];
+#pragma unroll
+  for (int k = 1; k < NB; ++k) d[k] = (k < p.nb) ? p.xh[k - 1] : 0.0;
+#pragma unroll
+  for (int k = 1; k < NA; ++k) m[k] = (k < p.na) ? p.yh[k - 1] : 0.0;
+  double cb[NB], nca[NA];
+  unsigned long long b_on[NB], b_ser[NB], a_on[NA], a_ser[NA];   // masks
+  const double *b_src[NB], *a_src[NA];
+  int64_t b_sn[NB], a_sn[NA];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    cb[k] = p.b.value[k];
+    b_on[k] = p.b.kind[k] != 0 ? ~0ull : 0ull;
+    b_ser[k] = p.b.kind[k] == 2 ? ~0ull : 0ull;
+    b_src[k] = p.b.kind[k] == 2 ? p.b.series[k] : p.x;      // absent / constant taps: any valid address
+    b_sn[k] = p.b.kind[k] == 2 ? p.b.sn[k] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    nca[k] = -p.a.value[k];
+    a_on[k] = (k > 0 && p.a.kind[k] != 0) ? ~0ull : 0ull;
+    a_ser[k] = (k > 0 && p.a.kind[k] == 2) ? ~0ull : 0ull;
+    a_src[k] = (k > 0 && p.a.kind[k] == 2) ? p.a.series[k] : p.x;
+    a_sn[k] = (k > 0 && p.a.kind[k] == 2) ? p.a.sn[k] : 0;
+  }
+  const bool divide = p.gain_mode == 1;
+  const unsigned long long negate = p.gain_mode == 2 ? ~0ull : 0ull, no_terms = p.n_terms == 0 ? ~0ull : 0ull;
+  const double gain = p.gain, zero = p.zero;
+
+  struct Batch { double x, sb[NB], sa[NA]; };
+  auto fetch = [&](int64_t n0, Batch &t) {
+    int64_t i = n0 + lane;
+    i = i < p.n ? i : p.n - 1;             // past the end: re-read the last sample (never used)
+    t.x = load_untracked(p.x + i * p.sxn);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) t.sb[k] = load_untracked(b_src[k] + i * b_sn[k]);
+#pragma unroll
+    for (int k = 1; k < NA; ++k) t.sa[k] = load_untracked(a_src[k] + i * a_sn[k]);
+  };
+  // the batch fetched before the most recent one has landed once at most kLoads loads (the most
+  // recent batch) plus the y store in between are outstanding; tie the registers to the wait
+  auto wait_loaded = [&](Batch &t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads) : "memory");
+    asm volatile("" : "+v"(t.x));
+#pragma unroll
+    for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(t.sb[k]));
+#pragma unroll
+    for (int k = 1; k < NA; ++k) asm volatile("" : "+v"(t.sa[k]));
+  };
+  auto recur = [&](const Batch &t, int64_t n0, auto div_tag) {
+    constexpr bool DIV = decltype(div_tag)::value;   // the division sequence must not sit in the other loop
+    const int cnt = (p.n - n0 < 64) ? (int)(p.n - n0) : 64;
+    double ybuf = 0.0;
+    for (int u = 0; u < cnt; ++u) {
+      d[0] = lane_value(t.x, u);
+      double acc = -0.0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double coef = pick(b_ser[k], lane_value(t.sb[k], u), cb[k]);
+        acc = pick(b_on[k], acc + coef * d[k], acc);
+      }
+#pragma unroll
+      for (int k = 1; k < NA; ++k) {
+        const double coef = pick(a_ser[k], -lane_value(t.sa[k], u), nca[k]);
+        acc = pick(a_on[k], acc + coef * m[k], acc);
+      }
+      if constexpr (DIV) acc = acc / gain;
+      acc = pick(negate, -acc, acc);
+      acc = pick(no_terms, zero, acc);
+      ybuf = (lane == u) ? acc : ybuf;
+#pragma unroll
+      for (int k = NA - 1; k > 1; --k) m[k] = m[k - 1];
+      if (NA > 1) m[1] = acc;
+#pragma unroll
+      for (int k = NB - 1; k > 0; --k) d[k] = d[k - 1];
+    }
+    if (lane < cnt) p.y[(n0 + lane) * p.syn] = ybuf;
+  };
+
+  Batch A, B;
+  fetch(0, A);
+  for (int64_t n0 = 0; n0 < p.n; n0 += 128) {
+    fetch(n0 + 64, B);
+    wait_loaded(A);
+    if (divide) recur(A, n0, std::true_type{});
+    else recur(A, n0, std::false_type{});
+    fetch(n0 + 128, A);
+    wait_loaded(B);
+    if (n0 + 64 < p.n) {
+      if (divide) recur(B, n0 + 64, std::true_type{});
+      else recur(B, n0 + 64, std::false_type{});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 1; k < NB; ++k)
+      if (k < p.nb) p.xh[k - 1] = d[k];
+#pragma unroll
+    for (int k = 1; k < NA; ++k)
+      if (k < p.na) p.yh[k - 1] = m[k];
+  }
 }
 
 }  // namespace alz
@@ -149,7 +306,11 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   const unsigned grid = (unsigned)((channels + 63) / 64);
-  if (nb <= 3 && na <= 3)
+  if (channels == 1 && nb <= 3 && na <= 3)
+    hipLaunchKernelGGL((alz::k_tv_one<3, 3>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+  else if (channels == 1)
+    hipLaunchKernelGGL((alz::k_tv_one<alz::kTvMax, alz::kTvMax>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+  else if (nb <= 3 && na <= 3)
     hipLaunchKernelGGL((alz::k_tv<3, 3, 8>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 4>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
