@@ -83,7 +83,7 @@ def cpu_baseline(b, a, n_samples, budget_s=12.0):
                                                                          os.cpu_count() or 0)}
 
 
-def side_workload(args, alz, torch, dev, rank, world, local):
+def side_workload(args, alz, torch, dev, rank, world, local, red_dev):
   """configs[3] (gammatone bank) and configs[4] (LPC frames): same timing protocol, own metric."""
   import torch.distributed as dist
   ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -129,7 +129,7 @@ def side_workload(args, alz, torch, dev, rank, world, local):
   sync_all()
   elapsed = time.perf_counter() - t0
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
   if rank == 0:
@@ -161,6 +161,8 @@ def main():
                   help="skip the post-run 4096-sample parity launch (keeps a rocprofv3 --stats average clean)")
   ap.add_argument("--fused", action="store_true",
                   help="opt-in FMA mode of the streaming kernel: NOT bit-exact (reported as such); default off")
+  ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                  help="process-group backend for N > 1 (nccl = RCCL; gloo lets tests run several ranks on one GPU)")
   ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
@@ -173,15 +175,21 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.backend == "gloo":
+    local %= max(torch.cuda.device_count(), 1)   # test mode: ranks may share a GPU
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.backend == "nccl":
+      dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+      dist.init_process_group("gloo")
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
+  red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the max-time all-reduce lives
 
   if args.workload in ("gammatone", "lpc"):
-    return side_workload(args, alz, torch, dev, rank, world, local)
+    return side_workload(args, alz, torch, dev, rank, world, local, red_dev)
   C, N = args.channels, 1 << args.log2_samples
   if args.workload == "fir":
     if args.channels == 4096 and args.log2_samples == 20:   # configs[2] defaults
@@ -230,7 +238,7 @@ def main():
   kernel_name = bank.last_kernel
 
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 

@@ -1,0 +1,66 @@
+"""bench.py's contract (one JSON line with the agreed keys) and __graft_entry__.smoke(), run as
+the driver runs them; the N > 1 path is exercised with two ranks sharing the one GPU of the
+test box (gloo for the barrier / max-time all-reduce, which is all the collectives it uses)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def run(cmd, timeout=600):
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+  assert len(lines) == 1, out.stdout
+  return json.loads(lines[0])
+
+
+def check(line, n_gpus, steps, warmup):
+  assert KEYS <= set(line), sorted(KEYS - set(line))
+  assert (line["n_gpus"], line["steps"], line["warmup"]) == (n_gpus, steps, warmup)
+  assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+  assert line["dtype"] == "f64" and line["data"] == "synthetic" and "workload" in line["config"]
+  roof = line["roofline"]
+  assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
+  assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+  assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def test_single_gpu_line_with_cpu_baseline():
+  line = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--channels", "512", "--log2-samples", "14"])
+  check(line, 1, 3, 1)
+  assert line["unit"] == "Gsamples/s" and line["config"]["parity_spot_check"] == "bit-exact"
+  cpu = line["cpu_baseline"]
+  assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] == 1
+
+
+@pytest.mark.parametrize("workload", ["fir", "gammatone", "lpc"])
+def test_side_workloads(workload):
+  extra = ["--channels", "256", "--log2-samples", "12"] if workload == "fir" else []
+  line = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--workload", workload] + extra)
+  check(line, 1, 2, 1)
+
+
+def test_two_ranks_weak_scaling_path():
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2", "--steps", "2",
+         "--warmup", "1", "--channels", "256", "--log2-samples", "13", "--backend", "gloo"]
+  line = run(cmd)
+  check(line, 2, 2, 1)
+  assert "cpu_baseline" not in line          # rank 0 at N = 1 only
+  assert line["config"]["channels_per_gpu"] == 256
+
+
+def test_smoke_entry():
+  out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
