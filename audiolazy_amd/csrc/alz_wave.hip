@@ -391,40 +391,63 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       for (int j = 0; j < kChunks; ++j)
         dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlotBytes + j * 1040);
     };
-    // feed-forward of tile t: lane (q, cl) owns samples 16q .. 16q+15 of channel cl
+    // feed-forward of tile t: lane (q, cl) owns samples 4j + q (j = 0..15) of channel cl, so the
+    // four lane groups of one ds_write_b64 fill four consecutive rows of the p ring (512
+    // contiguous bytes; with 16q + j the groups were 2 KiB apart: a 4-way bank conflict)
     auto feed_forward = [&](int64_t t) {
       const char *xs = xring + (int)(t % kXRing) * kSlotBytes + lane_off;
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kSlotBytes + lane_off;  // tile t-1
       char *ps = pring + (int)(t % kPRing) * kSlotBytes + lane_off_p;
-      double xv[18];
+      auto xat = [&](int u) -> double {       // x[u] of this tile; u = -1, -2 reach into tile t-1
+        return *reinterpret_cast<const double *>(xs + ALZ_EOFF(u));
+      };
+      // sample 4j + q - d sits q - d steps after sample 4j; in TIME layout the 16-byte pad after
+      // every 8 rows is crossed only for even j with q - d < 0 (adj), never otherwise
+      const int adj1 = (!CM && q == 0) ? 16 : 0, adj2 = (!CM && q < 2) ? 16 : 0;
+      const char *x_d0 = xs + q * kStep;
+      const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
+      const char *x_d2[2] = {xs + (q - 2) * kStep - adj2, xs + (q - 2) * kStep};
+      double x0[16], x1[16], x2[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) xv[j + 2] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q + j));
-      if (q > 0) {
-        xv[1] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q - 1));
-        xv[0] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(16 * q - 2));
-      } else if (t > 0) {
-        xv[1] = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1));
-        xv[0] = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2));
-      } else {
-        xv[1] = d1;
-        xv[0] = d2;
+      for (int j = 0; j < 16; ++j) {
+        if constexpr (PB & 1u) x0[j] = *reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j));
+        if constexpr (PB & 2u) {
+          if (j > 0) x1[j] = *reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j));
+        }
+        if constexpr (PB & 4u) {
+          if (j > 0) x2[j] = *reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j));
+        }
+      }
+      // j == 0: samples q - 1 and q - 2 may lie before the tile
+      if constexpr ((PB & 6u) != 0) {
+        double pm1, pm2;                        // x[-1], x[-2] relative to this tile
+        if (t > 0) {
+          pm1 = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1));
+          pm2 = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2));
+        } else {
+          pm1 = d1;
+          pm2 = d2;
+        }
+        const double c0 = xat(0), c1 = xat(1);
+        if constexpr (PB & 2u) x1[0] = q == 0 ? pm1 : q == 1 ? c0 : q == 2 ? c1 : xat(2);
+        if constexpr (PB & 4u) x2[0] = q == 0 ? pm2 : q == 1 ? pm1 : q == 2 ? c0 : c1;
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double acc = 0.0;
         bool first = true;
-        if constexpr (PB & 1u) { acc = b0 * xv[j + 2]; first = false; }
+        if constexpr (PB & 1u) { acc = b0 * x0[j]; first = false; }
         if constexpr (PB & 2u) {
-          if (FMA && !first) acc = __builtin_fma(b1, xv[j + 1], acc);
-          else { const double v = b1 * xv[j + 1]; acc = first ? v : acc + v; }
+          if (FMA && !first) acc = __builtin_fma(b1, x1[j], acc);
+          else { const double v = b1 * x1[j]; acc = first ? v : acc + v; }
           first = false;
         }
         if constexpr (PB & 4u) {
-          if (FMA && !first) acc = __builtin_fma(b2, xv[j], acc);
-          else { const double v = b2 * xv[j]; acc = first ? v : acc + v; }
+          if (FMA && !first) acc = __builtin_fma(b2, x2[j], acc);
+          else { const double v = b2 * x2[j]; acc = first ? v : acc + v; }
           first = false;
         }
-        *reinterpret_cast<double *>(ps + (16 * q + j) * kStep) = acc;
+        *reinterpret_cast<double *>(ps + (4 * j + q) * kStep) = acc;
       }
     };
     auto store_tile = [&](int64_t t) {
