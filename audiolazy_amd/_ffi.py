@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalzhip.so")
+LIB_PATH = os.environ.get("ALZ_LIBRARY") or os.path.join(_HERE, "libalzhip.so")   # ALZ_LIBRARY: A/B builds of the same ABI
 
 # status codes (include/alz.h)
 OK = 0
