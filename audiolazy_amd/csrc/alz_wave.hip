@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 //
 //   AUX wave  queues the tile DMA, waits for it, computes the feed-forward sums
 //             p[n] = b0*x[n] (+ b1*x[n-1]) (+ b2*x[n-2]) for a whole tile with all 64 lanes
-//             (time-parallel: 16 channels x 4 row blocks), and stores finished y tiles;
+//             (time-parallel: lane group q owns samples 4j + q), and stores finished y tiles;
 //   REC wave  runs only the serial part  y[n] = (p[n] + (-a1)*y[n-1]) + (-a2)*y[n-2]
 //             (4 f64 ops and one LDS read per step, one row-select LDS write per 4 steps).
 //
