@@ -324,6 +324,13 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 // G = 16 channels per workgroup (the REC wave's other 48 lanes are ghosts as in k_wave).
 // ---------------------------------------------------------------------------
 static constexpr int kXRing = 4, kPRing = 3, kYRing = 2;
+#ifndef ALZ_DUO_SLOT
+#define ALZ_DUO_SLOT (8192 + kChunks * 16)
+#endif
+#ifndef ALZ_DUO_CMPAD
+#define ALZ_DUO_CMPAD 16
+#endif
+static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads); its residue mod 256 matters, see DESIGN.md
 
 // Skew.  The four lane groups of the REC wave are exact copies of the same 16 recurrences; group
 // q runs q steps behind group 0 (it reads p[s - q] at step s).  At every step with s % 4 == 3
@@ -347,17 +354,21 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   char *xring = smem;
-  char *pring = smem + kXRing * kSlotBytes;
-  char *yring = pring + kPRing * kSlotBytes;
+  char *pring = smem + kXRing * kDuoSlot;
+  char *yring = pring + kPRing * kDuoSlot;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   // x ring (DMA target): byte offset of element (u, cl) = lane_off + ALZ_EOFF(u), 16-byte pad
   // after every 1 KiB chunk.  p and y rings: TIME rows are unpadded (row u at u*128), CHAN rows
   // keep the pad between channel pairs (REC's lanes read one channel each).
-  const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
+  // channel-major: a DMA chunk is two channels of 512 B, which share their banks; a 32-byte pad
+  // per chunk spreads the eight chunks and the four skewed lane groups over all 32 bank pairs
+  // (16 bytes left them 4-way conflicted).  Time-major rows keep the 16-byte pad.
+  constexpr int kPad = CM ? ALZ_DUO_CMPAD : 16, kChunkLds = 1024 + kPad;
+  const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * kPad : cl * 8;
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
   constexpr int kStep = CM ? 8 : G * 8;               // bytes from sample u to u+1 in the p/y rings
-  constexpr int kOutChunk = CM ? 1040 : 1024;         // bytes per 1 KiB store chunk in the y ring
-  const int lane_off_p = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
+  constexpr int kOutChunk = CM ? kChunkLds : 1024;         // bytes per 1 KiB store chunk in the y ring
+  const int lane_off_p = CM ? cl * T * 8 + ((cl * T) >> 7) * kPad : cl * 8;
 
   if (wave == 1) {
     // ------------------------------ AUX ------------------------------
@@ -389,15 +400,15 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       const int s = (int)(t % kXRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
-        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlotBytes + j * 1040);
+        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kDuoSlot + j * kChunkLds);
     };
     // feed-forward of tile t: lane (q, cl) owns samples 4j + q (j = 0..15) of channel cl, so the
     // four lane groups of one ds_write_b64 fill four consecutive rows of the p ring (512
     // contiguous bytes; with 16q + j the groups were 2 KiB apart: a 4-way bank conflict)
     auto feed_forward = [&](int64_t t) {
-      const char *xs = xring + (int)(t % kXRing) * kSlotBytes + lane_off;
-      const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kSlotBytes + lane_off;  // tile t-1
-      char *ps = pring + (int)(t % kPRing) * kSlotBytes + lane_off_p;
+      const char *xs = xring + (int)(t % kXRing) * kDuoSlot + lane_off;
+      const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kDuoSlot + lane_off;  // tile t-1
+      char *ps = pring + (int)(t % kPRing) * kDuoSlot + lane_off_p;
       auto xat = [&](int u) -> double {       // x[u] of this tile; u = -1, -2 reach into tile t-1
         return *reinterpret_cast<const double *>(xs + ALZ_EOFF(u));
       };
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       }
     };
     auto store_tile = [&](int64_t t) {
-      const char *ys = yring + (int)(t % kYRing) * kSlotBytes;
+      const char *ys = yring + (int)(t % kYRing) * kDuoSlot;
       double *yt = yg + t * y_tile;
       dbl2 v[kChunks];
 #pragma unroll
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
     if (q == 3) {
-      const char *xs = xring + (int)((nt - 1) % kXRing) * kSlotBytes + lane_off;
+      const char *xs = xring + (int)((nt - 1) % kXRing) * kDuoSlot + lane_off;
       if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
       if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
     }
@@ -503,9 +514,9 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     int ps_cur = 0, ps_prv = kPRing - 1, ys_cur = 0;         // ring slots of tile i, rotated by hand
     for (int64_t i = 0; i < nt; ++i) {
       // this lane reads sample (u - q) of the tile; u - q < 0 lives in the previous tile's slot
-      const char *cur = pring + ps_cur * kSlotBytes + lane_off_p - q * kStep;
-      const char *prv = pring + ps_prv * kSlotBytes + lane_off_p + (T - q) * kStep;
-      char *wr = yring + ys_cur * kSlotBytes + lane_off_p - q * kStep;
+      const char *cur = pring + ps_cur * kDuoSlot + lane_off_p - q * kStep;
+      const char *prv = pring + ps_prv * kDuoSlot + lane_off_p + (T - q) * kStep;
+      char *wr = yring + ys_cur * kDuoSlot + lane_off_p - q * kStep;
       ps_prv = ps_cur;
       ps_cur = (ps_cur + 1 == kPRing) ? 0 : ps_cur + 1;
       ys_cur = (ys_cur + 1 == kYRing) ? 0 : ys_cur + 1;
@@ -665,7 +676,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = duo ? (size_t)(kXRing + kPRing + kYRing) * kSlotBytes : (size_t)kRing * kSlotBytes;
+  size_t lds = duo ? (size_t)(kXRing + kPRing + kYRing) * kDuoSlot : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
   static bool attr_set[5][2][64] = {};
   const int gi = duo ? (io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
