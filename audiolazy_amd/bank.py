@@ -341,15 +341,23 @@ class FilterBank(object):
 
     def gen():
       it = iter(seq)
+      scalars = False
+      if self.n_inputs == 1:      # scalar items go through np.fromiter: no list of Python floats
+        for first in it:
+          scalars = not hasattr(first, "__len__")
+          it = itertools.chain([first], it)
+          break
       while True:
-        chunk = list(itertools.islice(it, block))
-        if not chunk:
+        if scalars:
+          x = np.fromiter(itertools.islice(it, block), dtype=np.float64).reshape(-1, 1)
+        else:
+          chunk = list(itertools.islice(it, block))
+          x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), self.n_inputs)
+        if x.shape[0] == 0:
           return
-        x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), self.n_inputs)
         y = self.process(x, layout="time")
         if scalar_out:
-          for v in y[:, 0].tolist():
-            yield v
+          yield from y[:, 0].tolist()
         else:
           for row in y:
             yield row
