@@ -32,8 +32,19 @@ class LinearFilter(object):
   """
 
   def __init__(self, numerator=None, denominator=None):
-    self.numpoly = Poly(numerator)
-    self.denpoly = Poly({0: 1} if denominator is None else denominator)
+    if isinstance(numerator, LinearFilter):          # filter type cast (reference :115-120)
+      if denominator is not None:
+        numerator = numerator / denominator
+      self.numpoly, self.denpoly = numerator.numpoly, numerator.denpoly
+    else:
+      self.numpoly = Poly(numerator)
+      self.denpoly = Poly({0: 1} if denominator is None else denominator)
+    # the denominator starts at z ** 0: a common delay / advance factor is cancelled (:126-132)
+    powers = [k for k, _ in self.denpoly.terms()]
+    if powers and min(powers) != 0:
+      shift = Poly({-min(powers): 1})
+      self.numpoly = self.numpoly * shift
+      self.denpoly = self.denpoly * shift
 
   # -- coefficient views (reference :55-96) -------------------------------------
   @staticmethod
@@ -226,6 +237,9 @@ class ZFilter(LinearFilter):
                                 self.denpoly.values() if self.denpoly.is_polynomial()
                                 else dict(self.denpoly.terms()))
 
+
+from .stream import IGNORED_CLASSES as _stream_ignored  # noqa: E402
+_stream_ignored.append(LinearFilter)
 
 z = ZFilter({-1: 1})   # z ** -1 is the unit delay: the Poly variable is x = z ** -1
 

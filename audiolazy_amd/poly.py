@@ -3,8 +3,10 @@
 Host-side mirror of what the filter hot path needs from the reference's ``Poly``
 (reference audiolazy/lazy_poly.py:66-490): construction from list / dict /
 scalar, ``+ - * / **``, composition, ``diff``, ``terms`` / ``values`` /
-``order``.  Coefficients are plain Python numbers (time-varying Stream
-coefficients are outside the engine's gate).
+``order``.  Coefficients are plain Python numbers or Streams (a Stream coefficient
+makes the filter time-varying; whenever an operation reads one to build a new
+coefficient it reads a ``copy()``, so the operand stays usable -- the job of the
+reference's ``thub`` calls, lazy_poly.py:392-395).
 
 Rounding contract: filter *design* results must equal the reference's to the
 last bit, and they depend on evaluation order, so the two places where order
@@ -17,6 +19,13 @@ matters follow the reference exactly --
 Terms whose coefficient equals zero are dropped on construction (:136-143).
 """
 import numbers
+
+from .stream import Stream, IGNORED_CLASSES
+
+
+def _use(v):
+  """The value of a coefficient for building another one (a Stream is teed, not consumed)."""
+  return v.copy() if isinstance(v, Stream) else v
 
 
 class Poly(object):
@@ -84,7 +93,7 @@ class Poly(object):
 
   # -- ring operations ---------------------------------------------------------
   def __neg__(self):
-    return Poly({k: -v for k, v in self._t.items()})
+    return Poly({k: -_use(v) for k, v in self._t.items()})
 
   def __pos__(self):
     return self
@@ -92,9 +101,9 @@ class Poly(object):
   def __add__(self, other):
     if not isinstance(other, Poly):
       other = Poly(other)
-    out = dict(self._t)
+    out = {k: _use(v) for k, v in self._t.items()}
     for k, v in other._t.items():
-      out[k] = (self._t[k] + v) if k in self._t else v
+      out[k] = (out[k] + _use(v)) if k in out else _use(v)
     return Poly(out)
 
   __radd__ = lambda self, other: Poly(other) + self
@@ -113,9 +122,9 @@ class Poly(object):
       for k2, v2 in other._t.items():
         k = k1 + k2
         if k in out:
-          out[k] += v1 * v2
+          out[k] += _use(v1) * _use(v2)
         else:
-          out[k] = v1 * v2
+          out[k] = _use(v1) * _use(v2)
     return Poly(out)
 
   def __rmul__(self, other):
@@ -128,8 +137,8 @@ class Poly(object):
       if len(other) != 1:
         raise NotImplementedError("Can't divide general Poly instances")
       (shift, value), = other._t.items()
-      return Poly({k - shift: v / value for k, v in self._t.items()})
-    return Poly({k: v / other for k, v in self._t.items()})
+      return Poly({k - shift: _use(v) / _use(value) for k, v in self._t.items()})
+    return Poly({k: _use(v) / _use(other) for k, v in self._t.items()})
 
   def __pow__(self, n):
     if isinstance(n, Poly):
@@ -192,5 +201,7 @@ class Poly(object):
       return "0"
     return " + ".join("%r * x^%r" % (v, k) for k, v in self.terms())
 
+
+IGNORED_CLASSES.append(Poly)
 
 x = Poly({1: 1})

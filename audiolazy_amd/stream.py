@@ -42,8 +42,16 @@ def blocks(seq, size=None, hop=None, padval=0.):
     yield win
 
 
+# classes whose own reflected operators must win over the elementwise Stream ones: filters and
+# polynomials (``gain_stream * z ** -1`` is a time-varying filter, not a Stream of filters;
+# reference lazy_stream.py:47-51 ``__ignored_classes__``).  Filled in by poly.py / filters.py.
+IGNORED_CLASSES = []
+
+
 def _binary(op):
   def method(self, other):
+    if isinstance(other, tuple(IGNORED_CLASSES)):
+      return NotImplemented
     if isinstance(other, Stream) or (hasattr(other, "__iter__") and not hasattr(other, "__len__")):
       return Stream(map(op, iter(self), iter(other)))
     return Stream(op(item, other) for item in self)
@@ -52,6 +60,8 @@ def _binary(op):
 
 def _rbinary(op):
   def method(self, other):
+    if isinstance(other, tuple(IGNORED_CLASSES)):
+      return NotImplemented
     return Stream(op(other, item) for item in self)
   return method
 

@@ -39,8 +39,10 @@ def test_errors(al):
   z, ZFilter = al.z, al.ZFilter
   with pytest.raises(ValueError):                            # lazy_filters.py:165-168
     (z ** 2)([1, 2, 3])
-  with pytest.raises(ZeroDivisionError):                     # lazy_filters.py:177-178
+  with pytest.raises(ValueError):       # the common delay is cancelled first (:126-132): 1 / z ** -1 is z
     ZFilter([1.], [0., 1.])([1, 2, 3])
+  with pytest.raises(ZeroDivisionError):                     # lazy_filters.py:177-178, at the engine's gate
+    al.FilterBank([([1.], [0., 1.])], n_inputs=1)
 
 
 def test_designs_called_like_the_reference(al):

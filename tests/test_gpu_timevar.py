@@ -54,7 +54,10 @@ def test_blocks_continue_one_stream(al):
 
 
 def test_errors(al):
+  from audiolazy_amd import timevar
   with pytest.raises(ZeroDivisionError):                    # lazy_filters.py:177-178
+    list(timevar.run([iter([1., 2.])], [0., .5], [1., 2.]))
+  with pytest.raises(ValueError):                           # ... which ZFilter turns into z / .5 first (:126-132)
     list(al.ZFilter([al.Stream([1., 2.])], [0., .5])([1., 2.]))
   with pytest.raises(ValueError):                           # lazy_filters.py:165-168
     (al.ZFilter([al.Stream([1., 2.])]) * al.z)([1., 2.])
