@@ -20,7 +20,7 @@
 
 namespace alz {
 
-static constexpr int kTvMax = 9;   // taps per side the register windows hold (delays 0 .. 8)
+static constexpr int kTvMax = 17;  // taps per side the register windows hold (delays 0 .. 16)
 
 struct TvSide {
   int kind[kTvMax];               // 0 absent, 1 constant, 2 series
@@ -165,6 +165,11 @@ template <int NB, int NA>
 __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
   const int lane = threadIdx.x;
   constexpr int kLoads = NB + NA;          // loads per batch: x, NB numerator and NA-1 denominator series
+  // Untracked (inline-asm) loads only in the small variant.  Above 256 registers hipcc parks
+  // values in AGPRs right after the asm statement and reuses the VGPR; a load still in flight
+  // would then land in a register that already holds something else (seen as a memory
+  // aperture violation with the 17-tap variant).
+  constexpr bool kUntracked = NB <= 3 && NA <= 3;
   double d[NB], m[NA];
 #pragma unroll
   for (int k = 1; k < NB; ++k) d[k] = (k < p.nb) ? p.xh[k - 1] : 0.0;
@@ -172,23 +177,19 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
   for (int k = 1; k < NA; ++k) m[k] = (k < p.na) ? p.yh[k - 1] : 0.0;
   double cb[NB], nca[NA];
   unsigned long long b_on[NB], b_ser[NB], a_on[NA], a_ser[NA];   // masks
-  const double *b_src[NB], *a_src[NA];
-  int64_t b_sn[NB], a_sn[NA];
+  // (taps that are not series carry series = x, stride 0 from the host: every fetch below is an
+  // unconditional load from a valid address, and no pointer table has to live in registers)
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     cb[k] = p.b.value[k];
     b_on[k] = p.b.kind[k] != 0 ? ~0ull : 0ull;
     b_ser[k] = p.b.kind[k] == 2 ? ~0ull : 0ull;
-    b_src[k] = p.b.kind[k] == 2 ? p.b.series[k] : p.x;      // absent / constant taps: any valid address
-    b_sn[k] = p.b.kind[k] == 2 ? p.b.sn[k] : 0;
   }
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
     nca[k] = -p.a.value[k];
     a_on[k] = (k > 0 && p.a.kind[k] != 0) ? ~0ull : 0ull;
     a_ser[k] = (k > 0 && p.a.kind[k] == 2) ? ~0ull : 0ull;
-    a_src[k] = (k > 0 && p.a.kind[k] == 2) ? p.a.series[k] : p.x;
-    a_sn[k] = (k > 0 && p.a.kind[k] == 2) ? p.a.sn[k] : 0;
   }
   const bool divide = p.gain_mode == 1;
   const unsigned long long negate = p.gain_mode == 2 ? ~0ull : 0ull, no_terms = p.n_terms == 0 ? ~0ull : 0ull;
@@ -198,15 +199,24 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
   auto fetch = [&](int64_t n0, Batch &t) {
     int64_t i = n0 + lane;
     i = i < p.n ? i : p.n - 1;             // past the end: re-read the last sample (never used)
-    t.x = load_untracked(p.x + i * p.sxn);
+    if constexpr (kUntracked) {
+      t.x = load_untracked(p.x + i * p.sxn);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) t.sb[k] = load_untracked(b_src[k] + i * b_sn[k]);
+      for (int k = 0; k < NB; ++k) t.sb[k] = load_untracked(p.b.series[k] + i * p.b.sn[k]);
 #pragma unroll
-    for (int k = 1; k < NA; ++k) t.sa[k] = load_untracked(a_src[k] + i * a_sn[k]);
+      for (int k = 1; k < NA; ++k) t.sa[k] = load_untracked(p.a.series[k] + i * p.a.sn[k]);
+    } else {
+      t.x = p.x[i * p.sxn];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) t.sb[k] = p.b.series[k][i * p.b.sn[k]];
+#pragma unroll
+      for (int k = 1; k < NA; ++k) t.sa[k] = p.a.series[k][i * p.a.sn[k]];
+    }
   };
   // the batch fetched before the most recent one has landed once at most kLoads loads (the most
   // recent batch) plus the y store in between are outstanding; tie the registers to the wait
   auto wait_loaded = [&](Batch &t) {
+    if constexpr (!kUntracked) return;       // hipcc waits for its own loads
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads) : "memory");
     asm volatile("" : "+v"(t.x));
 #pragma unroll
@@ -279,7 +289,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   if (!b || !a || !x_dev || !y_dev) return alz::fail(ALZ_E_ARG, "NULL argument");
   if (nb < 1 || na < 1 || channels < 1 || n < 0) return alz::fail(ALZ_E_ARG, "nb, na, channels >= 1 and n >= 0 required");
   if (nb > alz::kTvMax || na > alz::kTvMax)
-    return alz::fail(ALZ_E_UNSUPPORTED, "time-varying filters are limited to 9 taps per side");
+    return alz::fail(ALZ_E_UNSUPPORTED, "time-varying filters are limited to 17 taps per side");
   if ((nb > 1 && !xh_dev) || (na > 1 && !yh_dev)) return alz::fail(ALZ_E_ARG, "history arrays required");
   if (layout != ALZ_TIME_MAJOR && layout != ALZ_CHAN_MAJOR) return alz::fail(ALZ_E_ARG, "unknown layout");
   if (a[0].series_dev) return alz::fail(ALZ_E_ARG, "a0 must be constant (normalise a series gain on the host)");
@@ -292,11 +302,13 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   for (int k = 0; k < alz::kTvMax; ++k) {
     const alz_tv_tap_t *tb = k < nb ? &b[k] : nullptr, *ta = (k < na && k > 0) ? &a[k] : nullptr;
     p.b.kind[k] = !tb ? 0 : tb->series_dev ? 2 : (tb->value != 0.0 ? 1 : 0);
-    p.b.value[k] = tb ? tb->value : 0.0; p.b.series[k] = tb ? tb->series_dev : nullptr;
-    p.b.sn[k] = tb ? tb->stride_n : 0; p.b.sc[k] = tb ? tb->stride_c : 0;
+    const bool bs = p.b.kind[k] == 2;
+    p.b.value[k] = tb ? tb->value : 0.0; p.b.series[k] = bs ? tb->series_dev : x_dev;
+    p.b.sn[k] = bs ? tb->stride_n : 0; p.b.sc[k] = bs ? tb->stride_c : 0;
     p.a.kind[k] = !ta ? 0 : ta->series_dev ? 2 : (ta->value != 0.0 ? 1 : 0);
-    p.a.value[k] = ta ? ta->value : 0.0; p.a.series[k] = ta ? ta->series_dev : nullptr;
-    p.a.sn[k] = ta ? ta->stride_n : 0; p.a.sc[k] = ta ? ta->stride_c : 0;
+    const bool as = p.a.kind[k] == 2;
+    p.a.value[k] = ta ? ta->value : 0.0; p.a.series[k] = as ? ta->series_dev : x_dev;
+    p.a.sn[k] = as ? ta->stride_n : 0; p.a.sc[k] = as ? ta->stride_c : 0;
     p.n_terms += (p.b.kind[k] != 0) + (p.a.kind[k] != 0);
   }
   p.gain = a[0].value;
@@ -313,7 +325,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   else if (nb <= 3 && na <= 3)
     hipLaunchKernelGGL((alz::k_tv<3, 3, 8>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 4>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   hipError_t e = hipGetLastError();
   if (prev != device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return alz::fail(ALZ_E_HIP, std::string("k_tv launch: ") + hipGetErrorString(e));

@@ -112,9 +112,15 @@ class LinearFilter(object):
 
   # -- analysis -----------------------------------------------------------------
   def freq_response(self, freq):
-    """H(e^{j freq}), freq in rad/sample (reference :267-301); lists map elementwise."""
-    if isinstance(freq, (list, tuple)):
-      return [self.freq_response(f) for f in freq]
+    """H(e^{j freq}), freq in rad/sample (reference :267-301); iterables map elementwise (a
+    Stream gives a Stream, other containers their own type)."""
+    if hasattr(freq, "__iter__"):
+      import types
+      from .stream import Stream
+      data = (self.freq_response(f) for f in freq)
+      if isinstance(freq, types.GeneratorType):
+        return data
+      return Stream(data) if isinstance(freq, Stream) else type(freq)(data)
     z_ = cmath.exp(-1j * freq)
     den = self.denpoly(z_)
     if den == 0:
@@ -247,82 +253,176 @@ z = ZFilter({-1: 1})   # z ** -1 is the unit delay: the Poly variable is x = z *
 # ---------------------------------------------------------------------------
 # containers (reference :895-1084)
 # ---------------------------------------------------------------------------
+def _elementwise_freq(method):
+  """``freq`` may be a number or an iterable, mapped elementwise: a Stream gives a Stream, a
+  generator a generator, any other container its own type (the reference's ``@elementwise``,
+  lazy_misc.py:163-229)."""
+  import functools
+  import types
+
+  @functools.wraps(method)
+  def wrapper(self, freq):
+    if hasattr(freq, "__iter__"):
+      from .stream import Stream
+      data = (method(self, f) for f in freq)
+      if isinstance(freq, types.GeneratorType):
+        return data
+      if isinstance(freq, Stream):
+        return Stream(data)
+      return type(freq)(data)
+    return method(self, freq)
+  return wrapper
+
+
 class FilterList(list):
-  """A list of filters; a single filter or an iterable of filters builds it."""
+  """A list of filters that is itself a filter; a single filter or an iterable of filters
+  builds it (reference :906-968).  Items that are not callable (numbers, coefficient lists)
+  count as the LinearFilter they cast to (``callables``, :955-961); ``+`` and ``*`` act like on
+  lists and keep the class (:893-903)."""
 
   def __init__(self, *filters):
     if len(filters) == 1 and not callable(filters[0]) and hasattr(filters[0], "__iter__"):
       filters = filters[0]
     super(FilterList, self).__init__(filters)
 
+  @property
+  def callables(self):
+    return [f if callable(f) else LinearFilter(f) for f in self]
+
   def is_linear(self):
-    return all(isinstance(f, LinearFilter) or (isinstance(f, FilterList) and f.is_linear()) for f in self)
+    return all(isinstance(f, LinearFilter) or (hasattr(f, "is_linear") and f.is_linear())
+               for f in self.callables)
 
   def is_lti(self):
-    return self.is_linear() and all(f.is_lti() for f in self)
+    return self.is_linear() and all(f.is_lti() for f in self.callables)
 
   def is_causal(self):
-    return self.is_linear() and all(f.is_causal() for f in self)
+    return all(f.is_causal() for f in self.callables if hasattr(f, "is_causal"))
+
+  def __add__(self, other):
+    return type(self)(list.__add__(self, other))
+
+  def __radd__(self, other):
+    return type(self)(list.__add__(list(other), self))
+
+  def __mul__(self, other):
+    return type(self)(list.__mul__(self, other))
+
+  __rmul__ = __mul__
+
+  def __eq__(self, other):
+    return type(self) == type(other) and list.__eq__(self, other)
+
+  def __ne__(self, other):
+    return type(self) != type(other) or list.__ne__(self, other)
+
+  __hash__ = None
+
+  def _polys(self, name):
+    try:
+      return [getattr(f, name) for f in self.callables]
+    except AttributeError:
+      raise AttributeError("Non-linear filter")
 
 
 class CascadeFilter(FilterList):
-  """Filters applied one after the other; ``memory`` / ``zero`` are forwarded
-  unchanged to every stage (reference :970-1021, call :988-990).  A cascade of
-  linear filters runs as ONE fused bank on the GPU."""
+  """Filters applied one after the other; the call arguments after the input (``memory`` /
+  ``zero``) are forwarded unchanged to every stage (reference :970-1021, call :988-990).  A
+  cascade of LTI linear filters runs as ONE fused bank on the GPU; anything else (time-varying
+  members, arbitrary callables) is the plain composition of its members."""
 
-  def __call__(self, seq, memory=None, zero=0.):
-    if self.is_linear() and self.is_lti():
+  def __call__(self, *args, **kwargs):
+    seq = args[0]
+    members = self.callables
+    if members and all(isinstance(f, LinearFilter) and f.is_lti() for f in members):
       from .bank import FilterBank, sections_of
-      if len(self) == 0:
-        from .stream import Stream
-        return Stream(seq)
-      return FilterBank(sections_of(list(self)), n_inputs=1)(seq, memory=memory, zero=zero)
+      return FilterBank(sections_of(members), n_inputs=1)(seq, *args[1:], **kwargs)
     data = seq
-    for f in self:
-      data = f(data, memory=memory, zero=zero)
+    for f in members:
+      data = f(data, *args[1:], **kwargs)
+    if not members:
+      from .stream import Stream
+      return Stream(seq)
     return data
 
   @property
   def numpoly(self):
-    out = Poly(1)
-    for f in self:
-      out = out * f.numpoly
-    return out
+    out = None
+    for poly in self._polys("numpoly"):
+      out = poly if out is None else out * poly
+    return Poly(1) if out is None else out
 
   @property
   def denpoly(self):
-    out = Poly(1)
-    for f in self:
-      out = out * f.denpoly
-    return out
+    out = None
+    for poly in self._polys("denpoly"):
+      out = poly if out is None else out * poly
+    return Poly(1) if out is None else out
 
+  @_elementwise_freq
   def freq_response(self, freq):
-    out = 1.
-    for f in self:
-      out = out * f.freq_response(freq)
+    out = None
+    for f in self.callables:
+      if not hasattr(f, "freq_response"):
+        raise AttributeError("Non-linear filter")
+      r = f.freq_response(freq)
+      out = r if out is None else out * r
     return out
 
 
 class ParallelFilter(FilterList):
   """Filters fed with the same input, outputs summed ``((f1 + f2) + f3) ...``
-  (reference :1024-1084, call :1048-1054).  Runs as one OUTER bank on the GPU
-  followed by the ordered sum; an empty list yields ``zero`` per input item."""
+  (reference :1024-1084, call :1048-1054).  LTI linear members run as one OUTER bank on the GPU
+  followed by the ordered sum on the device; otherwise every member gets its own copy of the
+  input and the output Streams are added.  An empty list yields ``zero`` per input item."""
 
-  def __call__(self, seq, memory=None, zero=0., block=4096):
+  def __call__(self, *args, **kwargs):
     from .stream import Stream
-    if len(self) == 0:
+    seq = args[0]
+    members = self.callables
+    if len(members) == 0:
+      zero = kwargs.get("zero", 0.)
       return Stream(zero for _ in seq)
-    if all(isinstance(f, LinearFilter) for f in self):
+    if all(isinstance(f, LinearFilter) and f.is_lti() for f in members) and len(args) == 1 \
+       and set(kwargs) <= {"memory", "zero", "block"}:
       try:
-        return self._call_bank(seq, memory, zero, block)
+        return self._call_bank(seq, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block", 4096))
       except NotImplementedError:   # coefficients outside the engine's gate
         pass
-    data = list(seq)
-    outs = [list(f(data, memory=memory, zero=zero)) for f in self]
-    total = outs[0]
-    for other in outs[1:]:
-      total = [a + b for a, b in zip(total, other)]
-    return Stream(total)
+    import itertools
+    copies = itertools.tee(seq, len(members))
+    total = None
+    for f, src in zip(members, copies):
+      out = f(src, *args[1:], **kwargs)
+      out = out if isinstance(out, Stream) else Stream(out)
+      total = out if total is None else total + out
+    return total
+
+  @property
+  def numpoly(self):
+    if not self.is_linear():
+      raise AttributeError("Non-linear filter")
+    total = None
+    for f in self.callables:
+      total = f if total is None else total + f
+    return total.numpoly
+
+  @property
+  def denpoly(self):
+    out = None
+    for poly in self._polys("denpoly"):
+      out = poly if out is None else out * poly
+    return Poly(1) if out is None else out
+
+  @_elementwise_freq
+  def freq_response(self, freq):
+    out = None
+    for f in self.callables:
+      if not hasattr(f, "freq_response"):
+        raise AttributeError("Non-linear filter")
+      r = f.freq_response(freq)
+      out = r if out is None else out + r
+    return out
 
   def _call_bank(self, seq, memory, zero, block):
     """All filters as the coefficient sets of one OUTER bank over the single input, then the
@@ -331,12 +431,13 @@ class ParallelFilter(FilterList):
     import numpy as np
     from .bank import FilterBank, memory_to_hist, sections_of
     from .stream import Stream
-    for f in self:
+    members = self.callables
+    for f in members:
       if not f.is_causal():
         raise ValueError("Non-causal filter")
       if f.denpoly[0] == 0:
         raise ZeroDivisionError("Invalid filter gain")
-    secs = [sections_of(f)[0] for f in self]
+    secs = [sections_of(f)[0] for f in members]
     nb = max(max(len(b) for b, _ in secs), 1)
     na = max(len(a) for _, a in secs)
     b = np.zeros((len(secs), nb))

@@ -46,7 +46,7 @@ class Poly(object):
     for power, coef in terms.items():
       if isinstance(power, float) and power.is_integer():
         power = int(power)
-      if coef != 0:
+      if isinstance(coef, Stream) or coef != 0:     # a Stream is never "zero" (lazy_poly.py:138)
         clean[power] = coef
     self._t = clean
 
@@ -80,7 +80,16 @@ class Poly(object):
   def __eq__(self, other):
     if not isinstance(other, Poly):
       other = Poly(other)
-    return self._t == other._t
+    if set(self._t) != set(other._t):
+      return False
+    for k, v in self._t.items():
+      w = other._t[k]
+      if isinstance(v, Stream) or isinstance(w, Stream):   # Streams compare by identity
+        if v is not w:
+          return False
+      elif v != w:
+        return False
+    return True
 
   def __ne__(self, other):
     return not self == other
@@ -89,7 +98,8 @@ class Poly(object):
     return hash(frozenset(self._t.items()))
 
   def copy(self):
-    return Poly(self)
+    """Same terms; Stream coefficients are teed so both polynomials stay usable (:258-262)."""
+    return Poly({k: _use(v) for k, v in self._t.items()})
 
   # -- ring operations ---------------------------------------------------------
   def __neg__(self):
@@ -151,6 +161,8 @@ class Poly(object):
       return Poly()
     if len(self._t) == 1:
       (k, v), = self._t.items()
+      if isinstance(v, Stream):
+        return Poly({k * n: _use(v) ** n})
       return Poly({k * n: 1 if v == 1 else v ** n})   # lazy_poly.py:445-449
     if not isinstance(n, numbers.Integral) or n < 0:
       raise ValueError("only non-negative integer powers of a multi-term Poly")

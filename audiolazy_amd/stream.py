@@ -1,13 +1,15 @@
-"""Stream: the lazy iterable the filter protocol returns, and ``blocks``.
+"""Stream: the lazy iterable the filter protocol returns, ``blocks`` and ``thub``.
 
-Host-side mirror of the parts of the reference's ``Stream`` the filter hot path
-touches (reference audiolazy/lazy_stream.py:74-405): iteration, elementwise
-operators, ``take`` / ``peek`` / ``skip`` / ``limit`` / ``append`` / ``map`` /
-``copy`` and ``blocks`` (the feed of the blocked engine, lazy_stream.py:215-220
--> lazy_misc.py:74-129).  Two deliberate differences from the reference under
-Python >= 3.7: ``take(n)`` / ``limit(n)`` / ``peek(n)`` on a stream that ends
-early return what was there (the reference dies with RuntimeError because of
-PEP 479, lazy_stream.py:292, 348).
+Host-side mirror of the reference's ``Stream`` (audiolazy/lazy_stream.py:74-405): the
+constructor rules (one iterable: that iterable; one non-iterable: endless repeat; several
+non-iterables: endless cycle; several iterables: chained), elementwise operators of every
+kind (arithmetic, bitwise, comparisons; reflected; unary), ``take`` / ``peek`` / ``skip`` /
+``limit`` / ``append`` / ``map`` / ``filter`` / ``copy`` / elementwise attribute access and
+calls, and ``blocks`` (the feed of the blocked engine, lazy_stream.py:215-220 ->
+lazy_misc.py:74-129); ``thub`` is the tee hub the reference uses to let one Stream appear
+several times in an expression (:469-630).  One deliberate difference under Python >= 3.7:
+``take(n)`` / ``limit(n)`` / ``peek(n)`` on a stream that ends early return what was there
+(the reference dies with RuntimeError because of PEP 479, lazy_stream.py:292, 348).
 """
 import collections
 import itertools
@@ -48,13 +50,17 @@ def blocks(seq, size=None, hop=None, padval=0.):
 IGNORED_CLASSES = []
 
 
+def _is_iterable(obj):
+  return hasattr(obj, "__iter__")
+
+
 def _binary(op):
   def method(self, other):
     if isinstance(other, tuple(IGNORED_CLASSES)):
       return NotImplemented
-    if isinstance(other, Stream) or (hasattr(other, "__iter__") and not hasattr(other, "__len__")):
+    if _is_iterable(other):
       return Stream(map(op, iter(self), iter(other)))
-    return Stream(op(item, other) for item in self)
+    return Stream(map(lambda a: op(a, other), iter(self)))
   return method
 
 
@@ -62,90 +68,199 @@ def _rbinary(op):
   def method(self, other):
     if isinstance(other, tuple(IGNORED_CLASSES)):
       return NotImplemented
-    return Stream(op(other, item) for item in self)
+    if _is_iterable(other):
+      return Stream(map(op, iter(other), iter(self)))
+    return Stream(map(lambda a: op(other, a), iter(self)))
+  return method
+
+
+def _unary(op):
+  def method(self):
+    return Stream(map(op, iter(self)))
   return method
 
 
 class Stream(object):
-  """Lazy, single-pass iterable with elementwise operators.
+  """Lazy, single-pass iterable with elementwise operators (reference lazy_stream.py:74-405).
 
-  ``Stream(iterable)`` wraps it; ``Stream(a, b, c)`` (or a single non-iterable)
-  is the finite stream of those items, like the reference's constructor
-  (lazy_stream.py:150-178).
+  ``Stream(iterable)`` wraps it; ``Stream(5)`` repeats 5 for ever; ``Stream(1, 2, 3)`` cycles
+  through the items for ever; ``Stream(it1, it2)`` chains iterables (:137-191).
   """
 
-  def __init__(self, *items):
-    if len(items) == 1 and hasattr(items[0], "__iter__"):
-      self._it = iter(items[0])
+  def __init__(self, *dargs):
+    if len(dargs) == 0:
+      raise TypeError("Missing argument(s)")
+    if len(dargs) == 1:
+      self._data = iter(dargs[0]) if _is_iterable(dargs[0]) else itertools.repeat(dargs[0])
+    elif all(_is_iterable(arg) for arg in dargs):
+      self._data = itertools.chain(*dargs)
+    elif not any(_is_iterable(arg) for arg in dargs):
+      self._data = itertools.cycle(dargs)
     else:
-      self._it = iter(items)
+      raise TypeError("Input with both iterables and non-iterables")
 
   def __iter__(self):
-    return self._it
+    return self._data
 
-  def __next__(self):
-    return next(self._it)
-
-  next = __next__
+  def __bool__(self):
+    raise TypeError("Streams can't be used as booleans; freeze the stream first with "
+                    "list(my_stream) or tuple(my_stream), or use the bitwise operators")
 
   # -- consumption -----------------------------------------------------------
   def take(self, n=None, constructor=list):
-    """Next item (n is None) or a ``constructor`` of the next n items."""
+    """Next item (n is None: StopIteration when there is none) or a ``constructor`` of the
+    next n items (fewer when the stream ends); floats are rounded, ``inf`` takes all."""
+    data = iter(self)
     if n is None:
-      return next(self._it)
-    if n == float("inf"):
-      return constructor(self._it)
-    return constructor(itertools.islice(self._it, int(n)))
+      return next(data)
+    if isinstance(n, float):
+      if n == float("inf"):
+        return constructor(data)
+      n = int(round(n)) if n > 0 else 0     # so that -inf and nan take nothing
+    return constructor(itertools.islice(data, int(n)))
+
+  def copy(self):
+    """Independent copy; this stream stays usable (itertools.tee underneath, :294-301)."""
+    self._data, other = itertools.tee(self._data, 2)
+    return Stream(other)
+
+  tee = copy
 
   def peek(self, n=None, constructor=list):
-    """Like take, without consuming."""
-    if n is None:
-      first = next(self._it)
-      self._it = itertools.chain([first], self._it)
-      return first
-    head = list(itertools.islice(self._it, int(n)))
-    self._it = itertools.chain(head, self._it)
-    return constructor(head)
+    """Like take, without consuming (:303-322)."""
+    return self.copy().take(n=n, constructor=constructor)
 
   def skip(self, n):
-    for _ in itertools.islice(self._it, int(n)):
-      pass
+    """Throw away the first n items, lazily (:324-341)."""
+    def skipper(data, count):
+      for _ in itertools.islice(data, count):
+        pass
+      for item in data:
+        yield item
+    self._data = skipper(self._data, int(round(n)))
     return self
 
   def limit(self, n):
-    self._it = itertools.islice(self._it, int(n))
+    """End the stream after n items (:343-349)."""
+    self._data = itertools.islice(self._data, int(round(n)))
     return self
 
-  def append(self, *others):
-    self._it = itertools.chain(self._it, *[iter(o) if hasattr(o, "__iter__") else [o] for o in others])
+  def append(self, *other):
+    """Chain other stream(s) / items after this one: ``Stream(self, *other)`` (:366-374)."""
+    self._data = itertools.chain(self._data, iter(Stream(*other)))
     return self
 
   def map(self, func):
-    self._it = map(func, self._it)
+    self._data = map(func, self._data)
     return self
 
   def filter(self, func):
-    self._it = filter(func, self._it)
+    self._data = filter(func, self._data)
     return self
-
-  def copy(self):
-    """Independent copy (itertools.tee underneath, like the reference :235-240)."""
-    self._it, other = itertools.tee(self._it, 2)
-    return Stream(other)
 
   def blocks(self, *args, **kwargs):
     """Stream of blocks; see :func:`blocks` (reference lazy_stream.py:215-220)."""
     return Stream(blocks(iter(self), *args, **kwargs))
+
+  def __getattr__(self, name):
+    """Elementwise attribute access, e.g. ``stream.real`` (:351-357)."""
+    if name.startswith("__") or name in ("next", "_data"):
+      raise AttributeError(name)       # Streams are iterable, not iterators
+    return Stream(getattr(item, name) for item in iter(self))
+
+  def __call__(self, *args, **kwargs):
+    """Elementwise call of a stream of callables (:359-364)."""
+    return Stream(item(*args, **kwargs) for item in iter(self))
+
+  def __abs__(self):
+    return self.map(abs)
 
   # -- elementwise operators ---------------------------------------------------
   __add__, __radd__ = _binary(operator.add), _rbinary(operator.add)
   __sub__, __rsub__ = _binary(operator.sub), _rbinary(operator.sub)
   __mul__, __rmul__ = _binary(operator.mul), _rbinary(operator.mul)
   __truediv__, __rtruediv__ = _binary(operator.truediv), _rbinary(operator.truediv)
+  __floordiv__, __rfloordiv__ = _binary(operator.floordiv), _rbinary(operator.floordiv)
+  __mod__, __rmod__ = _binary(operator.mod), _rbinary(operator.mod)
   __pow__, __rpow__ = _binary(operator.pow), _rbinary(operator.pow)
+  __lshift__, __rlshift__ = _binary(operator.lshift), _rbinary(operator.lshift)
+  __rshift__, __rrshift__ = _binary(operator.rshift), _rbinary(operator.rshift)
+  __and__, __rand__ = _binary(operator.and_), _rbinary(operator.and_)
+  __or__, __ror__ = _binary(operator.or_), _rbinary(operator.or_)
+  __xor__, __rxor__ = _binary(operator.xor), _rbinary(operator.xor)
+  __lt__, __le__ = _binary(operator.lt), _binary(operator.le)
+  __gt__, __ge__ = _binary(operator.gt), _binary(operator.ge)
+  __eq__, __ne__ = _binary(operator.eq), _binary(operator.ne)
+  __hash__ = object.__hash__
+  __neg__, __pos__, __invert__ = _unary(operator.neg), _unary(operator.pos), _unary(operator.invert)
 
-  def __neg__(self):
-    return Stream(-item for item in self)
+
+class StreamTeeHub(Stream):
+  """A Stream that hands out up to ``n`` independent copies of itself, one per use (every
+  ``iter()`` -- hence every operator, ``take``, filter call -- consumes one), so that one
+  signal can appear several times in an expression (reference lazy_stream.py:469-571)."""
+
+  def __init__(self, data, n):
+    self._iters = list(itertools.tee(data, n))
+
+  def __iter__(self):
+    try:
+      return self._iters.pop(0)
+    except IndexError:
+      raise IndexError("StreamTeeHub has no more copies left to use")
+
+  @property
+  def _data(self):
+    return iter(self)
+
+  def copy(self):
+    """One of the remaining copies as a plain Stream (:554-570)."""
+    if len(self._iters) < 2:
+      raise IndexError("StreamTeeHub has no more copies left to use")
+    first, other = itertools.tee(self._iters[0], 2)
+    self._iters[0] = first
+    return Stream(other)
+
+  def _no_inplace(self, *args, **kwargs):
+    raise TypeError("a StreamTeeHub is read through its copies; take a copy() first")
+
+  skip = limit = append = map = filter = _no_inplace
 
   def __abs__(self):
-    return Stream(abs(item) for item in self)
+    return Stream(map(abs, iter(self)))
+
+
+def thub(data, n):
+  """Tee hub: ``data`` usable ``n`` times in what follows.  Non-iterables come back unchanged,
+  so designs can be written once for numbers and Streams (reference lazy_stream.py:573-630)."""
+  return StreamTeeHub(data, n) if _is_iterable(data) else data
+
+
+# the itertools names filter expressions are written with, returning Streams like the
+# reference's wrappers (audiolazy/lazy_itertools.py:40-60)
+def cycle(iterable):
+  return Stream(itertools.cycle(iterable))
+
+
+def repeat(item, times=None):
+  return Stream(itertools.repeat(item) if times is None else itertools.repeat(item, times))
+
+
+def count(start=0, step=1):
+  return Stream(itertools.count(start, step))
+
+
+def chain(*iterables):
+  return Stream(itertools.chain(*iterables))
+
+
+def zero_pad(seq, left=0, right=0, zero=0.):
+  """``left`` zeros, the sequence, ``right`` zeros (reference lazy_misc.py:132-160)."""
+  def gen():
+    for _ in range(left):
+      yield zero
+    for item in seq:
+      yield item
+    for _ in range(right):
+      yield zero
+  return gen()

@@ -173,7 +173,7 @@ typedef struct alz_tv_tap {
 } alz_tv_tap_t;
 /* LinearFilter.__call__ with Stream coefficients (lazy_filters.py:141-264) on one block of
  * `channels` independent streams: b[0..nb-1], a[0..na-1] (a[0] constant and non-zero: the
- * reference normalises a series a0 away first, :166-174); nb, na <= 9.  xh_dev / yh_dev hold the
+ * reference normalises a series a0 away first, :166-174); nb, na <= 17.  xh_dev / yh_dev hold the
  * input / output histories [k * channels + c] = x[-1-k] / y[-1-k] (nb-1 / na-1 rows) and are
  * updated in place, so consecutive blocks continue one stream; `zero` is the output of a filter
  * with no terms (:227-231).  Same layouts and pitches as alz_bank_process_dev. */

@@ -135,34 +135,235 @@ def test_one_pole_numerator_denominator_constructor(al, a):      # :226-233
   assert almost_eq(list(filt(data)), expected)
 
 
-@p("delay", range(1, 5))
+delays = list(range(1, 5))
+
+
+@p("delay", delays)
 def test_one_delay_variable_gain(al, delay):                     # :296-308
-  gain = al.Stream(itertools.cycle(alpha))
-  filt = gain * al.z ** -delay
-  assert isinstance(filt, al.ZFilter)
+  cycle, z, zero_pad = al.cycle, al.z, al.zero_pad
+  gain = cycle(alpha)
+  filt = gain * z ** -delay
   length = 50
-  padded = itertools.chain([0.] * delay, itertools.cycle(data))
-  expected = [g * d for g, d in itertools.islice(zip(itertools.cycle(alpha), padded), length)]
-  result = filt(itertools.cycle(data))
-  assert isinstance(result, al.Stream)
-  assert almost_eq(result.take(length), expected)
+  assert isinstance(filt, al.ZFilter)
+  data_stream = cycle(alpha) * zero_pad(cycle(data), left=delay)
+  expected = data_stream.take(length)
+  result_stream = filt(cycle(data))
+  assert isinstance(result_stream, al.Stream)
+  assert almost_eq(result_stream.take(length), expected)
 
 
 def test_variable_gain_in_denominator(al):                       # :310-330
-  z, Stream = al.z, al.Stream
-  filt = 1 / (Stream(1, 2, 3) - z ** -1)
+  Stream, z, cycle, thub = al.Stream, al.z, al.cycle, al.thub
+  a = Stream(1, 2, 3)
+  filt = 1 / (a - z ** -1)
   assert isinstance(filt, al.ZFilter)
-  ainv = [1, .5, 1. / 3]
-  expected_filt1 = Stream(ainv) / (1 - Stream(ainv) * z ** -1)
+  ainv = Stream(1, .5, 1. / 3)
+  expected_filt1 = ainv.copy() / (1 - ainv.copy() * z ** -1)
   assert isinstance(expected_filt1, al.ZFilter)
-  r = list(filt(itertools.cycle(data)))                  # the 3-item gain Stream ends the output
-  ex1 = list(expected_filt1(itertools.cycle(data)))
-  assert len(r) == 3 and almost_eq(r, ex1)
-  y, out = 0., []                                        # y[n] = (x[n] + y[n-1]) / a[n], by hand
-  for a, x in zip([1, 2, 3], data):
-    y = (x + y) / a
-    out.append(y)
-  assert almost_eq(r, out)
+  ai = thub(ainv, 2)
+  expected_filt2 = ai / (1 - ai * z ** -1)
+  assert isinstance(expected_filt2, al.ZFilter)
+  length = 50
+  expected1, expected2 = expected_filt1(cycle(data)), expected_filt2(cycle(data))
+  result = filt(cycle(data))
+  assert all(isinstance(s, Stream) for s in (expected1, expected2, result))
+  r, ex1, ex2 = result.take(length), expected1.take(length), expected2.take(length)
+  assert almost_eq(r, ex1) and almost_eq(r, ex2) and almost_eq(ex1, ex2)
+
+
+@p("delay", delays)
+def test_fir_time_variant_sum(al, delay):                        # :332-347
+  cycle, z, zero_pad = al.cycle, al.z, al.zero_pad
+  gain1, gain2 = cycle(alpha), cycle(alpha[-2::-1])
+  filt = gain1 * z ** -delay + gain2 * z ** -delays[0]
+  length = 50
+  assert isinstance(filt, al.ZFilter)
+  data_stream1 = cycle(alpha) * zero_pad(cycle(data), left=delay)
+  data_stream2 = cycle(alpha[-2::-1]) * zero_pad(cycle(data), left=delays[0])
+  expected = data_stream1 + data_stream2
+  result = filt(cycle(data))
+  assert isinstance(expected, al.Stream) and isinstance(result, al.Stream)
+  assert almost_eq(result.take(length), expected.take(length))
+
+
+@p("delay", delays)
+def test_iir_time_variant_sum(al, delay):                        # :349-392
+  Stream, z, cycle = al.Stream, al.z, al.cycle
+  gain1, gain2 = cycle(alpha), cycle(alpha[-2::-1])
+  gain3, gain4, gain5, gain6 = Stream(1, 2, 3), Stream(.1, .7, -.5, -1e-3), Stream(.1, .2), Stream(3, 2, 1, 0)
+  num1 = gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]
+  den1 = 1 + gain3.copy() * z ** -(delay + 2)
+  filt1 = num1 / den1
+  num2 = gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]
+  den2 = 1 + gain6.copy() * z ** -(delay - 1)
+  filt2 = num2 / den2
+  filt = filt1 + filt2
+  assert all(isinstance(f, al.ZFilter) for f in (num1, den1, filt1, num2, den2, filt2, filt))
+  length = 90
+  expected_filter = (
+    gain1.copy() * z ** -delay +
+    gain2.copy() * z ** -delays[0] +
+    gain1.copy() * gain6.copy() * z ** -(2 * delay - 1) +
+    gain2.copy() * gain6.copy() * z ** -(delay + delays[0] - 1) +
+    gain4.copy() * z ** -delay +
+    gain5.copy() * z ** -delays[-1] +
+    gain4.copy() * gain3.copy() * z ** -(2 * delay + 2) +
+    gain5.copy() * gain3.copy() * z ** -(delay + delays[-1] + 2)
+  ) / (
+    1 +
+    gain3.copy() * z ** -(delay + 2) +
+    gain6.copy() * z ** -(delay - 1) +
+    gain3.copy() * gain6.copy() * z ** -(2 * delay + 1)
+  )
+  assert isinstance(expected_filter, al.ZFilter)
+  expected, result = expected_filter(cycle(data)), filt(cycle(data))
+  assert isinstance(expected, Stream) and isinstance(result, Stream)
+  assert almost_eq(result.take(length), expected.take(length))
+
+
+@p("delay", delays)
+def test_fir_time_variant_multiplication(al, delay):             # :394-415
+  z, cycle = al.z, al.cycle
+  gain1, gain2, gain3 = cycle(alpha), cycle(alpha[::2]), 2 + cycle(alpha[::3])
+  filt1 = gain1.copy() * z ** -delay + gain2.copy() * z ** -(delay + 1)
+  filt2 = gain2.copy() * z ** -delay + gain3.copy() * z ** -(delay - 1)
+  filt = filt1 * filt2
+  expected_filter = (
+    (gain1.copy() + gain3.copy()) * gain2.copy() * z ** -(2 * delay) +
+    gain1.copy() * gain3.copy() * z ** -(2 * delay - 1) +
+    gain2.copy() ** 2 * z ** -(2 * delay + 1)
+  )
+  length = 80
+  assert all(isinstance(f, al.ZFilter) for f in (filt1, filt2, expected_filter))
+  expected, result = expected_filter(cycle(data)), filt(cycle(data))
+  assert almost_eq(result.take(length), expected.take(length))
+
+
+@p("delay", delays)
+def test_iir_time_variant_multiplication(al, delay):             # :417-458
+  Stream, z, cycle = al.Stream, al.z, al.cycle
+  gain1, gain2 = cycle([4, 5, 6, 5, 4, 3]), cycle(alpha[::-1])
+  gain3, gain4 = Stream(*(alpha + [1, 2, 3])), Stream(.1, -.2, .3)
+  gain5, gain6 = Stream(.1, .1, .1, -7), Stream(3, 2)
+  num1 = gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]
+  den1 = 1 + gain3.copy() * z ** -(delay - 1)
+  filt1 = num1 / den1
+  num2 = gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]
+  den2 = 1 + gain6.copy() * z ** -(delay + 5)
+  filt2 = num2 / den2
+  filt = filt1 * filt2
+  assert all(isinstance(f, al.ZFilter) for f in (num1, den1, filt1, num2, den2, filt2, filt))
+  length = 90
+  expected_filter = (
+    gain1.copy() * gain4.copy() * z ** -(2 * delay) +
+    gain2.copy() * gain4.copy() * z ** -(delay + delays[0]) +
+    gain1.copy() * gain5.copy() * z ** -(delay + delays[-1]) +
+    gain2.copy() * gain5.copy() * z ** -(delays[0] + delays[-1])
+  ) / (
+    1 +
+    gain3.copy() * z ** -(delay - 1) +
+    gain6.copy() * z ** -(delay + 5) +
+    gain3.copy() * gain6.copy() * z ** -(2 * delay + 4)
+  )
+  assert isinstance(expected_filter, al.ZFilter)
+  expected, result = expected_filter(cycle(data)), filt(cycle(data))
+  assert almost_eq(result.take(length), expected.take(length))
+
+
+def test_copy(al):                                               # :460-473
+  Stream, z, cycle = al.Stream, al.z, al.cycle
+  filt1 = (2 + Stream(1, 2, 3) * z ** -1) / Stream(1, 5)
+  filt2 = filt1.copy()
+  assert isinstance(filt2, al.ZFilter) and filt1 is not filt2
+  filt_ex = Stream(2, .4) + Stream(1, .4, 3, .2, 2, .6) * z ** -1
+  length = 50
+  r1 = filt1(cycle(data[::-1])).take(length)
+  r2 = filt2(cycle(data[::-1])).take(length)
+  ex = filt_ex(cycle(data[::-1])).take(length)
+  assert almost_eq(r1, ex) and almost_eq(r2, ex) and almost_eq(r1, r2)
+
+
+@p("delay", delays)
+def test_iir_time_variant_sum_with_copy(al, delay):              # :475-494
+  Stream, z, cycle, thub = al.Stream, al.z, al.cycle, al.thub
+  k = thub(min(alpha) + 2 + cycle(alpha), 3)
+  filt = z ** -2 / k + Stream(5, 7) * z / (1 + z ** -delay)
+  filt += filt.copy()
+  filt *= z ** -1
+  assert isinstance(filt, al.ZFilter)
+  length = 40
+  expected_filter = (
+    2 / k * z ** -3 +
+    2 / k * z ** -(delay + 3) +
+    Stream(10, 14)
+  ) / (1 + z ** -delay)
+  assert isinstance(expected_filter, al.ZFilter)
+  expected, result = expected_filter(cycle(data)), filt(cycle(data))
+  assert almost_eq(result.take(length), expected.take(length))
+
+
+def test_hashable(al):                                           # :496-502
+  z = al.z
+  filt = 1 / (7 + z ** -1)
+  my_set = {filt, 17, z, z ** -1, object}
+  assert z in my_set and z ** -1 in my_set and filt in my_set and -z not in my_set
+
+
+# ------------------------------------------------------------- containers (:505-566)
+@p("kind", ["CascadeFilter", "ParallelFilter"])
+def test_container_add_mul(al, kind):                            # :508-520
+  cls, z = getattr(al, kind), al.z
+  filt_sum = cls(z) + cls(z + 3)
+  assert isinstance(filt_sum, cls) and filt_sum == cls(z, z + 3)
+  filt_prod = cls(1 - z ** -1) * 3
+  assert isinstance(filt_prod, cls) and filt_prod == cls(1 - z ** -1, 1 - z ** -1, 1 - z ** -1)
+
+
+@p("kind", ["CascadeFilter", "ParallelFilter"])
+def test_container_non_linear(al, kind):                         # :522-536
+  import math
+  cls, z = getattr(al, kind), al.z
+  for filts in ((lambda d: d ** 2), (z ** -1, lambda d: d + 4), (1 / z ** -2, (lambda d: 0.), z ** -1)):
+    filt = cls(filts)
+    assert isinstance(filt, cls) and not filt.is_linear()
+    for attr in ("numpoly", "denpoly"):
+      with pytest.raises(AttributeError):
+        getattr(filt, attr)
+    with pytest.raises(AttributeError):
+      filt.freq_response(math.pi / 2)
+
+
+@p("kind", ["CascadeFilter", "ParallelFilter"])
+def test_container_const_filter(al, kind):                       # :538-548
+  import functools
+  cls = getattr(al, kind)
+  values = [2, 4, 3, 7 - 1, -8]
+  filt1, filt2 = cls(*values), cls(values)
+  func = operator.mul if kind == "CascadeFilter" else operator.add
+  expected_value = functools.reduce(func, values)
+  count = 10
+  for d in values:
+    expected = [d * expected_value] * count
+    assert filt1(al.Stream(d)).take(count) == expected
+    assert filt2(al.Stream(d)).take(count) == expected
+
+
+@p("source", [list(range(3)), "stream", [.2, .5, .4, .1]])
+def test_call_empty_containers(al, source):                      # :559-566
+  mk = (lambda: al.Stream([5., 4., 6., 7., 12., -2.])) if source == "stream" else (lambda: source)
+  ref = [5., 4., 6., 7., 12., -2.] if source == "stream" else source
+  assert list(al.CascadeFilter()(mk())) == list(ref)
+  assert all(el == 0. for el in al.ParallelFilter()(mk()))
+
+
+def test_container_with_a_plain_callable_member(al):
+  """A non-linear member runs as the plain composition / sum of the members' own calls."""
+  z = al.z
+  x = [1., 2., 3., 4.]
+  casc = al.CascadeFilter(z ** -1, lambda d: al.Stream(d) + 4)
+  assert list(casc(x)) == [4., 5., 6., 7.]
+  par = al.ParallelFilter(z ** -1, lambda d: al.Stream(d) * 2)
+  assert list(par(x)) == [2., 5., 8., 11.]
 
 
 def test_readme_lpc_example_filters(al):                         # README.rst:362-373 (filter part)

@@ -61,8 +61,8 @@ def test_errors(al):
     list(al.ZFilter([al.Stream([1., 2.])], [0., .5])([1., 2.]))
   with pytest.raises(ValueError):                           # lazy_filters.py:165-168
     (al.ZFilter([al.Stream([1., 2.])]) * al.z)([1., 2.])
-  with pytest.raises(NotImplementedError):                  # beyond the 9-tap register window
-    list(al.ZFilter([al.Stream([1., 2.])] + [0.] * 9 + [1.])([1., 2.]))
+  with pytest.raises(NotImplementedError):                  # beyond the 17-tap register window
+    list(al.ZFilter([al.Stream([1., 2.])] + [0.] * 16 + [1.])([1., 2.]))
 
 
 @pytest.mark.parametrize("layout", ["time", "chan"])
