@@ -8,7 +8,7 @@ HIP kernels for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design
 and the z**-1 algebra stay on the host in float64.
 """
 from ._ffi import ParCorError, load as load_library, device_count  # noqa: F401
-from .stream import Stream, blocks, thub, cycle, repeat, count, chain, zero_pad  # noqa: F401
+from .stream import Stream, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
 from .bank import FilterBank, memory_to_hist, sections_of  # noqa: F401
 from .poly import Poly, x  # noqa: F401
 from .strategy import StrategyDict  # noqa: F401
@@ -16,7 +16,7 @@ from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, c
                       lowpass, highpass)
 from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
 from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
-from .synth import white_noise, zeros, karplus_strong  # noqa: F401
+from .synth import white_noise, zeros, zeroes, ones, karplus_strong  # noqa: F401
 from .analysis import envelope, maverage  # noqa: F401
 from .pcm import WavStream, chunks, decode_pcm, encode_pcm  # noqa: F401
 

@@ -8,7 +8,7 @@ input streams runs as one OUTER FilterBank on the GPU (:func:`gammatone_bank`).
 """
 import math
 
-from .filters import z, ZFilter, CascadeFilter, resonator
+from .filters import z, ZFilter, CascadeFilter, resonator, _accepts_streams
 from .strategy import StrategyDict
 
 __all__ = ["erb", "gammatone_erb_constants", "gammatone", "gammatone_bank", "erb_space"]
@@ -55,6 +55,7 @@ gammatone = StrategyDict("gammatone")
 
 
 @gammatone.strategy("sampled")
+@_accepts_streams
 def gammatone(freq, bandwidth, phase=0, eta=4):
   """Impulse-invariant ("sampled") gammatone, n^(eta-1) e^(-bandwidth n) cos(freq n + phase)
   (reference :158-182): the (eta-1)-th z-derivative of the one-pole-pair kernel, split
@@ -72,6 +73,7 @@ def gammatone(freq, bandwidth, phase=0, eta=4):
 
 
 @gammatone.strategy("slaney")
+@_accepts_streams
 def gammatone(freq, bandwidth):
   """Slaney's cascade of four pole pairs, each with one real zero (reference :188-202)."""
   A = math.exp(-bandwidth)
@@ -84,6 +86,7 @@ def gammatone(freq, bandwidth):
 
 
 @gammatone.strategy("klapuri")
+@_accepts_streams
 def gammatone(freq, bandwidth):
   """Klapuri's cascade: resonator.z_exp, resonator.poles_exp, twice, at twice the
   bandwidth (reference :208-218)."""

@@ -71,6 +71,11 @@ class LinearFilter(object):
   def dendict(self):
     return dict(self.denpoly.terms())
 
+  def __iter__(self):
+    """(numdict, dendict): what the reference's helpers compare filters by (reference :134-136)."""
+    yield self.numdict
+    yield self.dendict
+
   def is_lti(self):
     """False when some coefficient is a Stream, i.e. varies in time (reference :303-314)."""
     return not any(hasattr(v, "__iter__") for poly in (self.numpoly, self.denpoly) for _, v in poly.terms())

@@ -16,6 +16,13 @@ import itertools
 import operator
 
 
+def rint(x):
+  """Nearest integer, halves away from zero -- the rounding the reference applies to durations
+  and ``take`` counts (lazy_misc.py:44-71); unlike the builtin ``round`` (halves to even)."""
+  import math
+  return int(math.floor(x + .5)) if x >= 0 else -int(math.floor(-x + .5))
+
+
 def blocks(seq, size=None, hop=None, padval=0.):
   """Blockenizer with the reference's semantics (lazy_misc.py:74-129).
 
@@ -116,7 +123,7 @@ class Stream(object):
     if isinstance(n, float):
       if n == float("inf"):
         return constructor(data)
-      n = int(round(n)) if n > 0 else 0     # so that -inf and nan take nothing
+      n = rint(n) if n > 0 else 0           # so that -inf and nan take nothing
     return constructor(itertools.islice(data, int(n)))
 
   def copy(self):

@@ -8,7 +8,7 @@ generators wrapped in a Stream; karplus_strong's filtering runs on the GPU engin
 import math
 import random
 
-from .stream import Stream
+from .stream import Stream, rint
 from .filters import comb
 
 
@@ -18,20 +18,32 @@ def white_noise(dur=None, low=-1., high=1.):
     if dur is None or (isinstance(dur, float) and math.isinf(dur) and dur > 0):
       while True:
         yield random.uniform(low, high)
-    for _ in range(int(round(dur))):
+    for _ in range(rint(dur)):
       yield random.uniform(low, high)
   return Stream(gen())
 
 
-def zeros(dur=None):
-  """``dur`` float zeros, endless when None / inf."""
+def _constant(value, dur):
   def gen():
     if dur is None or (isinstance(dur, float) and math.isinf(dur) and dur > 0):
       while True:
-        yield 0.
-    for _ in range(int(round(dur))):
-      yield 0.
+        yield value
+    for _ in range(rint(dur)):
+      yield value
   return Stream(gen())
+
+
+def zeros(dur=None):
+  """``dur`` float zeros, endless when None / inf (reference :303-322)."""
+  return _constant(0., dur)
+
+
+zeroes = zeros
+
+
+def ones(dur=None):
+  """``dur`` float ones, endless when None / inf (reference :280-300)."""
+  return _constant(1., dur)
 
 
 def karplus_strong(freq, tau=2e4, memory=white_noise):

@@ -159,38 +159,56 @@ def process_block(b, a, x, xh=None, yh=None, zero=0., layout="time"):
 
 def design_over_streams(design, *args):
   """The Stream-argument form of a scalar design function: ``design(*scalars)`` must return a
-  filter with constant coefficients; the result is a ZFilter whose coefficients are Streams
-  holding that design evaluated for every sample of the argument streams (scalars among the
-  arguments are held constant; the stream ends with the shortest argument)."""
-  from .filters import ZFilter
+  filter with constant coefficients (a ZFilter, or a CascadeFilter of them); the result has the
+  same structure with coefficients that are Streams holding that design evaluated for every
+  sample of the argument streams (scalars among the arguments are held constant; the stream ends
+  with the shortest argument)."""
+  from .filters import ZFilter, CascadeFilter
   from .stream import Stream
   iters = [iter(a) if is_series(a) else itertools.repeat(a) for a in args]
-  probe_args = []
-  firsts = []
-  for it in iters:
-    first = next(it)
-    firsts.append(first)
-    probe_args.append(first)
-  first_filt = design(*probe_args)
-  nb, na = len(first_filt.numlist), len(first_filt.denlist)
+  first_args = [next(it) for it in iters]
+  first_filt = design(*first_args)
+  cascade = isinstance(first_filt, CascadeFilter)
+  first_secs = list(first_filt) if cascade else [first_filt]
+  # Which coefficients exist is a property of the design, not of its first sample (lowpass.z at
+  # exactly pi/2 has R == 0): the structure is the union of the first sample's and that of a
+  # generic probe point next to it (only the streamed arguments are moved).
+  probe_secs = first_secs
+  try:
+    probe = design(*[v * 0.9371 + 0.0113 if is_series(a) else v for a, v in zip(args, first_args)])
+    probe_secs = list(probe) if cascade else [probe]
+  except (ValueError, ZeroDivisionError, ArithmeticError):
+    pass
+
+  def coef_at(filt, side, k):
+    lst = filt.numlist if side == "b" else filt.denlist
+    return lst[k] if k < len(lst) else 0.0
+  shapes = [(max(len(f.numlist), len(g.numlist)), max(len(f.denlist), len(g.denlist)))
+            for f, g in zip(first_secs, probe_secs)]
+  n_coefs = sum(nb + na for nb, na in shapes)
 
   def designs():
-    yield first_filt
+    yield first_secs
     for vals in zip(*iters):
-      yield design(*vals)
-  shared = itertools.tee(designs(), nb + na)
+      filt = design(*vals)
+      yield list(filt) if cascade else [filt]
+  shared = itertools.tee(designs(), max(n_coefs, 1))
 
-  def coef(src, side, k):
-    for filt in src:
-      lst = filt.numlist if side == "b" else filt.denlist
-      yield lst[k] if k < len(lst) else 0.0
-  num = [Stream(coef(shared[k], "b", k)) for k in range(nb)]
-  den = [Stream(coef(shared[nb + k], "a", k)) for k in range(na)]
-  # structural constants stay constants (a0 = 1, absent taps), as in the reference's algebra
-  for k in range(nb):
-    if first_filt.numlist[k] == 0:
-      num[k] = 0.0
-  for k in range(na):
-    if first_filt.denlist[k] == 0 or (k == 0 and first_filt.denlist[0] == 1):
-      den[k] = first_filt.denlist[k]
-  return ZFilter(num, den)
+  def coef(src, sec, side, k):
+    for secs in src:
+      yield coef_at(secs[sec], side, k)
+  out, idx = [], 0
+  for sec, (nb, na) in enumerate(shapes):
+    num, den = [], []
+    for k in range(nb):
+      # structural constants stay constants (absent taps, a0 = 1), as in the reference's algebra
+      absent = coef_at(first_secs[sec], "b", k) == 0 and coef_at(probe_secs[sec], "b", k) == 0
+      num.append(0.0 if absent else Stream(coef(shared[idx], sec, "b", k)))
+      idx += 1
+    for k in range(na):
+      v, w = coef_at(first_secs[sec], "a", k), coef_at(probe_secs[sec], "a", k)
+      const = (v == 0 and w == 0) or (k == 0 and v == 1 and w == 1)
+      den.append(v if const else Stream(coef(shared[idx], sec, "a", k)))
+      idx += 1
+    out.append(ZFilter(num, den))
+  return CascadeFilter(out) if cascade else out[0]
