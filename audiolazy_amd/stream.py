@@ -12,7 +12,9 @@ several times in an expression (:469-630).  One deliberate difference under Pyth
 (the reference dies with RuntimeError because of PEP 479, lazy_stream.py:292, 348).
 """
 import collections
+import collections.abc
 import itertools
+import numbers
 import operator
 
 
@@ -58,7 +60,7 @@ IGNORED_CLASSES = []
 
 
 def _is_iterable(obj):
-  return hasattr(obj, "__iter__")
+  return isinstance(obj, collections.abc.Iterable)    # (a class that merely defines __iter__ is not)
 
 
 def _binary(op):
@@ -124,7 +126,9 @@ class Stream(object):
       if n == float("inf"):
         return constructor(data)
       n = rint(n) if n > 0 else 0           # so that -inf and nan take nothing
-    return constructor(itertools.islice(data, int(n)))
+    elif not isinstance(n, numbers.Integral):
+      raise TypeError("take / peek need a number of items, not %r" % (type(n).__name__,))
+    return constructor(itertools.islice(data, max(int(n), 0)))
 
   def copy(self):
     """Independent copy; this stream stays usable (itertools.tee underneath, :294-301)."""
@@ -204,37 +208,58 @@ class Stream(object):
 
 class StreamTeeHub(Stream):
   """A Stream that hands out up to ``n`` independent copies of itself, one per use (every
-  ``iter()`` -- hence every operator, ``take``, filter call -- consumes one), so that one
-  signal can appear several times in an expression (reference lazy_stream.py:469-571)."""
+  ``iter()`` -- hence every operator, filter call, ``limit`` / ``skip`` / ``append`` / ``map`` /
+  ``filter`` / ``blocks``, each of which returns a plain Stream of that copy), so that one signal
+  can appear several times in an expression.  ``peek`` and ``copy`` do not use a copy up;
+  ``take`` is refused (cast to Stream first).  Reference lazy_stream.py:469-571."""
 
   def __init__(self, data, n):
-    self._iters = list(itertools.tee(data, n))
+    self._iters = list(itertools.tee(iter(data), n))
 
   def __iter__(self):
     try:
-      return self._iters.pop(0)
+      return self._iters.pop()
     except IndexError:
-      raise IndexError("StreamTeeHub has no more copies left to use")
+      raise IndexError("StreamTeeHub has no more copies left to use.")
 
-  @property
-  def _data(self):
-    return iter(self)
+  def take(self, *args, **kwargs):
+    raise AttributeError("Use peek or cast to Stream.")
 
   def copy(self):
-    """One of the remaining copies as a plain Stream (:554-570)."""
-    if len(self._iters) < 2:
-      raise IndexError("StreamTeeHub has no more copies left to use")
+    if not self._iters:
+      iter(self)            # raises the usual IndexError
     first, other = itertools.tee(self._iters[0], 2)
     self._iters[0] = first
     return Stream(other)
 
-  def _no_inplace(self, *args, **kwargs):
-    raise TypeError("a StreamTeeHub is read through its copies; take a copy() first")
+  def peek(self, n=None, constructor=list):
+    return self.copy().take(n=n, constructor=constructor)
 
-  skip = limit = append = map = filter = _no_inplace
+  def limit(self, n):
+    return Stream(self).limit(n)
+
+  def skip(self, n):
+    return Stream(self).skip(n)
+
+  def append(self, *other):
+    return Stream(self).append(*other)
+
+  def map(self, func):
+    return Stream(self).map(func)
+
+  def filter(self, func):
+    return Stream(self).filter(func)
+
+  def blocks(self, *args, **kwargs):
+    return Stream(self).blocks(*args, **kwargs)
 
   def __abs__(self):
-    return Stream(map(abs, iter(self)))
+    return Stream(self).map(abs)
+
+  def __getattr__(self, name):
+    if name.startswith("__") or name in ("next", "_iters"):
+      raise AttributeError(name)
+    return Stream(getattr(item, name) for item in iter(self))
 
 
 def thub(data, n):
