@@ -180,23 +180,31 @@ class Poly(object):
     return Poly(terms)
 
   def __call__(self, value):
-    """Evaluate at a number, or substitute another Poly / algebraic object.
+    """Evaluate at a number or a Stream (elementwise), or substitute another Poly / algebraic
+    object.
 
-    Substitution is ``sum(coeff * value ** power)`` over the terms in insertion
-    order (lazy_poly.py:308-311); numbers use the Horner scheme for plain
-    polynomials and the direct sum otherwise (lazy_poly.py:325-342).
+    Substitution is ``sum(coeff * value ** power)`` over the terms in insertion order
+    (lazy_poly.py:313-316); numbers and Streams use the Horner-like scheme for plain polynomials
+    -- merged steps for missing powers -- and the direct sum otherwise (:318-349).  A Stream is
+    teed once per use (``thub``), so it may be any single-pass iterable.
     """
-    if not isinstance(value, numbers.Number):
+    from .stream import thub
+    # (hasattr is useless on a Stream: attribute access is elementwise there)
+    if isinstance(value, Poly) or (not isinstance(value, Stream) and hasattr(value, "numpoly")):
       total = 0
       for power, coef in self._t.items():
-        total = total + coef * value ** power
+        total = total + _use(coef) * value ** power
       return Poly(total) if isinstance(value, Poly) else total
     if not self._t:
       return 0.
-    if value == 0:
-      return self[0]
+    if not isinstance(value, Stream) and not hasattr(value, "__iter__"):
+      if value is None:
+        raise TypeError("cannot evaluate a non-empty Poly at None")
+      if value == 0:
+        return self[0]
+    value = thub(value, len(self._t))
     if self.is_polynomial():
-      pairs = list(self.terms(reverse=True))
+      pairs = [(k, _use(v)) for k, v in self.terms(reverse=True)]
       last_power, result = pairs[0]
       for power, coef in pairs[1:]:
         gap = last_power - power
@@ -205,7 +213,7 @@ class Poly(object):
       return result * value ** last_power
     total = 0
     for power, coef in self.terms():
-      total = total + coef * value ** power
+      total = total + _use(coef) * value ** power
     return total
 
   def __repr__(self):

@@ -153,3 +153,24 @@ def test_number_of_poles_order(filt_func, freq, bw):
   assert isinstance(cfilt, CascadeFilter) and len(cfilt) == 4
   for filt in cfilt:
     assert len(filt.denominator) == 3
+
+
+# ------------------------------------------- test_filters_extdep.py:239-266 (TestResonatorScipy)
+@p("func", list(resonator))
+@p("freq", [pi * k / 9 for k in range(1, 9)])
+@p("bw", [pi / 23, pi / 31])
+def test_max_gain_is_at_resonance(func, freq, bw):
+  from scipy.optimize import fminbound
+  names = func.__name__.split("_")
+  filt = func(freq, bw)
+  resonance_freq = fminbound(lambda x: -dB20(filt.freq_response(x)), 0, pi, xtol=1e-10)
+  assert abs(dB20(filt.freq_response(resonance_freq))) <= 1e-12
+  if "freq" in names:                           # the given frequency is the pole angle
+    R = math.sqrt(filt.denominator[2])
+    assert 0 < R < 1
+    cosf = math.cos(freq)
+    assert close(cosf, -filt.denominator[1] / (2 * R))
+    cosw = cosf * (2 * R) / (1 + R ** 2) if "z" in names else cosf * (1 + R ** 2) / (2 * R)
+    assert close(cosw, math.cos(resonance_freq))
+  else:                                         # the given frequency is the resonance frequency
+    assert close(freq, resonance_freq)
