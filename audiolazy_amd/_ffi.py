@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ALZ_LIBRARY") or os.path.join(_HERE, "libalzhip.so") 
 
 # status codes (include/alz.h)
 OK = 0
+TV_NEGATED = 1
 E_ARG, E_NONCAUSAL, E_ZERO_GAIN, E_PARCOR, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 TIME_MAJOR, CHAN_MAJOR = 0, 1
 BANK_DIAGONAL, BANK_OUTER = 0, 1
@@ -60,7 +61,7 @@ SIGNATURES = {
 class TvTap(ctypes.Structure):
   """alz_tv_tap_t (include/alz.h)."""
   _fields_ = [("value", ctypes.c_double), ("series_dev", ctypes.c_void_p),
-              ("stride_n", ctypes.c_int64), ("stride_c", ctypes.c_int64)]
+              ("stride_n", ctypes.c_int64), ("stride_c", ctypes.c_int64), ("flags", ctypes.c_int64)]
 
 
 class ParCorError(ZeroDivisionError):

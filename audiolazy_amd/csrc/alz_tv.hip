@@ -27,6 +27,7 @@ struct TvSide {
   double value[kTvMax];
   const double *series[kTvMax];
   int64_t sn[kTvMax], sc[kTvMax];
+  int negated[kTvMax];            // denominator series already holds -a_k[n]
 };
 
 struct TvArgs {
@@ -86,8 +87,12 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
       for (int u = 0; u < B; ++u) sa[k][u] = 0.0;
       if (a_ser[k]) {
         const double *s = p.a.series[k] + c * p.a.sc[k];
+        const bool neg = p.a.negated[k] != 0;
 #pragma unroll
-        for (int u = 0; u < B; ++u) sa[k][u] = (u < cnt) ? -s[(n0 + u) * p.a.sn[k]] : 0.0;
+        for (int u = 0; u < B; ++u) {
+          const double v = (u < cnt) ? s[(n0 + u) * p.a.sn[k]] : 0.0;
+          sa[k][u] = neg ? v : -v;
+        }
       }
     }
     auto steps = [&](auto div_tag) {
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
 #pragma unroll
   for (int k = 1; k < NA; ++k) m[k] = (k < p.na) ? p.yh[k - 1] : 0.0;
   double cb[NB], nca[NA];
-  unsigned long long b_on[NB], b_ser[NB], a_on[NA], a_ser[NA];   // masks
+  unsigned long long b_on[NB], b_ser[NB], a_on[NA], a_ser[NA], a_neg[NA];   // masks
   // (taps that are not series carry series = x, stride 0 from the host: every fetch below is an
   // unconditional load from a valid address, and no pointer table has to live in registers)
 #pragma unroll
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
     nca[k] = -p.a.value[k];
     a_on[k] = (k > 0 && p.a.kind[k] != 0) ? ~0ull : 0ull;
     a_ser[k] = (k > 0 && p.a.kind[k] == 2) ? ~0ull : 0ull;
+    a_neg[k] = p.a.negated[k] != 0 ? ~0ull : 0ull;
   }
   const bool divide = p.gain_mode == 1;
   const unsigned long long negate = p.gain_mode == 2 ? ~0ull : 0ull, no_terms = p.n_terms == 0 ? ~0ull : 0ull;
@@ -238,7 +244,8 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
       }
 #pragma unroll
       for (int k = 1; k < NA; ++k) {
-        const double coef = pick(a_ser[k], -lane_value(t.sa[k], u), nca[k]);
+        const double sv = lane_value(t.sa[k], u);
+        const double coef = pick(a_ser[k], pick(a_neg[k], sv, -sv), nca[k]);
         acc = pick(a_on[k], acc + coef * m[k], acc);
       }
       if constexpr (DIV) acc = acc / gain;
@@ -309,6 +316,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     const bool as = p.a.kind[k] == 2;
     p.a.value[k] = ta ? ta->value : 0.0; p.a.series[k] = as ? ta->series_dev : x_dev;
     p.a.sn[k] = as ? ta->stride_n : 0; p.a.sc[k] = as ? ta->stride_c : 0;
+    p.a.negated[k] = (as && (ta->flags & ALZ_TV_NEGATED)) ? 1 : 0; p.b.negated[k] = 0;
     p.n_terms += (p.b.kind[k] != 0) + (p.a.kind[k] != 0);
   }
   p.gain = a[0].value;

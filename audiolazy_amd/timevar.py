@@ -51,6 +51,10 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=4096, device=0):
   yh = np.array([float(v) for v in hist] + [0.0] * (1 if na == 1 else 0))
   d_xh = _ffi.DevBuf(xh.nbytes, device).upload(xh)
   d_yh = _ffi.DevBuf(yh.nbytes, device).upload(yh)
+  # With a constant gain the reference negates each denominator coefficient as it is read; done
+  # here, in Python arithmetic, so that integer-valued coefficient streams give the reference's
+  # signed zeros (ALZ_TV_NEGATED).  A series gain makes every coefficient a float product first.
+  pre_negate = a_it[0] is None
   it = iter(seq)
   while True:
     chunk = _pull(it, block)
@@ -63,6 +67,8 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=4096, device=0):
         if src is not None:
           vals = _pull(src, n)
           n = min(n, len(vals))      # a coefficient stream that ends, ends the output
+          if side == "a" and k > 0 and pre_negate:
+            vals = [-v for v in vals]   # ``-next(a_k)`` in Python arithmetic: an int 0 stays 0, not -0.0
           series[(side, k)] = vals
     if n == 0:
       return
@@ -91,9 +97,10 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=4096, device=0):
       arr = (_ffi.TvTap * count)()
       for k in range(count):
         if (side, k) in cols:
-          arr[k] = _ffi.TvTap(0.0, base + keys.index((side, k)) * n * 8, 1, 0)
+          negated = _ffi.TV_NEGATED if (side == "a" and k > 0 and pre_negate) else 0
+          arr[k] = _ffi.TvTap(0.0, base + keys.index((side, k)) * n * 8, 1, 0, negated)
         else:
-          arr[k] = _ffi.TvTap(float(consts[k]), None, 0, 0)
+          arr[k] = _ffi.TvTap(float(consts[k]), None, 0, 0, 0)
       return arr
     tb = taps("b", nb, b)
     ta = taps("a", na, [gain] + list(a[1:]))
@@ -135,13 +142,13 @@ def process_block(b, a, x, xh=None, yh=None, zero=0., layout="time"):
         if v.dim() == 1:
           if v.numel() != n:
             raise ValueError("a shared coefficient series needs one value per sample")
-          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), 1, 0)
+          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), 1, 0, 0)
         elif tuple(v.shape) == tuple(x.shape):
-          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), *((C, 1) if lay == _ffi.TIME_MAJOR else (1, n)))
+          arr[k] = _ffi.TvTap(0.0, v.data_ptr(), *((C, 1) if lay == _ffi.TIME_MAJOR else (1, n)), 0)
         else:
           raise ValueError("a per-channel coefficient series must have the shape of x")
       else:
-        arr[k] = _ffi.TvTap(float(v), None, 0, 0)
+        arr[k] = _ffi.TvTap(float(v), None, 0, 0, 0)
     return arr
   tb, ta = taps(b), taps(a)
   if xh is None:

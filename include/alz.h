@@ -170,7 +170,13 @@ typedef struct alz_tv_tap {
   const double *series_dev; /* coefficient value for sample n at series_dev[n*stride_n + c*stride_c] */
   int64_t stride_n;
   int64_t stride_c;         /* 0: one series shared by every channel */
+  int64_t flags;            /* ALZ_TV_NEGATED: a denominator series that already holds -a_k[n] */
 } alz_tv_tap_t;
+/* The reference negates a denominator coefficient before the product (``-next(a_k) * m_k``).  For
+ * a Python int 0 that is 0, not -0.0, and the sign of a zero product can surface in the output; a
+ * host that wants the reference's result for integer-valued coefficient streams negates them
+ * itself (in Python arithmetic) and sets this flag. */
+#define ALZ_TV_NEGATED 1
 /* LinearFilter.__call__ with Stream coefficients (lazy_filters.py:141-264) on one block of
  * `channels` independent streams: b[0..nb-1], a[0..na-1] (a[0] constant and non-zero: the
  * reference normalises a series a0 away first, :166-174); nb, na <= 17.  xh_dev / yh_dev hold the

@@ -429,6 +429,42 @@ def timevar_cases():
   return out
 
 
+# --------------------------------------------------------------------------
+# 13. time-variant filter *algebra* (the expressions of audiolazy/tests/test_filters.py:349-494):
+#     what the reference's own Poly / ZFilter arithmetic on Stream coefficients produces
+# --------------------------------------------------------------------------
+def timevar_algebra_cases():
+  from audiolazy import cycle, thub
+  alpha = [-.5, -.2, -.1, 0, .1, .2, .5]
+  data = [-7, 3] + list(range(10)) + [-50, 0] + list(range(70, -70, -11))
+  delays = [1, 2, 3, 4]
+  out = []
+  for delay in (2, 3):
+    gain1, gain2 = cycle(alpha), cycle(alpha[-2::-1])
+    gain3, gain4, gain5, gain6 = Stream(1, 2, 3), Stream(.1, .7, -.5, -1e-3), Stream(.1, .2), Stream(3, 2, 1, 0)
+    filt1 = (gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]) / (1 + gain3.copy() * z ** -(delay + 2))
+    filt2 = (gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]) / (1 + gain6.copy() * z ** -(delay - 1))
+    out.append(dict(name="iir_sum", delay=delay, y=hx((filt1 + filt2)(cycle(data)).take(90))))
+  for delay in (1, 4):
+    gain1, gain2 = cycle([4, 5, 6, 5, 4, 3]), cycle(alpha[::-1])
+    gain3, gain4 = Stream(*(alpha + [1, 2, 3])), Stream(.1, -.2, .3)
+    gain5, gain6 = Stream(.1, .1, .1, -7), Stream(3, 2)
+    filt1 = (gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]) / (1 + gain3.copy() * z ** -(delay - 1))
+    filt2 = (gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]) / (1 + gain6.copy() * z ** -(delay + 5))
+    out.append(dict(name="iir_mul", delay=delay, y=hx((filt1 * filt2)(cycle(data)).take(90))))
+  filt1 = (2 + Stream(1, 2, 3) * z ** -1) / Stream(1, 5)
+  out.append(dict(name="copy", delay=0, y=hx(filt1.copy()(cycle(data[::-1])).take(50))))
+  for delay in (1, 3):
+    k = thub(min(alpha) + 2 + cycle(alpha), 3)
+    filt = z ** -2 / k + Stream(5, 7) * z / (1 + z ** -delay)
+    filt += filt.copy()
+    filt *= z ** -1
+    out.append(dict(name="sum_with_copy", delay=delay, y=hx(filt(cycle(data)).take(40))))
+  a = Stream(1, 2, 3)
+  out.append(dict(name="gain_in_denominator", delay=0, y=hx((1 / (a - z ** -1))(cycle(data)).take(50))))
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   dump("filters.json", filt_cases())
@@ -443,3 +479,4 @@ if __name__ == "__main__":
   dump("callers.json", callers_case())
   dump("formats.json", formats_cases())
   dump("timevar.json", timevar_cases())
+  dump("timevar_algebra.json", timevar_algebra_cases())

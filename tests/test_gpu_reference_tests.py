@@ -374,3 +374,44 @@ def test_readme_lpc_example_filters(al):                         # README.rst:36
   assert residual[:10] == [-1.0, 0.0, 0.5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
   synth_filt = 1 / analysis_filt
   assert synth_filt(residual).take(10) == [-1.0, 0.0, 1.0, 0.0, -1.0, 0.0, 1.0, 0.0, -1.0, 0.0]
+
+
+# ------------------------------------------------------------------------------------------
+# The same expressions against what the REFERENCE computes for them (tests/golden/
+# timevar_algebra.json, generated by oracle/gen_golden.py): the Stream-coefficient arithmetic of
+# Poly / ZFilter has to perform the reference's operations in the reference's order.
+def _same_bits(a, b):
+  import numpy as np
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  return a.shape == b.shape and bool(np.all(a.view(np.uint64) == b.view(np.uint64)))
+
+
+def test_time_variant_algebra_matches_the_reference_bit_for_bit(al):
+  from conftest import load_golden, unhex
+  Stream, z, cycle, thub = al.Stream, al.z, al.cycle, al.thub
+  for case in load_golden("timevar_algebra.json"):
+    delay, name = case["delay"], case["name"]
+    if name == "iir_sum":
+      gain1, gain2 = cycle(alpha), cycle(alpha[-2::-1])
+      gain3, gain4, gain5, gain6 = Stream(1, 2, 3), Stream(.1, .7, -.5, -1e-3), Stream(.1, .2), Stream(3, 2, 1, 0)
+      filt1 = (gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]) / (1 + gain3.copy() * z ** -(delay + 2))
+      filt2 = (gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]) / (1 + gain6.copy() * z ** -(delay - 1))
+      got = (filt1 + filt2)(cycle(data)).take(90)
+    elif name == "iir_mul":
+      gain1, gain2 = cycle([4, 5, 6, 5, 4, 3]), cycle(alpha[::-1])
+      gain3, gain4 = Stream(*(alpha + [1, 2, 3])), Stream(.1, -.2, .3)
+      gain5, gain6 = Stream(.1, .1, .1, -7), Stream(3, 2)
+      filt1 = (gain1.copy() * z ** -delay + gain2.copy() * z ** -delays[0]) / (1 + gain3.copy() * z ** -(delay - 1))
+      filt2 = (gain4.copy() * z ** -delay + gain5.copy() * z ** -delays[-1]) / (1 + gain6.copy() * z ** -(delay + 5))
+      got = (filt1 * filt2)(cycle(data)).take(90)
+    elif name == "copy":
+      got = ((2 + Stream(1, 2, 3) * z ** -1) / Stream(1, 5)).copy()(cycle(data[::-1])).take(50)
+    elif name == "sum_with_copy":
+      k = thub(min(alpha) + 2 + cycle(alpha), 3)
+      filt = z ** -2 / k + Stream(5, 7) * z / (1 + z ** -delay)
+      filt += filt.copy()
+      filt *= z ** -1
+      got = filt(cycle(data)).take(40)
+    else:
+      got = (1 / (Stream(1, 2, 3) - z ** -1))(cycle(data)).take(50)
+    assert _same_bits(got, unhex(case["y"])), (name, delay)
