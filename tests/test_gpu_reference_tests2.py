@@ -224,3 +224,34 @@ def test_lpc_kautocor_all_blocks_and_orders(al):                 # test_lpc.py:1
       assert filt.error >= 0.
       assert all(abs(a - b) <= 1e-9 * max(1., abs(b)) for a, b in zip(filt.numlist, coefs))
       assert abs(filt.error - err) <= 1e-9 * max(1., abs(err))
+
+
+# ---------------------------------------------------------------- test_analysis.py:177-207
+amdf_signal = [1.0, 2.0, 3.0, 2.0, 1.0, 2.0, 3.0, 2.0, 1.0]
+
+
+@p(("lag", "size", "expected"), [
+  (1, 1, [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), (2, 1, [1.0, 2.0, 2.0, 0.0, 2.0, 0.0, 2.0, 0.0, 2.0]),
+  (3, 1, [1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), (1, 2, [0.5, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
+  (2, 2, [0.5, 1.5, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), (3, 2, [0.5, 1.5, 2.5, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
+  (1, 4, [0.25, 0.5, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]), (2, 4, [0.25, 0.75, 1.25, 1.25, 1.5, 1.0, 1.0, 1.0, 1.0]),
+  (3, 4, [0.25, 0.75, 1.5, 1.75, 1.75, 1.5, 1.0, 1.0, 1.0])])
+def test_amdf_input_output_mapping(al, lag, size, expected):
+  filt = al.amdf(lag, size)
+  assert callable(filt) and almost_eq(list(filt(amdf_signal)), expected)
+
+
+@p("size", [1, 12])
+def test_amdf_lag_zero(al, size):
+  sig = list(al.white_noise(200))
+  assert list(al.amdf(lag=0, size=size)(sig, zero=0)) == [0 for _ in sig]
+
+
+@p("val", [0, 1, 2, 3., 4.8])
+@p("size", [2, 8, 15, 23])
+def test_maverage_deque_const_input(al, val, size):              # :131-143, the default strategy
+  assert al.maverage.default is al.maverage.deque
+  result = al.maverage(size)(al.Stream(val))
+  assert almost_eq(result.take(size - 1), [val * i / size for i in range(size)][1:])
+  for el in result.take(int(2.5 * size)):
+    assert abs(el - val) <= 2 ** -23 * abs(el + val)
