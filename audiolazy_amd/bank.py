@@ -21,6 +21,21 @@ from . import _ffi
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 
+# Items pulled from the input (and from coefficient Streams) per launch by the filter call
+# protocol.  Large blocks amortise the launch; interactive uses (a ControlStream steering a
+# time-varying filter, audio played as it is made) want a small one: ``block_size(64)``.
+_block = [4096]
+
+
+def block_size(n=None):
+  """Get / set the number of items every ``filt(seq)`` call pulls per GPU launch."""
+  if n is not None:
+    if int(n) < 1:
+      raise ValueError("block size must be positive")
+    _block[0] = int(n)
+  return _block[0]
+
+
 LAYOUTS = {"time": _ffi.TIME_MAJOR, "chan": _ffi.CHAN_MAJOR,
            _ffi.TIME_MAJOR: _ffi.TIME_MAJOR, _ffi.CHAN_MAJOR: _ffi.CHAN_MAJOR}
 
@@ -326,7 +341,7 @@ class FilterBank(object):
       raise ValueError("mixdown sums over the coefficient sets of an OUTER bank")
     return mix_sets(y, self.n_sets, self.n_inputs, layout=layout, out=out, device=self.device)
 
-  def __call__(self, seq, memory=None, zero=0., block=4096):
+  def __call__(self, seq, memory=None, zero=0., block=None):
     """The reference's filter call: any iterable in, a Stream out.
 
     Items of ``seq`` are scalars (one input channel) or rows of ``n_inputs``
@@ -338,6 +353,7 @@ class FilterBank(object):
     from .stream import Stream
     self.reset(memory=memory, zero=zero)
     scalar_out = self.channels == 1
+    block = block_size() if block is None else block
 
     def gen():
       it = iter(seq)

@@ -391,7 +391,7 @@ class ParallelFilter(FilterList):
     if all(isinstance(f, LinearFilter) and f.is_lti() for f in members) and len(args) == 1 \
        and set(kwargs) <= {"memory", "zero", "block"}:
       try:
-        return self._call_bank(seq, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block", 4096))
+        return self._call_bank(seq, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block"))
       except NotImplementedError:   # coefficients outside the engine's gate
         pass
     import itertools
@@ -434,8 +434,9 @@ class ParallelFilter(FilterList):
     ordered sum over the sets on the device (alz_mix_dev)."""
     import itertools
     import numpy as np
-    from .bank import FilterBank, memory_to_hist, sections_of
+    from .bank import FilterBank, memory_to_hist, sections_of, block_size
     from .stream import Stream
+    block = block_size() if block is None else block
     members = self.callables
     for f in members:
       if not f.is_causal():

@@ -206,6 +206,20 @@ class Stream(object):
   __neg__, __pos__, __invert__ = _unary(operator.neg), _unary(operator.pos), _unary(operator.invert)
 
 
+class ControlStream(Stream):
+  """Endless Stream of a control value that can be changed at any time through ``.value``
+  (reference lazy_stream.py:436-462).  Note that the GPU engine pulls its inputs and coefficient
+  streams a block at a time: a change is heard one block later (see ``block_size``)."""
+
+  def __init__(self, value):
+    self.value = value
+
+    def data_generator():
+      while True:
+        yield self.value
+    super(ControlStream, self).__init__(data_generator())
+
+
 class StreamTeeHub(Stream):
   """A Stream that hands out up to ``n`` independent copies of itself, one per use (every
   ``iter()`` -- hence every operator, filter call, ``limit`` / ``skip`` / ``append`` / ``map`` /

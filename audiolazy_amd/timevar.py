@@ -30,13 +30,14 @@ def _pull(it, n):
   return list(itertools.islice(it, n))
 
 
-def run(numlist, denlist, seq, memory=None, zero=0., block=4096, device=0):
+def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
   """Generator of output samples for one input stream.
 
   numlist / denlist : coefficients by delay (constants or iterables), denlist[0] = a0.
   """
-  from .bank import memory_to_hist
+  from .bank import memory_to_hist, block_size
   L = _ffi.load()
+  block = block_size() if block is None else block
   b = list(numlist) or [0.]
   a = list(denlist)
   if not a:

@@ -255,3 +255,23 @@ def test_maverage_deque_const_input(al, val, size):              # :131-143, the
   assert almost_eq(result.take(size - 1), [val * i / size for i in range(size)][1:])
   for el in result.take(int(2.5 * size)):
     assert abs(el - val) <= 2 ** -23 * abs(el + val)
+
+
+def test_control_stream_steers_a_time_varying_filter(al):
+  """examples/formants.py in miniature: a ControlStream behind a resonator frequency; with a small
+  block size the change is heard at the next block (lazy_stream.py:436-462 doctest first)."""
+  cs = al.ControlStream(7)
+  res = al.Stream(1, 3) + cs
+  assert res.take(5) == [8, 10, 8, 10, 8]
+  cs.value = 9
+  assert res.take(5) == [12, 10, 12, 10, 12]
+  old = al.block_size()
+  try:
+    al.block_size(8)
+    gain = al.ControlStream(1.)
+    out = (gain * al.z ** -1)(al.Stream(1.))
+    assert out.take(8) == [0.] + [1.] * 7
+    gain.value = 3.
+    assert out.take(8) == [3.] * 8
+  finally:
+    al.block_size(old)
