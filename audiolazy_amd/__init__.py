@@ -8,8 +8,8 @@ HIP kernels for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design
 and the z**-1 algebra stay on the host in float64.
 """
 from ._ffi import ParCorError, load as load_library, device_count  # noqa: F401
-from .stream import Stream, ControlStream, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
-from .bank import FilterBank, memory_to_hist, sections_of, block_size  # noqa: F401
+from .stream import Stream, ControlStream, Streamix, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
+from .bank import FilterBank, memory_to_hist, sections_of, block_size, mix_tracks, mix_sets  # noqa: F401
 from .poly import Poly, x  # noqa: F401
 from .strategy import StrategyDict  # noqa: F401
 from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, comb, resonator,  # noqa: F401

@@ -132,6 +132,54 @@ def mix_sets(y, n_sets, n_inputs, layout="time", out=None, device=0):
   return res
 
 
+def mix_tracks(tracks, deltas, zero=0., device=0):
+  """Streamix for tracks that are arrays, summed on the GPU (alz_mix_tracks_dev): ``tracks[k]``
+  enters ``deltas[k]`` samples after ``tracks[k-1]`` (Streamix.add's clock, floats allowed) and
+  the tracks playing at a sample are added in the order given, starting from ``zero``.  The
+  result is what ``list(smix)`` gives for ``smix.add(deltas[k], tracks[k])``, bit for bit.
+
+  tracks : 1-D float64 NumPy arrays (returns a NumPy array) or contiguous float64 torch CUDA
+           tensors (returns a CUDA tensor)."""
+  from .stream import _mix_starts
+  L = _ffi.load()
+  starts = _mix_starts(deltas)
+  if len(starts) != len(tracks):
+    raise ValueError("one delta per track")
+  use_torch = len(tracks) > 0 and _is_torch(tracks[0])
+  lengths = [int(t.numel() if use_torch else np.asarray(t).size) for t in tracks]
+  # (an empty track adds nothing to the sum, but the mixer keeps yielding ``zero`` until it starts)
+  n_out = max([s + n for s, n in zip(starts, lengths)] + [0])
+  order = [k for k in range(len(tracks)) if lengths[k] > 0]
+  nt = len(order)
+  c_starts = (ctypes.c_int64 * max(nt, 1))(*[starts[k] for k in order])
+  c_lengths = (ctypes.c_int64 * max(nt, 1))(*[lengths[k] for k in order])
+  ptrs = (ctypes.c_void_p * max(nt, 1))()
+  if use_torch:
+    import torch
+    dev = tracks[0].device
+    for i, k in enumerate(order):
+      t = tracks[k]
+      if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+        raise ValueError("tracks must be contiguous float64 CUDA tensors")
+      ptrs[i] = t.data_ptr()
+    out = torch.empty((n_out,), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _ffi.check(L.alz_mix_tracks_dev(nt, ptrs, c_starts, c_lengths, float(zero), n_out, out.data_ptr(),
+                                    dev.index or 0, ctypes.c_void_p(stream)))
+    return out
+  bufs = []
+  for i, k in enumerate(order):
+    arr = np.ascontiguousarray(tracks[k], dtype=np.float64).reshape(-1)
+    bufs.append(_ffi.DevBuf(arr.nbytes, device).upload(arr))
+    ptrs[i] = bufs[-1].ptr.value
+  if n_out == 0:
+    return np.empty((0,))
+  d_out = _ffi.DevBuf(n_out * 8, device)
+  _ffi.check(L.alz_mix_tracks_dev(nt, ptrs, c_starts, c_lengths, float(zero), n_out, d_out.ptr, device, None))
+  _ffi.check(L.alz_device_sync(device))
+  return d_out.download((n_out,), np.float64)
+
+
 class FilterBank(object):
   """``channels`` independent streams through per-channel cascades.
 

@@ -3,6 +3,8 @@
 //  * k_mix        ParallelFilter.__call__'s sum ((y0 + y1) + y2) ... over the outputs of the
 //                 filters fed with the same input (reference audiolazy/lazy_filters.py:1048-1054),
 //                 taken over the coefficient sets of an OUTER bank's output block.
+//  * k_mix_tracks Streamix (reference audiolazy/lazy_stream.py:633-724): tracks entering at their
+//                 own start samples, summed in the order they were added.
 //  * k_pcm_decode WavStream's sample conversion (reference audiolazy/lazy_wav.py:58-130):
 //                 little-endian 8/16/24/32-bit PCM -> float64, v / 2**(bits-1) (8-bit data is
 //                 unsigned, v - 128), or the stored integer itself with keep.
@@ -44,6 +46,31 @@ __global__ __launch_bounds__(256) void k_mix(MixArgs p) {
   }
   for (; s < p.n_sets; ++s) acc = acc + src[s * p.y_set];
   p.out[outer * p.o_outer + in] = acc;
+}
+
+// Streamix (reference lazy_stream.py:633-724): tracks that start at different samples, summed
+// in the order they were added:  data = zero; for snd in playing: data += next(snd).
+static constexpr int kMixTracks = 24;   // tracks per launch (more: further launches continue the sum)
+
+struct TrackArgs {
+  const double *track[kMixTracks];
+  int64_t start[kMixTracks], length[kMixTracks];
+  int n_tracks, first;      // first launch: the sum starts from `zero`, later ones from out[n]
+  double zero;
+  double *out;
+  int64_t n_out;
+};
+
+__global__ __launch_bounds__(256) void k_mix_tracks(TrackArgs p) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.n_out) return;
+  double acc = p.first ? p.zero : p.out[n];
+#pragma unroll 4
+  for (int k = 0; k < p.n_tracks; ++k) {
+    const int64_t i = n - p.start[k];
+    if (i >= 0 && i < p.length[k]) acc = acc + p.track[k][i];
+  }
+  p.out[n] = acc;
 }
 
 // ---------------------------------------------------------------------------- PCM decode
@@ -196,6 +223,34 @@ int alz_mix_dev(const double *y_dev, int64_t n_sets, int64_t n_inputs, int64_t n
   if (!scope.ok) return alz::fail(ALZ_E_HIP, "hipSetDevice failed");
   const unsigned grid = (unsigned)((p.total + 255) / 256);
   hipLaunchKernelGGL(alz::k_mix, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  ALZ_HIP_CHECK(hipGetLastError());
+  return ALZ_OK;
+}
+
+int alz_mix_tracks_dev(int n_tracks, const double *const *tracks_dev, const int64_t *starts, const int64_t *lengths,
+                       double zero, int64_t n_out, double *out_dev, int device, void *stream) {
+  if (n_tracks < 0 || n_out < 0) return alz::fail(ALZ_E_ARG, "negative count");
+  if (!out_dev || (n_tracks > 0 && (!tracks_dev || !starts || !lengths))) return alz::fail(ALZ_E_ARG, "NULL argument");
+  for (int k = 0; k < n_tracks; ++k)
+    if (!tracks_dev[k] || starts[k] < 0 || lengths[k] < 0) return alz::fail(ALZ_E_ARG, "bad track");
+  if (n_out == 0) return ALZ_OK;
+  alz::DeviceScope scope(device);
+  if (!scope.ok) return alz::fail(ALZ_E_HIP, "hipSetDevice failed");
+  const unsigned grid = (unsigned)((n_out + 255) / 256);
+  int done = 0;
+  do {   // at least one launch: with no track at all the output is `zero` everywhere
+    alz::TrackArgs p;
+    p.n_tracks = (n_tracks - done < alz::kMixTracks) ? n_tracks - done : alz::kMixTracks;
+    for (int k = 0; k < alz::kMixTracks; ++k) {
+      const bool on = k < p.n_tracks;
+      p.track[k] = on ? tracks_dev[done + k] : nullptr;
+      p.start[k] = on ? starts[done + k] : 0;
+      p.length[k] = on ? lengths[done + k] : 0;
+    }
+    p.first = done == 0; p.zero = zero; p.out = out_dev; p.n_out = n_out;
+    hipLaunchKernelGGL(alz::k_mix_tracks, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    done += p.n_tracks;
+  } while (done < n_tracks);
   ALZ_HIP_CHECK(hipGetLastError());
   return ALZ_OK;
 }

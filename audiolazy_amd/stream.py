@@ -220,6 +220,62 @@ class ControlStream(Stream):
     super(ControlStream, self).__init__(data_generator())
 
 
+def _mix_starts(deltas):
+  """Output sample at which each added track starts, by Streamix's clock: a counter that starts
+  at 0.5, gains 1 per output sample and loses the track's delta when the track starts; a track
+  starts as soon as the counter has reached its delta (reference lazy_stream.py:689-697)."""
+  import math
+  starts, count, n = [], 0.5, 0
+  for delta in deltas:
+    if delta < 0:
+      raise ValueError("Delta time should be always positive")
+    wait = max(0, int(math.ceil(delta - count)))
+    n += wait
+    count = count + float(wait) - delta
+    starts.append(n)
+  return starts
+
+
+class Streamix(Stream):
+  """Stream mixer: iterables that enter at their own times, summed sample by sample in the
+  order they were added, ``data = zero; data += next(snd)`` (reference lazy_stream.py:633-724).
+  ``add(delta, data)``: ``delta`` samples (may be float) after the previously added one.
+  ``keep=True`` keeps yielding ``zero`` when nothing is left to play.  For tracks that are
+  arrays, :func:`audiolazy_amd.bank.mix_tracks` does the same sum on the GPU."""
+
+  def __init__(self, keep=False, zero=0.):
+    self._waiting = collections.deque()
+    self._playing = []
+    self.keep = keep
+
+    def data_generator():
+      count = 0.5
+      while True:
+        while self._waiting and count >= self._waiting[0][0]:
+          delta, newdata = self._waiting.popleft()
+          self._playing.append(newdata)
+          count -= delta
+        data = zero
+        finished = []
+        for snd in self._playing:
+          try:
+            data += next(snd)
+          except StopIteration:
+            finished.append(snd)
+        for snd in finished:
+          self._playing.remove(snd)
+        if not (self.keep or self._playing or self._waiting):
+          return
+        yield data
+        count += 1.
+    super(Streamix, self).__init__(data_generator())
+
+  def add(self, delta, data):
+    if delta < 0:
+      raise ValueError("Delta time should be always positive")
+    self._waiting.append((delta, iter(data)))
+
+
 class StreamTeeHub(Stream):
   """A Stream that hands out up to ``n`` independent copies of itself, one per use (every
   ``iter()`` -- hence every operator, filter call, ``limit`` / ``skip`` / ``append`` / ``map`` /

@@ -146,6 +146,14 @@ int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
  * bit-identical to it. */
 int alz_mix_dev(const double *y_dev, int64_t n_sets, int64_t n_inputs, int64_t n, int layout,
                 int64_t ldy, int64_t ldo, double *out_dev, int device, void *stream);
+/* Streamix (lazy_stream.py:633-724) for tracks that are already arrays: track k (device pointer
+ * tracks_dev[k], lengths[k] samples) enters the mix at output sample starts[k];
+ * out[n] = ((zero + t_a[n - s_a]) + t_b[n - s_b]) ... over the tracks playing at n, in the order
+ * given (= the order they were added; the reference sums ``data += next(snd)`` over its playing
+ * list).  tracks_dev / starts / lengths are HOST arrays of n_tracks entries. */
+int alz_mix_tracks_dev(int n_tracks, const double *const *tracks_dev, const int64_t *starts,
+                       const int64_t *lengths, double zero, int64_t n_out, double *out_dev,
+                       int device, void *stream);
 /* WavStream's sample conversion (lazy_wav.py:58-61, 110-128): n_samples little-endian PCM items of
  * 8 (unsigned), 16, 24 or 32 bits, in file order (interleaved channels = a time-major block), to
  * float64: v / 2**(bits-1) with 8-bit data re-centred by -128, or the stored integer when keep != 0.

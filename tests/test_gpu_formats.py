@@ -200,3 +200,25 @@ def test_gammatone_bank_mixdown(al):
   assert same_bits(bank.mixdown(y, layout="chan"), oracle.mix(y, B, S, layout="chan"))
   with pytest.raises(ValueError):
     al.FilterBank([([1.], [1.])], n_inputs=3).mixdown(np.zeros((4, 3)))
+
+
+# ------------------------------------------------------------------------------- Streamix
+def test_mix_tracks_is_streamix(al):
+  """alz_mix_tracks_dev against the host Streamix (same adds, same order): bit for bit, with float
+  deltas, gaps, empty tracks and more tracks than one launch takes."""
+  import torch
+  rng = np.random.default_rng(11)
+  for n_tracks, zero in ((0, 0.), (1, 0.), (3, .25), (7, -1.5), (60, 0.)):
+    tracks = [rng.uniform(-1, 1, int(rng.integers(0, 400))) * 10.0 ** rng.integers(-6, 6) for _ in range(n_tracks)]
+    deltas = [float(rng.choice([0, 0., .4, 1, 2.5, 17, 100.25, 300])) for _ in range(n_tracks)]
+    smix = al.Streamix(zero=zero)
+    for d, t in zip(deltas, tracks):
+      smix.add(d, t.tolist())
+    ref = list(smix)
+    got = al.mix_tracks(tracks, deltas, zero=zero)
+    assert same_bits(got, ref), (n_tracks, zero)
+    if n_tracks:
+      got = al.mix_tracks([torch.from_numpy(t).cuda() for t in tracks], deltas, zero=zero)
+      assert same_bits(got.cpu().numpy(), ref)
+  with pytest.raises(ValueError):
+    al.mix_tracks([np.zeros(3)], [-1])

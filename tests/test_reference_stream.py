@@ -368,3 +368,37 @@ def test_thub_blocks(size, hop):                                 # :564-576
     assert blks.take(inf) == expected
   with pytest.raises(IndexError):
     data.blocks(size=size, hop=hop)
+
+
+# ---------------------------------------------------------------- Streamix (lazy_stream.py:633-724)
+def test_streamix_doctests():
+  from audiolazy_amd import Streamix, sHz
+  smix = Streamix(zero=0)
+  smix.add(0, [-1, 1, 3, 2])
+  smix.add(2, Stream([4, 4, 4]))
+  smix.add(0, tuple([-3, -5, -7, -5, -7, -1]))
+  assert list(smix) == [-1, 1, 4, 1, -3, -5, -7, -1]
+  s, Hz = sHz(10)
+  dur = int(2 * s)
+  sdata = [1 + (-1 - 1) * i / (dur - 1) for i in range(dur)]        # list(line(2 * s, 1, -1, finish=True))
+  smix = Streamix()
+  smix.add(0.0 * s, sdata)
+  smix.add(0.5 * s, sdata)
+  smix.add(1.0 * s, sdata)
+  result = [round(sm, 2) for sm in smix]
+  assert len(result) == 35 and 0.5 * s == 5.0
+  assert result[:7] == [1.0, 0.89, 0.79, 0.68, 0.58, 1.47, 1.26]
+  assert result[10:17] == [0.42, 0.21, 0.0, -0.21, -0.42, 0.37, 0.05] and result[-1] == -1.0
+  with pytest.raises(ValueError):
+    Streamix().add(-1, [1])
+
+
+def test_streamix_keep_and_gaps():
+  from audiolazy_amd import Streamix
+  smix = Streamix(zero=.5)
+  smix.add(0, [1., 2.])
+  smix.add(4, [10.])                       # two samples of silence in between
+  assert list(smix) == [1.5, 2.5, .5, .5, 10.5]
+  smix = Streamix(keep=True)
+  smix.add(1, [3.])
+  assert smix.take(4) == [0., 3., 0., 0.]
