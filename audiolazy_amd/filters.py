@@ -151,7 +151,17 @@ class LinearFilter(object):
     if self.denpoly[0] == 0:
       raise ZeroDivisionError("Invalid filter gain")
     from .bank import FilterBank
-    return FilterBank([(self.numlist or [0.], self.denlist)], n_inputs=1)(seq, memory=memory, zero=zero)
+    # the reference's vector-valued idiom: items that are rows of C values are C parallel streams
+    # through the same filter (``zero`` a row, ``memory`` a list of rows)
+    import itertools
+    it = iter(seq)
+    n_inputs = 1
+    for first in it:
+      if hasattr(first, "__len__"):
+        n_inputs = len(first)
+      it = itertools.chain([first], it)
+      break
+    return FilterBank([(self.numlist or [0.], self.denlist)], n_inputs=n_inputs)(it, memory=memory, zero=zero)
 
 
 class ZFilter(LinearFilter):

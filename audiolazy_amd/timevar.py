@@ -31,7 +31,10 @@ def _pull(it, n):
 
 
 def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
-  """Generator of output samples for one input stream.
+  """Generator of output samples for one input stream -- or, in the reference's vector-valued
+  idiom, for C parallel streams: items of ``seq`` that are rows of C values, ``zero`` a row,
+  ``memory`` a list of rows, and coefficient Streams whose items are numbers (shared by the
+  channels) or rows (one coefficient per channel, e.g. ``repeat(ndarray)``).
 
   numlist / denlist : coefficients by delay (constants or iterables), denlist[0] = a0.
   """
@@ -47,20 +50,27 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
   a_it = [iter(v) if is_series(v) else None for v in a]
   if a_it[0] is None and a[0] == 0:
     raise ZeroDivisionError("Invalid filter gain")
-  hist = memory_to_hist(memory, na - 1, zero)
-  xh = np.full((max(nb - 1, 1),), float(zero))
-  yh = np.array([float(v) for v in hist] + [0.0] * (1 if na == 1 else 0))
-  d_xh = _ffi.DevBuf(xh.nbytes, device).upload(xh)
-  d_yh = _ffi.DevBuf(yh.nbytes, device).upload(yh)
   # With a constant gain the reference negates each denominator coefficient as it is read; done
   # here, in Python arithmetic, so that integer-valued coefficient streams give the reference's
   # signed zeros (ALZ_TV_NEGATED).  A series gain makes every coefficient a float product first.
   pre_negate = a_it[0] is None
   it = iter(seq)
+  rows, C, d_xh, d_yh, zero_row = False, 1, None, None, None
   while True:
     chunk = _pull(it, block)
     if not chunk:
       return
+    if d_xh is None:       # the first item tells scalars from rows
+      rows = hasattr(chunk[0], "__len__")
+      C = len(chunk[0]) if rows else 1
+      zero_row = np.broadcast_to(np.asarray(zero, dtype=np.float64), (C,)).copy()
+      hist = memory_to_hist(memory, na - 1, zero)
+      xh = np.tile(zero_row, (max(nb - 1, 1), 1))
+      yh = np.zeros((max(na - 1, 1), C))
+      for k, item in enumerate(hist):
+        yh[k] = np.broadcast_to(np.asarray(item, dtype=np.float64), (C,))
+      d_xh = _ffi.DevBuf(xh.nbytes, device).upload(xh)
+      d_yh = _ffi.DevBuf(yh.nbytes, device).upload(yh)
     n = len(chunk)
     series = {}
     for side, its in (("b", b_it), ("a", a_it)):
@@ -73,33 +83,36 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
           series[(side, k)] = vals
     if n == 0:
       return
-    x = np.asarray(chunk[:n], dtype=np.float64)
-    cols = {key: np.asarray(vals[:n], dtype=np.float64) for key, vals in series.items()}
+    x = np.ascontiguousarray(np.asarray(chunk[:n], dtype=np.float64).reshape(n, C))
+    cols = {key: np.asarray(vals[:n], dtype=np.float64).reshape(n, -1) for key, vals in series.items()}
     gain = a[0]
     if ("a", 0) in cols:             # series a0: every other coefficient times 1 / a0 (:166-174)
       inv = 1.0 / cols.pop(("a", 0))
       for k in range(nb):
         if ("b", k) in cols:
           cols[("b", k)] = cols[("b", k)] * inv
-        elif b[k] != 0:
-          cols[("b", k)] = float(b[k]) * inv
+        elif np.any(np.asarray(b[k]) != 0):
+          cols[("b", k)] = np.asarray(b[k], dtype=np.float64) * inv
       for k in range(1, na):
         if ("a", k) in cols:
           cols[("a", k)] = cols[("a", k)] * inv
-        elif a[k] != 0:
-          cols[("a", k)] = float(a[k]) * inv
+        elif np.any(np.asarray(a[k]) != 0):
+          cols[("a", k)] = np.asarray(a[k], dtype=np.float64) * inv
       gain = 1.0
-    keys = sorted(cols)
-    packed = np.ascontiguousarray(np.stack([cols[k] for k in keys])) if keys else np.zeros((1, n))
-    d_coef = _ffi.DevBuf(packed.nbytes, device).upload(packed)
-    base = d_coef.ptr.value
+    bufs = {}
+    for key, arr in cols.items():
+      if arr.shape[1] not in (1, C):
+        raise ValueError("a coefficient row has %d values for %d channels" % (arr.shape[1], C))
+      arr = np.ascontiguousarray(arr)
+      bufs[key] = (_ffi.DevBuf(arr.nbytes, device).upload(arr), arr.shape[1])
 
     def taps(side, count, consts):
       arr = (_ffi.TvTap * count)()
       for k in range(count):
-        if (side, k) in cols:
+        if (side, k) in bufs:
+          buf, width = bufs[(side, k)]
           negated = _ffi.TV_NEGATED if (side == "a" and k > 0 and pre_negate) else 0
-          arr[k] = _ffi.TvTap(0.0, base + keys.index((side, k)) * n * 8, 1, 0, negated)
+          arr[k] = _ffi.TvTap(0.0, buf.ptr.value, width, 1 if (width == C and C > 1) else 0, negated)
         else:
           arr[k] = _ffi.TvTap(float(consts[k]), None, 0, 0, 0)
       return arr
@@ -107,12 +120,16 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
     ta = taps("a", na, [gain] + list(a[1:]))
     d_x = _ffi.DevBuf(x.nbytes, device).upload(x)
     d_y = _ffi.DevBuf(x.nbytes, device)
-    _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), 1,
-                                    d_x.ptr, d_y.ptr, n, _ffi.TIME_MAJOR, 1, 1, d_xh.ptr, d_yh.ptr,
-                                    float(zero), device, None))
+    _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), C,
+                                    d_x.ptr, d_y.ptr, n, _ffi.TIME_MAJOR, C, C, d_xh.ptr, d_yh.ptr,
+                                    float(zero_row[0]), device, None))
     _ffi.check(L.alz_device_sync(device))
-    for v in d_y.download((n,), np.float64).tolist():
-      yield v
+    y = d_y.download((n, C), np.float64)
+    if rows:
+      for row in y:
+        yield row
+    else:
+      yield from y[:, 0].tolist()
     if n < len(chunk):
       return
 

@@ -203,3 +203,26 @@ def test_envelope_and_maverage_callers(al):
       assert same_bits(filt.numlist, unhex(c["b"])) and same_bits(filt.denlist, unhex(c["a"]))
       y = list(filt(x))
     assert same_bits(y, unhex(c["y"])), (c["fn"], c["strategy"], c["arg"])
+
+
+def test_vector_valued_samples_like_the_reference(al):
+  """tests/golden/multichannel.json was produced with the reference's own multichannel idiom
+  (test_filters_extdep.py:49-89): rows as samples, ``zero`` a row, per-channel coefficients as
+  ``repeat(ndarray)`` Streams.  The same expression here, bit for bit; and rows through one
+  shared LTI filter equal the per-channel scalar runs."""
+  mc = load_golden("multichannel.json")
+  z, repeat = al.z, al.repeat
+  C = mc["C"]
+  b = np.array([unhex(r) for r in mc["b"]])
+  a = np.array([unhex(r) for r in mc["a"]])
+  x = np.array([unhex(r) for r in mc["x"]])
+  want = np.array([unhex(r) for r in mc["y"]])
+  num = sum(repeat(b[:, k].copy()) * z ** -k for k in range(3) if np.any(b[:, k] != 0))
+  den = 1 + sum(repeat(a[:, k].copy()) * z ** -k for k in (1, 2))
+  got = np.array(list((num / den)(iter(x), zero=np.zeros(C))))
+  assert same_bits(got, want)
+  s, Hz = al.sHz(48000)
+  filt = al.resonator.z_exp(1000 * Hz, 100 * Hz)
+  rows = np.array(list(filt(iter(x), zero=np.full(C, .125), memory=[np.arange(C) * .01, .5])))
+  for c in range(C):
+    assert same_bits(rows[:, c], list(filt(list(x[:, c]), zero=.125, memory=[c * .01, .5]))), c
