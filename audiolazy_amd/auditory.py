@@ -86,11 +86,12 @@ def gammatone(freq, bandwidth):
 
 
 @gammatone.strategy("klapuri")
-@_accepts_streams
 def gammatone(freq, bandwidth):
   """Klapuri's cascade: resonator.z_exp, resonator.poles_exp, twice, at twice the
-  bandwidth (reference :208-218)."""
-  bw2 = bandwidth * 2
+  bandwidth (reference :208-218).  Numbers or Streams (the resonators take both)."""
+  from .stream import thub
+  bw2 = thub(thub(bandwidth, 1) * 2, 4)
+  freq = thub(freq, 4)
   return CascadeFilter(reson(freq, bw2) for reson in [resonator.z_exp, resonator.poles_exp] * 2)
 
 

@@ -536,46 +536,65 @@ def comb(delay, alpha=1):
   return 1 + alpha * z ** -delay
 
 
+# The designs below are written once for numbers and for Streams, like the reference's: the
+# elementwise math helpers map over an iterable argument and ``thub`` lets a Stream-valued
+# intermediate appear several times (its second argument = how many).  With Stream arguments the
+# coefficients come out as Streams (a time-varying filter) built by cheap generator arithmetic --
+# the same float operations, in the same order, as the scalar case.
+def _elementwise(fn):
+  def mapped(value):
+    if hasattr(value, "__iter__"):
+      from .stream import Stream
+      return Stream(map(fn, iter(value)))
+    return fn(value)
+  return mapped
+
+
+_exp, _cos, _sin, _sqrt = (_elementwise(f) for f in (math.exp, math.cos, math.sin, math.sqrt))
+
+
+def _thub(value, uses):
+  from .stream import thub
+  return thub(value, uses)
+
+
 resonator = StrategyDict("resonator")
 
 
 @resonator.strategy("poles_exp")
-@_accepts_streams
 def resonator(freq, bandwidth):
   """Two-pole resonator, 0 dB peak at the resonance (reference :1179-1209).
   ``freq`` and ``bandwidth`` in rad/sample; pole radius R = exp(-bandwidth / 2)."""
-  R = math.exp(-bandwidth * .5)
-  cost = math.cos(freq) * (2 * R) / (1 + R ** 2)
-  gain = (1 - R ** 2) * math.sqrt(1 - cost ** 2)
+  R = _thub(_exp(-_thub(bandwidth, 1) * .5), 5)
+  cost = _thub(_cos(freq) * (2 * R) / (1 + R ** 2), 2)
+  gain = (1 - R ** 2) * _sqrt(1 - cost ** 2)
   return gain / (1 - 2 * R * cost * z ** -1 + R ** 2 * z ** -2)
 
 
 @resonator.strategy("freq_poles_exp")
-@_accepts_streams
 def resonator(freq, bandwidth):
   """Two-pole resonator with the poles exactly at ``freq`` (reference :1212-1242)."""
-  R = math.exp(-bandwidth * .5)
-  gain = (1 - R ** 2) * math.sin(freq)
-  return gain / (1 - 2 * R * math.cos(freq) * z ** -1 + R ** 2 * z ** -2)
+  R = _thub(_exp(-_thub(bandwidth, 1) * .5), 3)
+  freq = _thub(freq, 2)
+  gain = (1 - R ** 2) * _sin(freq)
+  return gain / (1 - 2 * R * _cos(freq) * z ** -1 + R ** 2 * z ** -2)
 
 
 @resonator.strategy("z_exp")
-@_accepts_streams
 def resonator(freq, bandwidth):
   """Two poles plus zeros at DC and Nyquist, 0 dB at ``freq`` (reference :1245-1276)."""
-  R = math.exp(-bandwidth * .5)
-  cost = math.cos(freq) * (1 + R ** 2) / (2 * R)
+  R = _thub(_exp(-_thub(bandwidth, 1) * .5), 5)
+  cost = _cos(freq) * (1 + R ** 2) / (2 * R)
   gain = (1 - R ** 2) * .5
   return gain * (1 - z ** -2) / (1 - 2 * R * cost * z ** -1 + R ** 2 * z ** -2)
 
 
 @resonator.strategy("freq_z_exp")
-@_accepts_streams
 def resonator(freq, bandwidth):
   """As ``z_exp`` with the poles exactly at ``freq`` (reference :1279-1310)."""
-  R = math.exp(-bandwidth * .5)
+  R = _thub(_exp(-_thub(bandwidth, 1) * .5), 3)
   gain = (1 - R ** 2) * .5
-  return gain * (1 - z ** -2) / (1 - 2 * R * math.cos(freq) * z ** -1 + R ** 2 * z ** -2)
+  return gain * (1 - z ** -2) / (1 - 2 * R * _cos(freq) * z ** -1 + R ** 2 * z ** -2)
 
 
 lowpass = StrategyDict("lowpass")
@@ -583,78 +602,78 @@ highpass = StrategyDict("highpass")
 
 
 def _one_pole_radius(x):
-  return x - math.sqrt(x ** 2 - 1)
+  x = _thub(x, 2)
+  return _thub(x - _sqrt(x ** 2 - 1), 2)
 
 
 @lowpass.strategy("pole")
-@_accepts_streams
 def lowpass(cutoff):
   """One pole, exact -3 dB at ``cutoff`` rad/sample (reference :1370-1378)."""
-  R = _one_pole_radius(2 - math.cos(cutoff))
+  R = _one_pole_radius(2 - _cos(cutoff))
   return (1 - R) / (1 - R * z ** -1)
 
 
 @highpass.strategy("pole")
-@_accepts_streams
 def highpass(cutoff):
   """One pole highpass, mirror of lowpass.pole (reference :1381-1389)."""
-  R = _one_pole_radius(2 + math.cos(cutoff))
+  R = _one_pole_radius(2 + _cos(cutoff))
   return (1 - R) / (1 + R * z ** -1)
 
 
 def _pole_zero_radius(num, cutoff):
-  den = math.cos(cutoff)
-  return num / (den if den else 1)   # numerator already zero there (reference :1399-1403)
+  den = _cos(cutoff)
+  if hasattr(den, "__iter__"):
+    from .stream import Stream
+    den = Stream((el if el else 1) for el in den)
+  else:
+    den = den if den else 1      # numerator already zero there (reference :1399-1403)
+  return _thub(num / den, 2)
 
 
 @lowpass.strategy("z")
-@_accepts_streams
 def lowpass(cutoff):
   """One pole and a zero at Nyquist (reference :1392-1405)."""
-  R = _pole_zero_radius(math.sin(cutoff) - 1, cutoff)
+  cutoff = _thub(cutoff, 2)
+  R = _pole_zero_radius(_sin(cutoff) - 1, cutoff)
   gain = (1 + R) / 2
   return gain * (1 + z ** -1) / (1 + R * z ** -1)
 
 
 @highpass.strategy("z")
-@_accepts_streams
 def highpass(cutoff):
   """One pole and a zero at DC (reference :1408-1421)."""
-  R = _pole_zero_radius(1 - math.sin(cutoff), cutoff)
+  cutoff = _thub(cutoff, 2)
+  R = _pole_zero_radius(1 - _sin(cutoff), cutoff)
   gain = (1 + R) / 2
   return gain * (1 - z ** -1) / (1 - R * z ** -1)
 
 
 @lowpass.strategy("pole_exp")
-@_accepts_streams
 def lowpass(cutoff):
   """Matched-Z one pole, R = e ** -cutoff (reference :1424-1437)."""
-  R = math.exp(-cutoff)
+  R = _thub(_exp(-_thub(cutoff, 1)), 2)
   return (1 - R) / (1 - R * z ** -1)
 
 
 @highpass.strategy("pole_exp")
-@_accepts_streams
 def highpass(cutoff):
   """Matched-Z one pole highpass, R = e ** (cutoff - pi) (reference :1440-1454)."""
-  R = math.exp(cutoff - math.pi)
+  R = _thub(_exp(_thub(cutoff, 1) - math.pi), 2)
   return (1 - R) / (1 + R * z ** -1)
 
 
 @lowpass.strategy("z_exp")
-@_accepts_streams
 def lowpass(cutoff):
   """Matched-Z pole plus zero at Nyquist (reference :1457-1472)."""
-  R = math.exp(cutoff - math.pi)
+  R = _thub(_exp(_thub(cutoff, 1) - math.pi), 2)
   G = (R + 1) / 2
   return G * (1 + z ** -1) / (1 + R * z ** -1)
 
 
 @highpass.strategy("z_exp")
-@_accepts_streams
 def highpass(cutoff):
   """Matched-Z pole plus zero at DC (reference :1475-1490)."""
-  R = math.exp(-cutoff)
+  R = _thub(_exp(-_thub(cutoff, 1)), 2)
   G = (R + 1) / 2
   return G * (1 - z ** -1) / (1 - R * z ** -1)
 

@@ -30,6 +30,20 @@ def _pull(it, n):
   return list(itertools.islice(it, n))
 
 
+class _Pool(object):
+  """Device buffers kept from block to block (a hipMalloc per block and series would dominate
+  small blocks): ``get(name, nbytes)`` returns a buffer of at least that size."""
+
+  def __init__(self, device):
+    self.device, self._bufs = device, {}
+
+  def get(self, name, nbytes):
+    buf = self._bufs.get(name)
+    if buf is None or buf.nbytes < nbytes:
+      buf = self._bufs[name] = _ffi.DevBuf(max(nbytes, 4096), self.device)
+    return buf
+
+
 def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
   """Generator of output samples for one input stream -- or, in the reference's vector-valued
   idiom, for C parallel streams: items of ``seq`` that are rows of C values, ``zero`` a row,
@@ -54,6 +68,7 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
   # here, in Python arithmetic, so that integer-valued coefficient streams give the reference's
   # signed zeros (ALZ_TV_NEGATED).  A series gain makes every coefficient a float product first.
   pre_negate = a_it[0] is None
+  pool = _Pool(device)
   it = iter(seq)
   rows, C, d_xh, d_yh, zero_row = False, 1, None, None, None
   while True:
@@ -104,7 +119,7 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
       if arr.shape[1] not in (1, C):
         raise ValueError("a coefficient row has %d values for %d channels" % (arr.shape[1], C))
       arr = np.ascontiguousarray(arr)
-      bufs[key] = (_ffi.DevBuf(arr.nbytes, device).upload(arr), arr.shape[1])
+      bufs[key] = (pool.get(key, arr.nbytes).upload(arr), arr.shape[1])
 
     def taps(side, count, consts):
       arr = (_ffi.TvTap * count)()
@@ -118,8 +133,8 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
       return arr
     tb = taps("b", nb, b)
     ta = taps("a", na, [gain] + list(a[1:]))
-    d_x = _ffi.DevBuf(x.nbytes, device).upload(x)
-    d_y = _ffi.DevBuf(x.nbytes, device)
+    d_x = pool.get("x", x.nbytes).upload(x)
+    d_y = pool.get("y", x.nbytes)
     _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), C,
                                     d_x.ptr, d_y.ptr, n, _ffi.TIME_MAJOR, C, C, d_xh.ptr, d_yh.ptr,
                                     float(zero_row[0]), device, None))
