@@ -22,9 +22,15 @@
 
 namespace alz {
 
-static constexpr int kFirR = 32;   // outputs per lane held in registers
-static constexpr int kFirK = 16;   // taps per block
-static constexpr int kFirTB = 256; // output rows per wave
+#ifndef ALZ_FIR_R
+#define ALZ_FIR_R 32
+#endif
+#ifndef ALZ_FIR_K
+#define ALZ_FIR_K 16
+#endif
+static constexpr int kFirR = ALZ_FIR_R;   // outputs per lane held in registers
+static constexpr int kFirK = ALZ_FIR_K;   // taps per block
+static constexpr int kFirTB = 8 * kFirR; // output rows per wave
 
 struct FArgs {
   const double *x;
