@@ -1,11 +1,12 @@
 """audiolazy_amd -- an MI355X-native blocked stream-filter engine behind
 AudioLazy's ZFilter / Stream operator surface.
 
-Only the hot path of the reference is here: linear filter
-execution (LinearFilter/ZFilter.__call__, CascadeFilter, resonator/comb,
-lowpass/highpass, the gammatone bank) and lpc.kautocor, executed by hand-written
-HIP kernels for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design
-and the z**-1 algebra stay on the host in float64.
+Only the hot path of the reference is here: linear filter execution
+(LinearFilter/ZFilter.__call__ incl. Stream-valued coefficients, CascadeFilter, ParallelFilter,
+resonator/comb, lowpass/highpass, the gammatone bank), lpc.kautocor, and the pieces either side
+of it (WavStream / chunks sample formats, Streamix mixing), executed by hand-written HIP kernels
+for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design, the z**-1 algebra and the lazy
+Stream type stay on the host in float64 and follow the reference's semantics.
 """
 from ._ffi import ParCorError, load as load_library, device_count  # noqa: F401
 from .stream import Stream, ControlStream, Streamix, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
