@@ -354,8 +354,14 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   char *xring = smem;
+  // p and y rings are written and read only by this kernel's own lanes, so their layout is free:
+  // channel-major keeps 16 bytes after EVERY channel (a half-wave -- 16 channels x 2 lane groups --
+  // then touches 32 distinct bank pairs; a pad per two channels, as the DMA layout of the x ring
+  // has it, made every access 2-way conflicted)
+  constexpr int kChanPitch = 64 * 8 + 16;                      // bytes per channel row in the p / y rings (CM)
+  constexpr int kPYSlot = CM ? 16 * kChanPitch : kDuoSlot;
   char *pring = smem + kXRing * kDuoSlot;
-  char *yring = pring + kPRing * kDuoSlot;
+  char *yring = pring + kPRing * kPYSlot;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   // x ring (DMA target): byte offset of element (u, cl) = lane_off + ALZ_EOFF(u), 16-byte pad
   // after every 1 KiB chunk.  p and y rings: TIME rows are unpadded (row u at u*128), CHAN rows
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
   constexpr int kStep = CM ? 8 : G * 8;               // bytes from sample u to u+1 in the p/y rings
   constexpr int kOutChunk = CM ? kChunkLds : 1024;         // bytes per 1 KiB store chunk in the y ring
-  const int lane_off_p = CM ? cl * T * 8 + ((cl * T) >> 7) * kPad : cl * 8;
+  const int lane_off_p = CM ? cl * kChanPitch : cl * 8;
 
   if (wave == 1) {
     // ------------------------------ AUX ------------------------------
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     auto feed_forward = [&](int64_t t) {
       const char *xs = xring + (int)(t % kXRing) * kDuoSlot + lane_off;
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kDuoSlot + lane_off;  // tile t-1
-      char *ps = pring + (int)(t % kPRing) * kDuoSlot + lane_off_p;
+      char *ps = pring + (int)(t % kPRing) * kPYSlot + lane_off_p;
       auto xat = [&](int u) -> double {       // x[u] of this tile; u = -1, -2 reach into tile t-1
         return *reinterpret_cast<const double *>(xs + ALZ_EOFF(u));
       };
@@ -462,11 +468,13 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       }
     };
     auto store_tile = [&](int64_t t) {
-      const char *ys = yring + (int)(t % kYRing) * kDuoSlot;
+      const char *ys = yring + (int)(t % kYRing) * kPYSlot;
       double *yt = yg + t * y_tile;
       dbl2 v[kChunks];
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * kOutChunk + lane * 16);
+      for (int j = 0; j < kChunks; ++j)
+        v[j] = *reinterpret_cast<const dbl2 *>(ys + (CM ? (2 * j + lane / 32) * kChanPitch + (lane % 32) * 16
+                                                          : j * kOutChunk + lane * 16));
 #pragma unroll
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
@@ -514,9 +522,9 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     int ps_cur = 0, ps_prv = kPRing - 1, ys_cur = 0;         // ring slots of tile i, rotated by hand
     for (int64_t i = 0; i < nt; ++i) {
       // this lane reads sample (u - q) of the tile; u - q < 0 lives in the previous tile's slot
-      const char *cur = pring + ps_cur * kDuoSlot + lane_off_p - q * kStep;
-      const char *prv = pring + ps_prv * kDuoSlot + lane_off_p + (T - q) * kStep;
-      char *wr = yring + ys_cur * kDuoSlot + lane_off_p - q * kStep;
+      const char *cur = pring + ps_cur * kPYSlot + lane_off_p - q * kStep;
+      const char *prv = pring + ps_prv * kPYSlot + lane_off_p + (T - q) * kStep;
+      char *wr = yring + ys_cur * kPYSlot + lane_off_p - q * kStep;
       ps_prv = ps_cur;
       ps_cur = (ps_cur + 1 == kPRing) ? 0 : ps_cur + 1;
       ys_cur = (ys_cur + 1 == kYRing) ? 0 : ys_cur + 1;
@@ -676,7 +684,8 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
-  size_t lds = duo ? (size_t)(kXRing + kPRing + kYRing) * kDuoSlot : (size_t)kRing * kSlotBytes;
+  size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
+                   : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
   static bool attr_set[5][2][64] = {};
   const int gi = duo ? (io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
