@@ -20,6 +20,7 @@ from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # n
 from .synth import white_noise, zeros, zeroes, ones, karplus_strong  # noqa: F401
 from .analysis import envelope, maverage, amdf  # noqa: F401
 from .pcm import WavStream, chunks, decode_pcm, encode_pcm  # noqa: F401
+from .misc import dB10, dB20, freq2lag, lag2freq, almost_eq, line  # noqa: F401
 
 
 def sHz(rate):

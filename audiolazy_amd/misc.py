@@ -1,0 +1,82 @@
+"""Small helpers the reference's filter examples and tests lean on (host side, a few lines each):
+``dB10`` / ``dB20`` (reference audiolazy/lazy_math.py:112-125), ``freq2lag`` / ``lag2freq``
+(lazy_misc.py:323-331), ``almost_eq`` (lazy_misc.py:232-296) and ``line`` (lazy_synth.py:143-180).
+"""
+import math
+
+from .stream import Stream, rint
+
+
+def _elementwise(fn):
+  def mapped(data):
+    if hasattr(data, "__iter__"):
+      out = (fn(v) for v in data)
+      return Stream(out) if isinstance(data, Stream) else type(data)(out)
+    return fn(data)
+  mapped.__name__ = fn.__name__
+  mapped.__doc__ = fn.__doc__
+  return mapped
+
+
+@_elementwise
+def dB10(data):
+  """Power ratio (a squared amplitude) in dB; -inf for zero."""
+  return 10 * math.log10(abs(data)) if data != 0 else -float("inf")
+
+
+@_elementwise
+def dB20(data):
+  """Amplitude ratio in dB; -inf for zero."""
+  return 20 * math.log10(abs(data)) if data != 0 else -float("inf")
+
+
+def freq2lag(v):
+  """Frequency in rad/sample -> period in samples (and back: the map is its own inverse)."""
+  return 2 * math.pi / v
+
+
+lag2freq = freq2lag
+
+
+def _pairs(a, b, pad):
+  import itertools
+  return itertools.zip_longest(a, b, fillvalue=pad)
+
+
+def almost_eq(a, b, bits=32, tol=1, ignore_type=True, pad=0.):
+  """``a == b`` up to the last ``tol`` bits of a ``bits``-wide float's significand, item by item
+  through nested iterables (the reference's default comparison helper)."""
+  if not (ignore_type or type(a) == type(b)):
+    return False
+  it_a, it_b = hasattr(a, "__iter__"), hasattr(b, "__iter__")
+  if it_a != it_b:
+    return False
+  if it_a:
+    return all(almost_eq(x, y, bits, tol, ignore_type) for x, y in _pairs(a, b, pad))
+  significand = {32: 23, 64: 52, 80: 63, 128: 112}[bits]
+  return abs(a - b) <= 2 ** (tol - significand - 1) * abs(a + b)
+
+
+def _almost_eq_diff(a, b, max_diff=1e-7, ignore_type=True, pad=0.):
+  if not (ignore_type or type(a) == type(b)):
+    return False
+  it_a, it_b = hasattr(a, "__iter__"), hasattr(b, "__iter__")
+  if it_a != it_b:
+    return False
+  if it_a:
+    return all(_almost_eq_diff(x, y, max_diff, ignore_type) for x, y in _pairs(a, b, pad))
+  return abs(a - b) <= max_diff
+
+
+almost_eq.bits = almost_eq
+almost_eq.diff = _almost_eq_diff
+
+
+def line(dur, begin=0., end=1., finish=False):
+  """Finite Stream of ``dur`` samples on the straight line from ``begin`` towards ``end``;
+  ``end`` itself is the last sample only with ``finish=True``."""
+  def gen():
+    m = (end - begin) / (dur - (1. if finish else 0.))
+    for sample in range(rint(dur)):
+      yield begin + sample * m
+  return Stream(gen())
