@@ -341,7 +341,10 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // FMA = true is the opt-in fused mode (alz_bank_set_fused): v_fma_f64 instead of separately rounded
 // mul + add -- half the recurrence chain, NOT bit-identical to the reference (differences at the
 // 1e-13 level, far inside the 1e-6 contract).
-template <bool CM, unsigned PB, unsigned PA, bool FMA>
+// DIV = true divides the finished sum by a0 (``(...) / gain``, lazy_filters.py:236-240): the banks
+// whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
+// it has its own instantiation.
+template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false>
 __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
@@ -515,7 +518,9 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
     double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
     double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
-    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2));
+    double a0 = 1.0;
+    if constexpr (DIV) a0 = p.a[0 * p.n_sets + set];
+    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2), "+v"(a0));
     double t2 = na2 * m2;                                    // (-a2) * y[n-2] for the next step
     __builtin_amdgcn_s_barrier();                            // p of tile 0 is ready
     constexpr int NCH = T / 8;
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
             if constexpr (PA & 1u) acc = acc + na1 * m1;
             if constexpr (PA & 2u) acc = acc + na2 * m2;
           }
+          if constexpr (DIV) acc = acc / a0;                  // (the carried product used the old y[n-1])
           if (k == 0 && u < 3 && i == 0) {
             // start of the stream: group q has nothing to do before step q; hold its state
             const bool on = u >= q;
@@ -609,10 +615,10 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   return nullptr;
 }
 
-template <bool CM, bool FMA>
+template <bool CM, bool FMA, bool DIV = false>
 static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
@@ -632,7 +638,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
                 int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
   *done_samples = 0;
   *done_channels = 0;
-  if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform && !sec.any_div)) return ALZ_OK;
+  if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform)) return ALZ_OK;
   const bool cm = io.sxn == 1 && io.syn == 1 && !(io.sxc == 1 && io.syc == 1);
   const bool tm = io.sxc == 1 && io.syc == 1;
   if (!cm && !tm) return ALZ_OK;
@@ -648,6 +654,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   if (io.channels < 48 * 256) g = 16;
   static const int g_env = getenv("ALZ_G") ? atoi(getenv("ALZ_G")) : 0;   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
+  if (sec.any_div) g = 16;      // a0 != 1 somewhere: only the two-wave kernel has the dividing form
   const bool outer = io.mode == ALZ_BANK_OUTER;
   if (outer) {
     // a wave's channels must be adjacent inputs of ONE coefficient set; later cascade sections of
@@ -662,7 +669,11 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
   wave_fn duo = nullptr;
-  if (g == 16 && duo_env) {
+  if (g == 16 && sec.any_div) {
+    duo = cm ? pick_duo_pattern<true, false, true>(sec.present_b, sec.present_a)
+             : pick_duo_pattern<false, false, true>(sec.present_b, sec.present_a);
+    if (!duo) return ALZ_OK;
+  } else if (g == 16 && duo_env) {
     if (io.fused)
       duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
@@ -687,8 +698,8 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
                    : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
-  static bool attr_set[5][2][64] = {};
-  const int gi = duo ? (io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
+  static bool attr_set[6][2][64] = {};
+  const int gi = duo ? (sec.any_div ? 5 : io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
   const unsigned key = (sec.present_b << 2 | sec.present_a) & 63;
   if (!attr_set[gi][cm][key]) {
     ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -699,7 +710,7 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
   *done_channels = groups * g;
-  *kernel_name = duo ? (io.fused ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  *kernel_name = duo ? (sec.any_div ? "k_duo<16,div>" : io.fused ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
   return ALZ_OK;
 }
 

@@ -504,3 +504,24 @@ def test_fir_channel_major_per_channel_taps_long_block(alz, oracle):
   ref = oracle.bank([nb], [1], b, a, x, layout="chan", xh=np.full((C, nb - 1), 0.5), zero=0.5)
   assert same_bits(y, ref)
   assert np.all(y[3] == 0.5)
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_streaming_with_gain_division(alz, oracle, layout):
+  """a0 != 1 on a biquad bank large enough for the streaming kernel: (sum) / a0 per sample
+  (lazy_filters.py:236-240), bit-exact, including a0 == -1, a0 == 1 rows and block splits."""
+  rng = np.random.default_rng(31)
+  C, N = 256, 1000
+  b = rng.uniform(-1, 1, (C, 3))
+  a = rng.uniform(-.45, .45, (C, 3))
+  a[:, 0] = rng.choice([2., .5, -1., 1., 3.7], C)
+  x = rng.uniform(-1, 1, (N, C) if layout == "time" else (C, N))
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset(zero=.125)
+  cut = 448
+  parts = [bank.process(np.ascontiguousarray(x[:cut] if layout == "time" else x[:, :cut]), layout=layout)]
+  assert "k_duo<16,div>" in bank.last_kernel
+  parts.append(bank.process(np.ascontiguousarray(x[cut:] if layout == "time" else x[:, cut:]), layout=layout))
+  got = np.concatenate(parts, axis=0 if layout == "time" else 1)
+  ref = oracle.bank([3], [3], b, a, x, layout=layout, zero=.125)
+  assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
