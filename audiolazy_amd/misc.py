@@ -5,6 +5,7 @@
 import math
 
 from .stream import Stream, rint
+from .strategy import StrategyDict
 
 
 def _elementwise(fn):
@@ -43,6 +44,10 @@ def _pairs(a, b, pad):
   return itertools.zip_longest(a, b, fillvalue=pad)
 
 
+almost_eq = StrategyDict("almost_eq")
+
+
+@almost_eq.strategy("bits")
 def almost_eq(a, b, bits=32, tol=1, ignore_type=True, pad=0.):
   """``a == b`` up to the last ``tol`` bits of a ``bits``-wide float's significand, item by item
   through nested iterables (the reference's default comparison helper)."""
@@ -52,24 +57,22 @@ def almost_eq(a, b, bits=32, tol=1, ignore_type=True, pad=0.):
   if it_a != it_b:
     return False
   if it_a:
-    return all(almost_eq(x, y, bits, tol, ignore_type) for x, y in _pairs(a, b, pad))
+    return all(almost_eq.bits(x, y, bits, tol, ignore_type) for x, y in _pairs(a, b, pad))
   significand = {32: 23, 64: 52, 80: 63, 128: 112}[bits]
   return abs(a - b) <= 2 ** (tol - significand - 1) * abs(a + b)
 
 
-def _almost_eq_diff(a, b, max_diff=1e-7, ignore_type=True, pad=0.):
+@almost_eq.strategy("diff")
+def almost_eq(a, b, max_diff=1e-7, ignore_type=True, pad=0.):
+  """``|a - b| <= max_diff`` item by item through nested iterables."""
   if not (ignore_type or type(a) == type(b)):
     return False
   it_a, it_b = hasattr(a, "__iter__"), hasattr(b, "__iter__")
   if it_a != it_b:
     return False
   if it_a:
-    return all(_almost_eq_diff(x, y, max_diff, ignore_type) for x, y in _pairs(a, b, pad))
+    return all(almost_eq.diff(x, y, max_diff, ignore_type) for x, y in _pairs(a, b, pad))
   return abs(a - b) <= max_diff
-
-
-almost_eq.bits = almost_eq
-almost_eq.diff = _almost_eq_diff
 
 
 def line(dur, begin=0., end=1., finish=False):

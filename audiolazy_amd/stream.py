@@ -18,11 +18,14 @@ import numbers
 import operator
 
 
-def rint(x):
-  """Nearest integer, halves away from zero -- the rounding the reference applies to durations
-  and ``take`` counts (lazy_misc.py:44-71); unlike the builtin ``round`` (halves to even)."""
+def rint(x, step=1):
+  """Nearest multiple of ``step`` (an integer), halves away from zero -- the rounding the reference
+  applies to durations and ``take`` counts (lazy_misc.py:44-71); unlike the builtin ``round``
+  (halves to even)."""
   import math
-  return int(math.floor(x + .5)) if x >= 0 else -int(math.floor(-x + .5))
+  q = x / step
+  n = int(math.floor(q + .5)) if q >= 0 else -int(math.floor(-q + .5))
+  return n * step
 
 
 def blocks(seq, size=None, hop=None, padval=0.):
