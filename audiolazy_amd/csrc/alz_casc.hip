@@ -53,7 +53,9 @@ __device__ __forceinline__ void c_dma16(const void *gsrc, unsigned lds_dst) {
 }
 typedef double cdbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void c_store16(double *gdst, cdbl2 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+  // nt: the output is never read back by this launch, and a filterbank's input tiles -- re-read by
+  // every band from L2 -- should not be pushed out by it (+6 % on cfg4)
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void c_wait_vm(int n) {
   switch (n) {
