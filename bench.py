@@ -242,6 +242,18 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+  # yardstick, outside the timed region: a plain device-to-device copy of the same block
+  d2d_gbps = None
+  if rank == 0:
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    y.copy_(x)
+    c0.record()
+    for _ in range(3):
+      y.copy_(x)
+    c1.record()
+    torch.cuda.synchronize(dev)
+    d2d_gbps = 3 * 2.0 * x.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+
   # spot parity: 4 channels of the last block against the oracle would need the whole
   # stream history; instead re-run a fresh 4096-sample block and compare bit for bit
   parity = None
@@ -273,7 +285,8 @@ def main():
     achieved = ALG_BYTES_PER_SAMPLE * C * N / (k_avg_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N}
+            "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N,
+            "d2d_copy_same_block_GBps": d2d_gbps}
     # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
     # from inside this process): measured traffic / algorithmic ratio of the same kernel at
     # 2**18-sample blocks, scaled to this launch's algorithmic bytes
