@@ -132,6 +132,31 @@ def side_workload(args, alz, torch, dev, rank, world, local, red_dev):
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+  parity = None
+  if rank == 0 and not args.no_parity_check:
+    try:   # the oracle is a checker, never a dependency of the timed path
+      from oracle import oracle
+      if args.workload == "gammatone":
+        nchk = 256
+        bank.reset()
+        xs = x[:, :nchk].contiguous()
+        got = bank.process(xs, layout="chan").cpu().numpy()
+        k = alz.gammatone_erb_constants(4)[0]
+        bands = [alz.gammatone.slaney(fc, k * alz.erb(fc, Hz)) for fc in fcs]
+        nbs, nas = [len(f.numlist) for f in bands[0]], [len(f.denlist) for f in bands[0]]
+        bcat = np.repeat(np.array([sum((f.numlist for f in band), []) for band in bands]), S, axis=0)
+        acat = np.repeat(np.array([sum((f.denlist for f in band), []) for band in bands]), S, axis=0)
+        ref = oracle.bank(nbs, nas, bcat, acat, np.tile(xs.cpu().numpy(), (B, 1)), layout="chan")
+        parity = "bit-exact" if np.array_equal(got.view(np.uint64), ref.view(np.uint64)) else "MISMATCH"
+      else:
+        nf = 256
+        coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order)
+        rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
+        worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
+        parity = ("coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)" % worst
+                  if worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs) else "MISMATCH (%.3g)" % worst)
+    except Exception as exc:
+      parity = "unchecked (%s)" % exc
   if rank == 0:
     k_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -139,7 +164,8 @@ def side_workload(args, alz, torch, dev, rank, world, local, red_dev):
       "metric": metric, "value": world * units * args.steps / elapsed / 1e9, "unit": unit_name,
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)"},
+      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)",
+                 "parity_spot_check": parity},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms_avg": k_ms,
                    "algorithmic_bytes_per_launch": alg_bytes}}))
