@@ -471,7 +471,10 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   const int64_t in_rows = layout == ALZ_TIME_MAJOR ? n : h->n_inputs;
   const int64_t out_rows = layout == ALZ_TIME_MAJOR ? n : h->channels;
   if (ldx < in_cols || ldy < out_cols) return fail(ALZ_E_ARG, "leading dimension too small");
-  const int64_t lsx = (in_cols + 1) & ~(int64_t)1, lsy = (out_cols + 1) & ~(int64_t)1;
+  // (a single column needs no padding: no 16-byte-piece kernel takes a one-channel bank, and a
+  // contiguous vector keeps the copies one-dimensional and the time-parallel FIR kernel eligible)
+  const int64_t lsx = in_cols == 1 ? 1 : (in_cols + 1) & ~(int64_t)1;
+  const int64_t lsy = out_cols == 1 ? 1 : (out_cols + 1) & ~(int64_t)1;
   int rc = grow(&h->stage_x, &h->stage_x_bytes, (uint64_t)in_rows * lsx * 8);
   if (rc) return rc;
   rc = grow(&h->stage_y, &h->stage_y_bytes, (uint64_t)out_rows * lsy * 8);

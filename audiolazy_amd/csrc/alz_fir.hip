@@ -263,8 +263,11 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
                const char **kernel_name) {
   *taken = false;
   if (sec.na != 1 || sec.nb < 2) return ALZ_OK;
-  const bool tm = io.sxc == 1 && io.syc == 1;
-  const bool cm = !tm && io.sxn == 1 && io.syn == 1;
+  // one stream (what the filter call protocol sends) is contiguous in time whichever layout it is
+  // called: it goes to the time-parallel kernel, where 64 lanes share the channel instead of one
+  const bool one = io.channels == 1 && io.n_inputs == 1 && io.sxn == 1 && io.syn == 1;
+  const bool tm = !one && io.sxc == 1 && io.syc == 1;
+  const bool cm = one || (!tm && io.sxn == 1 && io.syn == 1);
   if (!tm && !cm) return ALZ_OK;
   if (io.x == io.y) return ALZ_OK;
   if ((sec.present_b) == 0) return ALZ_OK;                 // all-zero filter: k_generic yields `zero`
