@@ -331,7 +331,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   else if (channels == 1)
     hipLaunchKernelGGL((alz::k_tv_one<alz::kTvMax, alz::kTvMax>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
   else if (nb <= 3 && na <= 3)
-    hipLaunchKernelGGL((alz::k_tv<3, 3, 8>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((alz::k_tv<3, 3, 16>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   hipError_t e = hipGetLastError();
