@@ -43,8 +43,14 @@ struct TvArgs {
   int n_terms;
 };
 
-template <int NB, int NA, int B>
+// PB / PA: compile-time presence masks (bit k <=> b_k present; bit k-1 <=> a_k present) for the
+// curated biquad-class patterns -- absent taps then cost nothing and present ones need no
+// "is it there" select; kTvAny leaves presence to the run-time descriptors.
+static constexpr unsigned kTvAny = ~0u;
+
+template <int NB, int NA, int B, unsigned PB = kTvAny, unsigned PA = kTvAny>
 __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
+  constexpr bool STATIC = PB != kTvAny;
   const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (c >= p.channels) return;
   double d[NB], m[NA];            // d[k] = x[n-k], m[k] = y[n-k]  (d[0], m[0] are scratch)
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
     for (int k = 0; k < NB; ++k) {
 #pragma unroll
       for (int u = 0; u < B; ++u) sb[k][u] = 0.0;
-      if (b_ser[k]) {
+      if ((!STATIC || ((PB >> k) & 1u)) && b_ser[k]) {
         const double *s = p.b.series[k] + c * p.b.sc[k];
 #pragma unroll
         for (int u = 0; u < B; ++u) sb[k][u] = (u < cnt) ? s[(n0 + u) * p.b.sn[k]] : 0.0;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
     for (int k = 1; k < NA; ++k) {
 #pragma unroll
       for (int u = 0; u < B; ++u) sa[k][u] = 0.0;
-      if (a_ser[k]) {
+      if ((!STATIC || ((PA >> (k - 1)) & 1u)) && a_ser[k]) {
         const double *s = p.a.series[k] + c * p.a.sc[k];
         const bool neg = p.a.negated[k] != 0;
 #pragma unroll
@@ -103,19 +109,27 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
       double acc = -0.0;           // additive identity: the first present term initialises the sum
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const double coef = b_ser[k] ? sb[k][u] : cb[k];
-        const double s = acc + coef * d[k];
-        acc = b_on[k] ? s : acc;
+        if constexpr (STATIC) {
+          if ((PB >> k) & 1u) acc = acc + (b_ser[k] ? sb[k][u] : cb[k]) * d[k];
+        } else {
+          const double coef = b_ser[k] ? sb[k][u] : cb[k];
+          const double s = acc + coef * d[k];
+          acc = b_on[k] ? s : acc;
+        }
       }
 #pragma unroll
       for (int k = 1; k < NA; ++k) {
-        const double coef = a_ser[k] ? sa[k][u] : nca[k];
-        const double s = acc + coef * m[k];
-        acc = a_on[k] ? s : acc;
+        if constexpr (STATIC) {
+          if ((PA >> (k - 1)) & 1u) acc = acc + (a_ser[k] ? sa[k][u] : nca[k]) * m[k];
+        } else {
+          const double coef = a_ser[k] ? sa[k][u] : nca[k];
+          const double s = acc + coef * m[k];
+          acc = a_on[k] ? s : acc;
+        }
       }
       if constexpr (DIV) acc = acc / gain;
       acc = negate ? -acc : acc;
-      acc = no_terms ? zero : acc;
+      if constexpr (!STATIC) acc = no_terms ? zero : acc;
       if (u < cnt) {
         yc[(n0 + u) * p.syn] = acc;
 #pragma unroll
@@ -330,8 +344,17 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     hipLaunchKernelGGL((alz::k_tv_one<3, 3>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
   else if (channels == 1)
     hipLaunchKernelGGL((alz::k_tv_one<alz::kTvMax, alz::kTvMax>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
-  else if (nb <= 3 && na <= 3)
-    hipLaunchKernelGGL((alz::k_tv<3, 3, 16>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+  else if (nb <= 3 && na <= 3) {
+    unsigned pb = 0, pa = 0;
+    for (int k = 0; k < 3; ++k) pb |= (p.b.kind[k] != 0) << k;
+    for (int k = 1; k < 3; ++k) pa |= (p.a.kind[k] != 0) << (k - 1);
+    void (*fn)(alz::TvArgs) = alz::k_tv<3, 3, 16>;
+#define ALZ_TV_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) fn = alz::k_tv<3, 3, 16, PB_, PA_>;
+    ALZ_TV_PAT(1, 1) ALZ_TV_PAT(3, 1) ALZ_TV_PAT(1, 3) ALZ_TV_PAT(3, 3) ALZ_TV_PAT(5, 3) ALZ_TV_PAT(7, 3)
+    ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
+#undef ALZ_TV_PAT
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+  }
   else
     hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
   hipError_t e = hipGetLastError();
