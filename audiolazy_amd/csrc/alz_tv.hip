@@ -180,8 +180,9 @@ __device__ __forceinline__ double load_untracked(const double *ptr) {
   return v;
 }
 
-template <int NB, int NA>
+template <int NB, int NA, unsigned PB = kTvAny, unsigned PA = kTvAny>
 __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
+  constexpr bool STATIC = PB != kTvAny;     // compile-time presence masks, as in k_tv
   const int lane = threadIdx.x;
   constexpr int kLoads = NB + NA;          // loads per batch: x, NB numerator and NA-1 denominator series
   // Untracked (inline-asm) loads only in the small variant.  Above 256 registers hipcc parks
@@ -253,18 +254,22 @@ __global__ __launch_bounds__(64) void k_tv_one(TvArgs p) {
       double acc = -0.0;
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
+        if (STATIC && !((PB >> k) & 1u)) continue;
         const double coef = pick(b_ser[k], lane_value(t.sb[k], u), cb[k]);
-        acc = pick(b_on[k], acc + coef * d[k], acc);
+        if (STATIC) acc = acc + coef * d[k];
+        else acc = pick(b_on[k], acc + coef * d[k], acc);
       }
 #pragma unroll
       for (int k = 1; k < NA; ++k) {
+        if (STATIC && !((PA >> (k - 1)) & 1u)) continue;
         const double sv = lane_value(t.sa[k], u);
         const double coef = pick(a_ser[k], pick(a_neg[k], sv, -sv), nca[k]);
-        acc = pick(a_on[k], acc + coef * m[k], acc);
+        if (STATIC) acc = acc + coef * m[k];
+        else acc = pick(a_on[k], acc + coef * m[k], acc);
       }
       if constexpr (DIV) acc = acc / gain;
       acc = pick(negate, -acc, acc);
-      acc = pick(no_terms, zero, acc);
+      if (!STATIC) acc = pick(no_terms, zero, acc);
       ybuf = (lane == u) ? acc : ybuf;
 #pragma unroll
       for (int k = NA - 1; k > 1; --k) m[k] = m[k - 1];
@@ -340,8 +345,17 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   const unsigned grid = (unsigned)((channels + 63) / 64);
-  if (channels == 1 && nb <= 3 && na <= 3)
-    hipLaunchKernelGGL((alz::k_tv_one<3, 3>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+  if (channels == 1 && nb <= 3 && na <= 3) {
+    unsigned pb = 0, pa = 0;
+    for (int k = 0; k < 3; ++k) pb |= (p.b.kind[k] != 0) << k;
+    for (int k = 1; k < 3; ++k) pa |= (p.a.kind[k] != 0) << (k - 1);
+    void (*fn)(alz::TvArgs) = alz::k_tv_one<3, 3>;
+#define ALZ_TV_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) fn = alz::k_tv_one<3, 3, PB_, PA_>;
+    ALZ_TV_PAT(1, 1) ALZ_TV_PAT(3, 1) ALZ_TV_PAT(1, 3) ALZ_TV_PAT(3, 3) ALZ_TV_PAT(5, 3) ALZ_TV_PAT(7, 3)
+    ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
+#undef ALZ_TV_PAT
+    hipLaunchKernelGGL(fn, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+  }
   else if (channels == 1)
     hipLaunchKernelGGL((alz::k_tv_one<alz::kTvMax, alz::kTvMax>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
   else if (nb <= 3 && na <= 3) {
