@@ -183,6 +183,7 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
   std::vector<double> bt, at;
   transpose_to_dev_order(b_host, bt, n_sets, tb);
   transpose_to_dev_order(a_host, at, n_sets, ta);
+  bt.resize(bt.size() + 16, 0.0);   // k_fir_ring reads whole 8-tap blocks with scalar loads: keep them in bounds
   const uint64_t xs = (uint64_t)(h->thx > 0 ? h->thx : 1) * h->channels * 8 * 2;
   const uint64_t ys = (uint64_t)(h->thy > 0 ? h->thy : 1) * h->channels * 8 * 2;
   if (hipMalloc((void **)&h->b_dev, bt.size() * 8) != hipSuccess ||

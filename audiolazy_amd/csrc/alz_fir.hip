@@ -18,6 +18,7 @@
 //
 // Bound: FP64 issue, not HBM: 2*nb - 1 f64 ops per output sample (511 for 256 taps) at one op
 // per ~4.5 cycles per SIMD.
+#include <cstdlib>
 #include "alz_common.h"
 
 namespace alz {
@@ -31,6 +32,10 @@ namespace alz {
 static constexpr int kFirR = ALZ_FIR_R;   // outputs per lane held in registers
 static constexpr int kFirK = ALZ_FIR_K;   // taps per block
 static constexpr int kFirTB = 8 * kFirR; // output rows per wave
+#ifndef ALZ_FIR_SK
+#define ALZ_FIR_SK 8
+#endif
+static constexpr int kFirSK = ALZ_FIR_SK; // taps per block in k_fir_s (two row buffers: 8 fit, 16 spill)
 
 struct FArgs {
   const double *x;
@@ -141,6 +146,270 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
       for (int r = 0; r < kFirR; ++r) {
         const int64_t t = t0 + r;
         if (t < p.n) p.y[t * p.syn + c] = all_zero ? p.zero : (p.div ? acc[r] / a0 : acc[r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_fir_s: k_fir for taps shared by the whole bank, restructured around what bounded k_fir<true>
+// (62 % of the separately-rounded f64 rate): the K new rows of a tap block were loaded at the top
+// of the block and needed by its first tap, so each of the two waves of a SIMD sat out a whole
+// L2 / HBM latency per block.  Here the rows of block kb + K are requested before the sums of
+// block kb start (a second K-row register buffer), the taps are wave-uniform SGPR pairs
+// (readfirstlane of the broadcast LDS read: the multiply takes them as its scalar operand and
+// 2K VGPRs are free for the buffer), and the row addresses are one uniform base per block plus a
+// per-lane 32-bit offset.  Same sums, same order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_uniform(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)bits);
+  const int hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_fir_s(FArgs p) {
+  constexpr int R = kFirR, K = kFirSK;
+  const int lane = threadIdx.x;
+  int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + lane;
+  const bool live = c < p.c_end;
+  if (!live) c = p.c_end - 1;
+  const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? c % p.n_inputs : c;
+  const double a0 = p.a[0];
+  const int64_t tb0 = (int64_t)blockIdx.y * kFirTB;
+  extern __shared__ __attribute__((aligned(16))) double tap_lds[];
+  const int padded = ((p.nb + K - 1) / K) * K;
+  for (int k = lane; k < padded; k += 64) tap_lds[k] = (k < p.nb) ? p.b[k] : 0.0;
+  __syncthreads();
+  const unsigned lane_off = (unsigned)in * 8u;               // launch_fir keeps channels * 8 < 2^31
+  const int64_t row_bytes = p.sxn * 8;
+
+  auto load_row = [&](int64_t t) -> double {
+    if (t > p.n - 1) t = p.n - 1;
+    int64_t hk = -t - 1;
+    if (hk > p.nb - 2) hk = p.nb - 2;
+    const double *src = (t >= 0) ? p.x + t * p.sxn + in : p.xh + (hk < 0 ? 0 : hk) * p.channels + c;
+    return *src;
+  };
+  // rows tb .. tb + K - 1 (all <= n - 1 by construction) into dst
+  auto load_group = [&](int64_t tb, double (&dst)[K]) {
+    if (tb >= 0) {
+      const char *base = (const char *)p.x + tb * row_bytes;  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < K; ++j) dst[j] = *(const double *)(base + j * row_bytes + lane_off);
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) dst[j] = load_row(tb + j);
+    }
+  };
+
+  for (int sub = 0; sub < kFirTB; sub += R) {
+    const int64_t t0 = tb0 + sub;
+    if (t0 >= p.n) break;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = -0.0;
+    double xw[R + K - 1], xn[K];
+#pragma unroll
+    for (int j = K; j < R + K - 1; ++j) xw[j] = load_row(t0 - (K - 1) + j);
+    load_group(t0 - (K - 1), xn);
+    for (int kb = 0; kb < p.nb; kb += K) {
+      if (kb > 0) {
+#pragma unroll
+        for (int j = R + K - 2; j >= K; --j) xw[j] = xw[j - K];
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) xw[j] = xn[j];
+      if (kb + K < p.nb) load_group(t0 - (kb + K) - (K - 1), xn);   // next block's rows, in flight
+      double bk[K];
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) bk[kk] = wave_uniform(tap_lds[kb + kk]);
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        if ((__double_as_longlong(bk[kk]) << 1) == 0) continue;    // +-0 tap: absent from the sum
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+          const double m0 = bk[kk] * xw[r - kk + (K - 1)];
+          const double m1 = bk[kk] * xw[r + 1 - kk + (K - 1)];
+          const double m2 = bk[kk] * xw[r + 2 - kk + (K - 1)];
+          const double m3 = bk[kk] * xw[r + 3 - kk + (K - 1)];
+          acc[r] = acc[r] + m0;
+          acc[r + 1] = acc[r + 1] + m1;
+          acc[r + 2] = acc[r + 2] + m2;
+          acc[r + 3] = acc[r + 3] + m3;
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t t = t0 + r;
+        if (t < p.n) p.y[t * p.syn + c] = p.div ? acc[r] / a0 : acc[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_fir_ring: k_fir_s without its non-arithmetic vector instructions (PMC: 18 % of the VALU slots
+// of k_fir_s were window moves, per-lane row pointers, tap broadcasts and zero tests, on ALUs that
+// are 93 % busy).  The x window is a register ring of NG = R/K + 2 groups of K rows: a tap block
+// uses NG - 1 of them and the last one receives the rows of the next block, so going to the next
+// block renames groups instead of moving registers -- the block loop is unrolled NG times with the
+// ring phase a template parameter.  Rows come through buffer loads (uniform descriptor per group,
+// per-lane 32-bit channel offset, uniform row offset: no vector address arithmetic), taps through
+// scalar loads from the constant address space (SGPR operands of the multiplies), and the
+// "tap is +-0, hence absent from the sum" test is scalar too.
+// ---------------------------------------------------------------------------
+typedef const double __attribute__((address_space(4))) *const_taps_t;
+static constexpr int kRingK = kFirSK;
+static constexpr int kRingG = kFirR / kRingK + 2;
+static_assert(kFirR % kRingK == 0, "ring groups");
+
+__device__ __forceinline__ bool tap_absent(double t) {
+  long long sh;
+  asm("s_lshl_b64 %0, %1, 1" : "=s"(sh) : "s"(__double_as_longlong(t)) : "scc");
+  return sh == 0;
+}
+
+struct RingCtx {
+  const FArgs *p;
+  int64_t in, c, row_bytes;
+  unsigned lane_off;
+  const_taps_t taps;
+};
+
+__device__ __forceinline__ double ring_edge_row(const RingCtx &q, int64_t t) {
+  const FArgs &p = *q.p;
+  if (t > p.n - 1) t = p.n - 1;                             // past the block: never used
+  int64_t hk = -t - 1;                                      // before the stream: history row
+  if (hk > p.nb - 2) hk = p.nb - 2;                         // beyond the delay line: never used
+  const double *src = (t >= 0) ? p.x + t * p.sxn + q.in : p.xh + (hk < 0 ? 0 : hk) * p.channels + q.c;
+  return *src;
+}
+
+// rows tb .. tb + K - 1 (all <= n - 1) of this wave's channels into one ring group.  The buffer
+// loads are issued whatever tb is (from row 0 when the group reaches before the block) and the rare
+// history case overwrites them afterwards: with the loads behind a branch the compiler's waitcnt
+// pass has to assume at the join that none were issued and waits for ALL outstanding loads before
+// the first use of the PREVIOUS group -- which is exactly the latency this prefetch is there to hide.
+__device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, double (&dst)[kRingK]) {
+  const int64_t tc = tb < 0 ? 0 : tb;
+  const char *base = (const char *)q.p->x + tc * q.row_bytes;            // wave-uniform
+  int64_t valid = (q.p->n - tc) * q.row_bytes;             // rows past the block read as 0.0 (range check)
+  if (valid > 0x7fffffff) valid = 0x7fffffff;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)valid, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < kRingK; ++j)
+    dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, (int)(j * q.row_bytes), 0));
+  if (tb < 0) {
+#pragma unroll
+    for (int j = 0; j < kRingK; ++j) dst[j] = ring_edge_row(q, tb + j);
+  }
+}
+
+// one tap block (taps kb .. kb + K - 1) at ring phase PH: window row j lives in group
+// (j / K - PH) mod NG; group NG - 1 - PH is free and takes the next block's rows
+__device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double (&tap)[kRingK]) {
+  const int nb = q.p->nb;
+#pragma unroll
+  for (int kk = 0; kk < kRingK; ++kk) {
+    const double t = q.taps[kb + kk];                       // the taps array is padded (alz_api.hip)
+    tap[kk] = (kb + kk < nb) ? t : 0.0;
+  }
+}
+
+template <int PH>
+__device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, double (&xr)[kRingG][kRingK],
+                                          double (&acc)[kFirR], const double (&tap)[kRingK],
+                                          double (&tap_next)[kRingK]) {
+  constexpr int R = kFirR, K = kRingK, NG = kRingG;
+  ring_load_group(q, t0 - (kb + K) - (K - 1), xr[NG - 1 - PH]);   // unused after the last block
+  ring_load_taps(q, kb + K, tap_next);                            // likewise (all 0.0 past the end)
+#pragma unroll
+  for (int kk = 0; kk < K; ++kk) {
+    if (tap_absent(tap[kk])) continue;
+#define ALZ_RING_X(j) xr[(((j) / K) + NG - PH) % NG][(j) % K]
+#pragma unroll
+    for (int r = 0; r < R; r += 4) {
+      const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
+      const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
+      const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
+      const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
+      acc[r] = acc[r] + m0;
+      acc[r + 1] = acc[r + 1] + m1;
+      acc[r + 2] = acc[r + 2] + m2;
+      acc[r + 3] = acc[r + 3] + m3;
+    }
+#undef ALZ_RING_X
+  }
+}
+
+// NG is even: the two tap buffers swap roles with the parity of the phase
+template <int PH>
+__device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb, double (&xr)[kRingG][kRingK],
+                                           double (&acc)[kFirR], double (&tap_a)[kRingK], double (&tap_b)[kRingK],
+                                           bool &done) {
+  if constexpr (PH < kRingG) {
+    if (!done) {
+      if constexpr (PH % 2 == 0) ring_step<PH>(q, t0, kb, xr, acc, tap_a, tap_b);
+      else ring_step<PH>(q, t0, kb, xr, acc, tap_b, tap_a);
+      kb += kRingK;
+      done = kb >= q.p->nb;
+    }
+    ring_steps<PH + 1>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+  }
+}
+
+#ifndef ALZ_FIR_WAVES
+#define ALZ_FIR_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_FIR_WAVES, ALZ_FIR_WAVES)))
+void k_fir_ring(FArgs p) {
+  constexpr int R = kFirR, K = kRingK, NG = kRingG;
+  const int lane = threadIdx.x;
+  RingCtx q;
+  q.p = &p;
+  q.c = p.c_first + (int64_t)blockIdx.x * 64 + lane;
+  const bool live = q.c < p.c_end;
+  if (!live) q.c = p.c_end - 1;
+  q.in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? q.c % p.n_inputs : q.c;
+  q.lane_off = (unsigned)q.in * 8u;                         // launch_fir keeps channels * 8 < 2^31
+  q.row_bytes = p.sxn * 8;
+  q.taps = (const_taps_t)(uintptr_t)p.b;
+  const double a0 = p.a[0];
+  const int64_t tb0 = (int64_t)blockIdx.y * kFirTB;
+
+  for (int sub = 0; sub < kFirTB; sub += R) {
+    const int64_t t0 = tb0 + sub;
+    if (t0 >= p.n) break;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = -0.0;
+    double xr[NG][K];
+#pragma unroll
+    for (int j = K; j < R + K; ++j)                          // groups 1 .. NG - 2: rows of this output run
+      xr[j / K][j % K] = (j < R + K - 1) ? ring_edge_row(q, t0 - (K - 1) + j) : 0.0;
+    ring_load_group(q, t0 - (K - 1), xr[0]);
+#pragma unroll
+    for (int j = 0; j < K; ++j) xr[NG - 1][j] = 0.0;
+    int kb = 0;
+    bool done = false;
+    double tap_a[K], tap_b[K];
+    ring_load_taps(q, 0, tap_a);
+    while (!done) {
+      ring_steps<0>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+      if constexpr (NG % 2 != 0) {                           // odd ring: the roles end up swapped
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { const double t = tap_a[kk]; tap_a[kk] = tap_b[kk]; tap_b[kk] = t; }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t t = t0 + r;
+        if (t < p.n) p.y[t * p.syn + q.c] = p.div ? acc[r] / a0 : acc[r];
       }
     }
   }
@@ -282,7 +551,9 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const unsigned gy = (unsigned)((io.n + kFirTB - 1) / kFirTB);
   if (gy > 65535u) return ALZ_OK;  // block longer than the grid's y range: caller falls back
-  const size_t tap_bytes = (size_t)((sec.nb + kFirK - 1) / kFirK) * kFirK * sizeof(double);
+  const char *shared_name = "k_fir<shared>";
+  const size_t tap_bytes = (size_t)((sec.nb + kFirK - 1) / kFirK) * kFirK * sizeof(double);   // kFirSK divides kFirK
+  static_assert(kFirK % kFirSK == 0, "tap padding");
   if (sec.shared_sets && tap_bytes > 48 * 1024) return ALZ_OK;   // absurdly long: let k_generic have it
   if (cm) {
     const int hist = sec.nb - 1;
@@ -291,7 +562,17 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     const unsigned gyc = (unsigned)((io.n + kCmOut - 1) / kCmOut);
     if (gyc > 65535u || io.c_count > 0x7fffffff) return ALZ_OK;
     hipLaunchKernelGGL(k_fir_cm, dim3((unsigned)io.c_count, gyc), dim3(64), lds, stream, p);
-  } else if (sec.shared_sets)
+  } else if (sec.shared_sets && io.n_inputs * 8 < ((int64_t)1 << 31) && io.channels * 8 < ((int64_t)1 << 31) &&
+             io.sxn * 8 * kRingK < ((int64_t)1 << 31) && !getenv("ALZ_FIR_OLD")) {
+    if (getenv("ALZ_FIR_S")) {
+      hipLaunchKernelGGL(k_fir_s, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
+      shared_name = "k_fir_s";
+    } else {
+      hipLaunchKernelGGL(k_fir_ring, dim3(gx, gy), dim3(64), 0, stream, p);
+      shared_name = "k_fir_ring";
+    }
+  }
+  else if (sec.shared_sets)
     hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
   else
     hipLaunchKernelGGL(k_fir<false>, dim3(gx, gy), dim3(64), 0, stream, p);
@@ -311,7 +592,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   }
   ALZ_HIP_CHECK(hipGetLastError());
   *taken = true;
-  *kernel_name = cm ? "k_fir_cm" : sec.shared_sets ? "k_fir<shared>" : "k_fir<per-channel>";
+  *kernel_name = cm ? "k_fir_cm" : sec.shared_sets ? shared_name : "k_fir<per-channel>";
   return ALZ_OK;
 }
 

@@ -334,7 +334,10 @@ def main():
       tf = flops / (k_avg_ms * 1e-3) / 1e12
       roof = {"bound": "valu_f64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
               "traffic": None, "kernel_ms_avg": k_avg_ms, "algorithmic_flops_per_launch": flops,
-              "hbm_GBps": achieved}
+              "hbm_GBps": achieved,
+              "note": "unfused mul + add halves the FMA spec (39.3); under this FP64 load the engine clock "
+                      "sits at 2.0 GHz, not 2.4 (GRBM_GUI_ACTIVE), which puts the unfused roof at 32.8 "
+                      "TFLOP/s with the VALUs 87 % busy: profiles/r01_pmc_fir.txt"}
       workload = ("configs[2]: 256-tap FIR lowpass (Hamming-windowed sinc, shared taps) x %d channels, "
                   "float64, %d-sample blocks, 1 MI355X per rank" % (C, N))
       metric = "Gsamples/s through ZFilter FIR-256 bank"

@@ -281,7 +281,7 @@ def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
   bank = alz.FilterBank([(taps, [1.0])], n_inputs=C)
   bank.reset(zero=0.125)
   y = bank.process(x)
-  assert bank.last_kernel == "k_fir<shared>"
+  assert bank.last_kernel == "k_fir_ring"
   ref = oracle.bank([256], [1], taps, np.array([1.0]), x, xh=np.full((C, 255), 0.125), zero=0.125)
   assert same_bits(y, ref)
   # blocks continue the stream (history kept on the device), including blocks shorter than the taps
@@ -297,6 +297,35 @@ def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
   assert bank.last_kernel == "k_fir_cm" and same_bits(yc, ref.T)
   x2c = np.ascontiguousarray(x2.T)
   assert same_bits(bank.process(x2c, layout="chan"), whole[N:N + 40].T)
+
+
+@pytest.mark.parametrize("switch,name", [(None, "k_fir_ring"), ("ALZ_FIR_S", "k_fir_s"),
+                                         ("ALZ_FIR_OLD", "k_fir<shared>")])
+@pytest.mark.parametrize("nb,N,gain", [(20, 5, 1.0), (17, 77, 1.0), (64, 300, 2.0), (255, 1000, 1.0),
+                                       (256, 40, -1.0), (100, 2100, 0.5)])
+def test_fir_shared_taps_kernels_shapes(alz, oracle, monkeypatch, switch, name, nb, N, gain):
+  """The three shared-tap kernels (ring of row groups / prefetching / first version) on tap counts
+  that are not a multiple of the tap block, blocks shorter than a row group, zero taps (+0 and -0:
+  absent from the sum, an inf must not get through them) and a gain."""
+  if switch:
+    monkeypatch.setenv(switch, "1")
+  rng = np.random.default_rng(nb * 7 + N)
+  C = 70
+  taps = rng.uniform(-1, 1, nb)
+  taps[3] = 0.0
+  taps[nb - 2] = -0.0
+  x = rng.uniform(-1, 1, (N, C))
+  if N > 10:
+    x[N // 2, 11] = np.inf                     # reaches y only through taps that are present
+  bank = alz.FilterBank([(taps, [gain])], n_inputs=C)
+  bank.reset(zero=0.25)
+  y = bank.process(x)
+  assert bank.last_kernel == name
+  x2 = rng.uniform(-1, 1, (33, C))
+  whole = oracle.bank([nb], [1], taps, np.array([gain]), np.concatenate([x, x2]),
+                      xh=np.full((C, nb - 1), 0.25), zero=0.25)
+  assert same_bits(y, whole[:N])
+  assert same_bits(bank.process(x2), whole[N:])
 
 
 def test_fir_per_channel_taps_zero_taps_and_gain(alz, oracle):
