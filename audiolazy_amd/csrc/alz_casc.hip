@@ -331,6 +331,14 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
 // stage s produced.
 // ---------------------------------------------------------------------------
 static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per workgroup (a tile is only 16 steps long)
+#ifndef ALZ_PIPE_OVERLAP
+#define ALZ_PIPE_OVERLAP 1
+#endif
+// ALZ_PIPE_OVERLAP: a stage wave reads the tile it will work on in the NEXT interval while it does the
+// arithmetic of the current one (two register sets that swap roles every interval), so the LDS read
+// latency of the hand-over is no longer in series with the recurrence; a stage then lags its
+// predecessor by two barrier intervals instead of one.
+static constexpr int kPLag = ALZ_PIPE_OVERLAP ? 2 : 1;
 
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
 template <bool CM, int SPW, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
@@ -349,6 +357,10 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   const int64_t in0 = outer ? c0 % p.n_inputs : c0;
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
+  // stage w reads tile t - kPLag w (and, overlapped, computes tile t - kPLag w - 1) in interval t;
+  // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
+  constexpr int store_lag = ALZ_PIPE_OVERLAP ? 2 * NW : NW;
+  const int64_t n_iv = (nt + store_lag + 2) & ~(int64_t)1;
   char *xring = smem;
   char *qring = smem + kPXRing * kCSlot;                 // NW-1 hand-off rings, 2 slots each
   char *yring = qring + (NW - 1) * 2 * kCSlot;
@@ -358,6 +370,15 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
 #define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
 
+  {
+    // experiment (ALZ_WAVE_DEBUG bits 4-6): start the workgroups of one XCD (blockIdx / 8) a few
+    // hundred ns apart, so that the bands do not all ask L2 for the same input tile at once
+    const int skew = (p.dbg >> 4) & 7;
+    if (skew) {
+      const int d = (int)((blockIdx.x >> 3) & 31) * skew;
+      for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   if (wave >= NW) {
     // ---------------- helpers: wave NW queues the tile DMA, wave NW+1 stores finished tiles ----------------
     // (two waves, because loads and stores of one wave share one in-order vmcnt counter of 63)
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
         c_wait_vm(on ? (int)(after > 5 ? 5 : after) * 8 : 0);   // tile 0 has landed
       }
       __builtin_amdgcn_s_barrier();
-      for (int64_t t = 0; t < nt + NW; ++t) {
+      for (int64_t t = 0; t < n_iv; ++t) {
         if (t + D < nt && on) queue_tile(t + D);
         if (t + 1 < nt) {
           const int64_t last = (t + D < nt - 1) ? t + D : nt - 1;
@@ -402,9 +423,9 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       __builtin_amdgcn_s_barrier();
-      for (int64_t t = 0; t < nt + NW; ++t) {
-        if (t >= NW && t - NW < nt && !(p.dbg & 4)) {
-          const int64_t tt = t - NW;
+      for (int64_t t = 0; t < n_iv; ++t) {
+        if (t >= store_lag && t - store_lag < nt && !(p.dbg & 4)) {
+          const int64_t tt = t - store_lag;
           const char *ys = yring + (int)(tt % 2) * kCSlot;
           double *yt = yg + tt * y_tile;
           cdbl2 w[kCChunks];
@@ -453,61 +474,85 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       for (int k = 0; k < 7; ++k) asm volatile("" : "+v"(dx[j][k]));
     }
 
-    __builtin_amdgcn_s_barrier();
-    for (int64_t t = 0; t < nt + NW; ++t) {
-      const int64_t tile = t - wave;
-      if (tile >= 0 && tile < nt) {
-        double v[16];
-        // input: stage 0 reads the DMA layout, the others the lane-private hand-off layout
-        if (wave == 0) {
-          const char *src = xring + (int)(tile % kPXRing) * kCSlot + lane_off;
+    auto read_tile = [&](int64_t tile, double (&v)[16]) {
+      // input: stage 0 reads the DMA layout, the others the lane-private hand-off layout
+      if (wave == 0) {
+        const char *src = xring + (int)(tile % kPXRing) * kCSlot + lane_off;
 #pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double *>(src + ALZ_COFF(u));
-        } else {
-          const char *src = qring + ((wave - 1) * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double *>(src + ALZ_COFF(u));
+      } else {
+        const char *src = qring + ((wave - 1) * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * 1024);
-            v[2 * j] = w.x;
-            v[2 * j + 1] = w.y;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * 1024);
+          v[2 * j] = w.x;
+          v[2 * j + 1] = w.y;
         }
-        if (!(p.dbg & 2)) {
-          if constexpr (SPW == 2) {
-            if (wave == 0)
-              section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1>(
-                  v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
-            else
-              section_pair_chunk<16, nb_of(PB2), PB2, PA2, nb_of(PB3), PB3, PA3>(
-                  v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < SPW; ++j) {
-              const int s = wave * SPW + j;
-              if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-              else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-              else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-              else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            }
-          }
-        }
-        if (wave == NW - 1) {
-          char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
+      }
+    };
+    auto work_tile = [&](int64_t tile, double (&v)[16]) {
+      if (!(p.dbg & 2)) {
+        if constexpr (SPW == 2) {
+          if (wave == 0)
+            section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1>(
+                v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
+          else
+            section_pair_chunk<16, nb_of(PB2), PB2, PA2, nb_of(PB3), PB3, PA3>(
+                v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
         } else {
-          char *dst = qring + (wave * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            cdbl2 w;
-            w.x = v[2 * j];
-            w.y = v[2 * j + 1];
-            *reinterpret_cast<cdbl2 *>(dst + j * 1024) = w;
+          for (int j = 0; j < SPW; ++j) {
+            const int s = wave * SPW + j;
+            if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (wave == NW - 1) {
+        char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
+      } else {
+        char *dst = qring + (wave * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          cdbl2 w;
+          w.x = v[2 * j];
+          w.y = v[2 * j + 1];
+          *reinterpret_cast<cdbl2 *>(dst + j * 1024) = w;
+        }
+      }
+    };
+    __builtin_amdgcn_s_barrier();
+    if constexpr (ALZ_PIPE_OVERLAP) {
+      double va[16], vb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) va[u] = vb[u] = 0.0;
+      auto interval = [&](int64_t t, double (&cur)[16], double (&nxt)[16]) {
+        const int64_t ahead = t - kPLag * wave;               // tile to fetch; the one before it is in `cur`
+        if (ahead >= 0 && ahead < nt) read_tile(ahead, nxt);
+        asm volatile("" ::: "memory");                        // the reads are issued before the arithmetic
+        if (ahead >= 1 && ahead - 1 < nt) work_tile(ahead - 1, cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      };
+      for (int64_t t = 0; t < n_iv; t += 2) {
+        interval(t, va, vb);
+        interval(t + 1, vb, va);
+      }
+    } else {
+      for (int64_t t = 0; t < n_iv; ++t) {
+        const int64_t tile = t - wave;
+        if (tile >= 0 && tile < nt) {
+          double v[16];
+          read_tile(tile, v);
+          work_tile(tile, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
@@ -579,7 +624,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   const int64_t groups = io.channels / 64, tiles = io.n / 16;
   if (groups == 0 || tiles == 0) return ALZ_OK;
   // ALZ_PIPE: 0 = single-wave k_casc, 1 = one section per stage wave, 2 = two sections per stage wave
-  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 2;
+  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
   casc_fn pipe = nullptr;
   if (nsec == 4 && pipe_env == 1) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
   if (nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
