@@ -334,11 +334,15 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 #ifndef ALZ_PIPE_OVERLAP
 #define ALZ_PIPE_OVERLAP 1
 #endif
-// ALZ_PIPE_OVERLAP: a stage wave reads the tile it will work on in the NEXT interval while it does the
-// arithmetic of the current one (two register sets that swap roles every interval), so the LDS read
-// latency of the hand-over is no longer in series with the recurrence; a stage then lags its
-// predecessor by two barrier intervals instead of one.
-static constexpr int kPLag = ALZ_PIPE_OVERLAP ? 2 : 1;
+// ALZ_PIPE_OVERLAP 1: a stage wave reads the tile it will work on in the NEXT interval while it does
+// the arithmetic of the current one (two register sets that swap roles every interval), so the LDS
+// read latency of the hand-over is no longer in series with the recurrence; a stage then lags its
+// predecessor by two barrier intervals instead of one.  2: the results of the PREVIOUS tile are
+// written out at the start of the interval as well (three register sets in rotation, lag 3), so
+// neither direction of the hand-over waits in series with the arithmetic -- measured SLOWER (364 vs
+// 394 Gsamples/s on cfg4: all the LDS traffic of the six waves then lands at the start of the
+// interval), kept for A/B only.
+static constexpr int kPLag = ALZ_PIPE_OVERLAP + 1;
 
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
 template <bool CM, int SPW, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
@@ -359,8 +363,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   const int64_t nt = p.n_tiles;
   // stage w reads tile t - kPLag w (and, overlapped, computes tile t - kPLag w - 1) in interval t;
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
-  constexpr int store_lag = ALZ_PIPE_OVERLAP ? 2 * NW : NW;
-  const int64_t n_iv = (nt + store_lag + 2) & ~(int64_t)1;
+  constexpr int store_lag = kPLag * NW;
+  const int64_t n_iv = (nt + store_lag + 1 + 5) / 6 * 6;    // a multiple of the 2- and 3-interval unrolls
   char *xring = smem;
   char *qring = smem + kPXRing * kCSlot;                 // NW-1 hand-off rings, 2 slots each
   char *yring = qring + (NW - 1) * 2 * kCSlot;
@@ -370,15 +374,6 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
 #define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
 
-  {
-    // experiment (ALZ_WAVE_DEBUG bits 4-6): start the workgroups of one XCD (blockIdx / 8) a few
-    // hundred ns apart, so that the bands do not all ask L2 for the same input tile at once
-    const int skew = (p.dbg >> 4) & 7;
-    if (skew) {
-      const int d = (int)((blockIdx.x >> 3) & 31) * skew;
-      for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-  }
   if (wave >= NW) {
     // ---------------- helpers: wave NW queues the tile DMA, wave NW+1 stores finished tiles ----------------
     // (two waves, because loads and stores of one wave share one in-order vmcnt counter of 63)
@@ -490,7 +485,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
         }
       }
     };
-    auto work_tile = [&](int64_t tile, double (&v)[16]) {
+    auto do_sections = [&](double (&v)[16]) {
       if (!(p.dbg & 2)) {
         if constexpr (SPW == 2) {
           if (wave == 0)
@@ -510,6 +505,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
           }
         }
       }
+    };
+    auto write_tile = [&](int64_t tile, const double (&v)[16]) {
       if (wave == NW - 1) {
         char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
 #pragma unroll
@@ -525,8 +522,31 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
         }
       }
     };
+    auto work_tile = [&](int64_t tile, double (&v)[16]) {
+      do_sections(v);
+      write_tile(tile, v);
+    };
     __builtin_amdgcn_s_barrier();
-    if constexpr (ALZ_PIPE_OVERLAP) {
+    if constexpr (ALZ_PIPE_OVERLAP == 2) {
+      double va[16], vb[16], vc[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) va[u] = vb[u] = vc[u] = 0.0;
+      // interval t: write out tile a - 2 (done in the previous interval), fetch tile a, work on tile a - 1
+      auto interval = [&](int64_t t, double (&out)[16], double (&cur)[16], double (&nxt)[16]) {
+        const int64_t a = t - kPLag * wave;
+        if (a >= 2 && a - 2 < nt) write_tile(a - 2, out);
+        if (a >= 0 && a < nt) read_tile(a, nxt);
+        asm volatile("" ::: "memory");                        // LDS traffic is issued before the arithmetic
+        if (a >= 1 && a - 1 < nt) do_sections(cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      };
+      for (int64_t t = 0; t < n_iv; t += 3) {
+        interval(t, va, vb, vc);
+        interval(t + 1, vb, vc, va);
+        interval(t + 2, vc, va, vb);
+      }
+    } else if constexpr (ALZ_PIPE_OVERLAP == 1) {
       double va[16], vb[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) va[u] = vb[u] = 0.0;
