@@ -14,6 +14,7 @@
 // load per wave.  A single stream (channels == 1, the reference's own use) takes k_tv_one, where
 // the lanes prefetch in time instead.  Arithmetic: separately rounded mul/add in the reference's
 // order (bit-exact).
+#include <cstdlib>
 #include "alz_common.h"
 
 #include <type_traits>
@@ -143,6 +144,136 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
     if (divide) steps(std::true_type{});
     else steps(std::false_type{});
   }
+#pragma unroll
+  for (int k = 1; k < NB; ++k)
+    if (k < p.nb) p.xh[(int64_t)(k - 1) * p.channels + c] = d[k];
+#pragma unroll
+  for (int k = 1; k < NA; ++k)
+    if (k < p.na) p.yh[(int64_t)(k - 1) * p.channels + c] = m[k];
+}
+
+// ---------------------------------------------------------------------------
+// k_tvp<PB, PA, B>: k_tv for the curated biquad-class presence patterns, rebuilt around the cost of
+// a step.  One wave per 64 channels has its SIMD to itself and issues about one instruction per
+// five cycles, so a step costs what it issues: k_tv's step carries per-step "is the batch this
+// long" branches, per-step constant / series selects and address arithmetic from spilled SGPRs.
+// Here
+//  * full batches and the ragged tail are separate instantiations of the batch body (no per-step
+//    bounds tests in the full one), fully unrolled, so the delay lines rotate by renaming;
+//  * the coefficient values of a batch are put in registers BEFORE the dependent steps by one
+//    wave-uniform branch per tap and batch: a constant is copied, a series shared by the bank
+//    (channel stride 0) is read with scalar loads from the constant address space, and only a
+//    per-channel series costs vector loads (running pointers, no multiplies);
+//  * denominator terms are subtracted (acc - a_k[n] * y[n-k] is acc + (-a_k[n]) * y[n-k] bit for
+//    bit; the negation is a source modifier), so nothing is negated per value except a series the
+//    host already negated (ALZ_TV_NEGATED, the int-0 rule), which is negated back;
+//  * the gain mode (none / negate / divide) picks one of three step bodies per batch.
+// Same terms, same order, same roundings as k_tv.  Tried on top of this and not kept: the next
+// batch's loads issued before the steps of the current one (two register sets, compiler-untracked
+// loads with a counted s_waitcnt; staging shared series in SGPRs) -- slower, the scalar loads and
+// SGPR spills cost more than the latency they hid (19 vs 27 Gsamples/s at 4096 channels); a second
+// wave per block touching the rows a few batches ahead; narrower waves (4..32 channels per wave).
+// ---------------------------------------------------------------------------
+#ifndef ALZ_TVP_B
+#define ALZ_TVP_B 16   // samples per batch (12 and 8 measured slower or equal)
+#endif
+typedef const double __attribute__((address_space(4))) *tv_uniform_t;
+
+template <bool FULL, int B>
+__device__ __forceinline__ void tvp_fill(const TvSide &sd, int k, int64_t c, int64_t n0, int cnt, bool negate_back,
+                                         double (&out)[B]) {
+  if (sd.kind[k] != 2) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) out[u] = sd.value[k];
+  } else if (sd.sc[k] == 0 && sd.sn[k] == 1) {               // one series for the whole bank, contiguous
+    tv_uniform_t s = (tv_uniform_t)(uintptr_t)(sd.series[k] + n0);
+#pragma unroll
+    for (int u = 0; u < B; ++u) out[u] = (FULL || u < cnt) ? s[u] : 0.0;
+  } else if (sd.sc[k] == 0) {                                 // one series for the whole bank, strided
+    tv_uniform_t s = (tv_uniform_t)(uintptr_t)(sd.series[k] + n0 * sd.sn[k]);
+    const int64_t sn = sd.sn[k];
+#pragma unroll
+    for (int u = 0; u < B; ++u) out[u] = (FULL || u < cnt) ? s[u * sn] : 0.0;
+  } else {                                                    // a series per channel
+    const char *q = (const char *)(sd.series[k] + c * sd.sc[k] + n0 * sd.sn[k]);
+    const int64_t step = sd.sn[k] * 8;
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      out[u] = (FULL || u < cnt) ? *(const double *)q : 0.0;
+      q += step;
+    }
+  }
+  if (negate_back && sd.kind[k] == 2) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) out[u] = -out[u];
+  }
+}
+
+template <unsigned PB, unsigned PA, int B>
+__global__ __launch_bounds__(64) void k_tvp(TvArgs p) {
+  constexpr int NB = 3, NA = 3;
+  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.channels) return;
+  double d[NB], m[NA];            // d[k] = x[n-k], m[k] = y[n-k]  (d[0], m[0] are scratch)
+#pragma unroll
+  for (int k = 1; k < NB; ++k) d[k] = (k < p.nb) ? p.xh[(int64_t)(k - 1) * p.channels + c] : 0.0;
+#pragma unroll
+  for (int k = 1; k < NA; ++k) m[k] = (k < p.na) ? p.yh[(int64_t)(k - 1) * p.channels + c] : 0.0;
+  const double gain = p.gain;
+  const char *xp = (const char *)(p.x + c * p.sxc);
+  char *yp = (char *)(p.y + c * p.syc);
+  const int64_t sx8 = p.sxn * 8, sy8 = p.syn * 8;
+
+  auto batch = [&](auto full_tag, int64_t n0, int cnt) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    double xv[B], cb[NB][B], ca[NA][B];
+    {
+      const char *q = xp + n0 * sx8;
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        xv[u] = (FULL || u < cnt) ? *(const double *)q : 0.0;
+        q += sx8;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if ((PB >> k) & 1u) tvp_fill<FULL, B>(p.b, k, c, n0, cnt, false, cb[k]);
+#pragma unroll
+    for (int k = 1; k < NA; ++k)
+      if ((PA >> (k - 1)) & 1u) tvp_fill<FULL, B>(p.a, k, c, n0, cnt, p.a.negated[k] != 0, ca[k]);
+    auto steps = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;         // 0 none, 1 divide, 2 negate
+      char *q = yp + n0 * sy8;
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        d[0] = xv[u];
+        double acc = -0.0;         // additive identity: the first present term initialises the sum
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+          if ((PB >> k) & 1u) acc = acc + cb[k][u] * d[k];
+#pragma unroll
+        for (int k = 1; k < NA; ++k)
+          if ((PA >> (k - 1)) & 1u) acc = acc - ca[k][u] * m[k];
+        if constexpr (MODE == 1) acc = acc / gain;
+        if constexpr (MODE == 2) acc = -acc;
+        if (FULL || u < cnt) {
+          *(double *)q = acc;
+          q += sy8;
+#pragma unroll
+          for (int k = NA - 1; k > 1; --k) m[k] = m[k - 1];
+          m[1] = acc;
+#pragma unroll
+          for (int k = NB - 1; k > 0; --k) d[k] = d[k - 1];
+        }
+      }
+    };
+    if (p.gain_mode == 0) steps(std::integral_constant<int, 0>{});
+    else if (p.gain_mode == 1) steps(std::integral_constant<int, 1>{});
+    else steps(std::integral_constant<int, 2>{});
+  };
+  int64_t n0 = 0;
+  for (; n0 + B <= p.n; n0 += B) batch(std::true_type{}, n0, B);
+  if (n0 < p.n) batch(std::false_type{}, n0, (int)(p.n - n0));
 #pragma unroll
   for (int k = 1; k < NB; ++k)
     if (k < p.nb) p.xh[(int64_t)(k - 1) * p.channels + c] = d[k];
@@ -363,7 +494,9 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     for (int k = 0; k < 3; ++k) pb |= (p.b.kind[k] != 0) << k;
     for (int k = 1; k < 3; ++k) pa |= (p.a.kind[k] != 0) << (k - 1);
     void (*fn)(alz::TvArgs) = alz::k_tv<3, 3, 16>;
-#define ALZ_TV_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) fn = alz::k_tv<3, 3, 16, PB_, PA_>;
+    static const bool old_env = getenv("ALZ_TV_OLD") != nullptr;   // A/B: the first version of the pattern kernels
+#define ALZ_TV_PAT(PB_, PA_) \
+  if (pb == PB_ && pa == PA_) fn = old_env ? alz::k_tv<3, 3, 16, PB_, PA_> : alz::k_tvp<PB_, PA_, ALZ_TVP_B>;
     ALZ_TV_PAT(1, 1) ALZ_TV_PAT(3, 1) ALZ_TV_PAT(1, 3) ALZ_TV_PAT(3, 3) ALZ_TV_PAT(5, 3) ALZ_TV_PAT(7, 3)
     ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
 #undef ALZ_TV_PAT
