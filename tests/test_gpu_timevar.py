@@ -92,3 +92,79 @@ def test_multichannel_block(al, layout):
   for ch in (0, 1, 33, 69):
     ref = oracle.tv_df1([b0, -.5], [2., a1[:, ch], a2], x[:, ch], zero=.25)
     assert same_bits(y[:, ch], ref), ch
+
+
+# ---------------------------------------------------------------------------------------------------
+# Differential fuzz of alz_tv_process_dev through the raw C ABI: every curated presence pattern (k_tvp),
+# other shapes (k_tv), every way a tap can get its values (constant, series shared by the bank --
+# contiguous or strided --, series per channel, series the host already negated), the three gain
+# modes, batch-ragged lengths, both layouts; against the pure-Python restatement, bit for bit.
+# ---------------------------------------------------------------------------------------------------
+PATTERNS = [(1, 1), (3, 1), (1, 3), (3, 3), (5, 3), (7, 3), (1, 2), (1, 0), (2, 0), (3, 0), (4, 0), (7, 0),
+            (6, 3), (5, 1)]                       # the last two are not curated: the general kernel
+
+
+@pytest.mark.parametrize("case", range(56))
+def test_raw_abi_fuzz(al, case):
+  import ctypes
+  import torch
+  from audiolazy_amd import _ffi
+  rng = np.random.default_rng(1000 + case)
+  pb, pa = PATTERNS[case % len(PATTERNS)]
+  N = int(rng.choice([1, 5, 15, 16, 17, 31, 32, 50, 100]))
+  C = int(rng.choice([2, 3, 64, 70]))
+  layout = "time" if rng.random() < .6 else "chan"
+  gain = float(rng.choice([1.0, -1.0, 2.5]))
+  nb = max(k + 1 for k in range(3) if (pb >> k) & 1)
+  na = 1 + max([k for k in (1, 2) if (pa >> (k - 1)) & 1], default=0)
+  L = _ffi.load()
+  keep, ref_b, ref_a = [], [], []
+  x = rng.uniform(-1, 1, (N, C))
+
+  def make_tap(present, is_a):
+    """-> (TvTap, reference value: float or [N] or [N, C] array of what the tap IS, sign as the reference sees it)"""
+    if not present:
+      return _ffi.TvTap(0.0, None, 0, 0, 0), 0.0
+    how = rng.choice(["const", "shared", "strided", "lane", "negated"] if is_a else ["const", "shared", "strided", "lane"])
+    if how == "const":
+      v = float(rng.uniform(-.9, .9)) or .5
+      return _ffi.TvTap(v, None, 0, 0, 0), v
+    if how in ("shared", "negated"):
+      vals = rng.uniform(-.9, .9, N)
+      held = -vals if how == "negated" else vals           # what the device buffer holds
+      t = torch.from_numpy(held.copy()).cuda(); keep.append(t)
+      return _ffi.TvTap(0.0, t.data_ptr(), 1, 0, _ffi.TV_NEGATED if how == "negated" else 0), vals
+    if how == "strided":
+      vals = rng.uniform(-.9, .9, N)
+      buf = np.zeros(3 * N); buf[::3] = vals
+      t = torch.from_numpy(buf).cuda(); keep.append(t)
+      return _ffi.TvTap(0.0, t.data_ptr(), 3, 0, 0), vals
+    vals = rng.uniform(-.9, .9, (N, C))
+    arr = vals if layout == "time" else vals.T
+    t = torch.from_numpy(np.ascontiguousarray(arr)).cuda(); keep.append(t)
+    return _ffi.TvTap(0.0, t.data_ptr(), *((C, 1) if layout == "time" else (1, N)), 0), vals
+
+  tb = (_ffi.TvTap * nb)()
+  for k in range(nb):
+    tb[k], v = make_tap((pb >> k) & 1, False); ref_b.append(v)
+  ta = (_ffi.TvTap * na)()
+  ta[0] = _ffi.TvTap(gain, None, 0, 0, 0); ref_a.append(gain)
+  for k in range(1, na):
+    ta[k], v = make_tap((pa >> (k - 1)) & 1, True); ref_a.append(v)
+  xd = torch.from_numpy(np.ascontiguousarray(x if layout == "time" else x.T)).cuda()
+  y = torch.empty_like(xd)
+  xh = torch.full((max(nb - 1, 1), C), .125, dtype=torch.float64, device="cuda")
+  yh = torch.full((max(na - 1, 1), C), .125, dtype=torch.float64, device="cuda")
+  lay = _ffi.TIME_MAJOR if layout == "time" else _ffi.CHAN_MAJOR
+  ld = C if layout == "time" else N
+  stream = torch.cuda.current_stream().cuda_stream
+  _ffi.check(L.alz_tv_process_dev(nb, ctypes.cast(tb, ctypes.c_void_p), na, ctypes.cast(ta, ctypes.c_void_p), C,
+                                  xd.data_ptr(), y.data_ptr(), N, lay, ld, ld, xh.data_ptr(), yh.data_ptr(),
+                                  .125, 0, ctypes.c_void_p(stream)))
+  torch.cuda.synchronize()
+  got = y.cpu().numpy()
+  got = got if layout == "time" else got.T
+  for ch in sorted(set([0, 1, C // 2, C - 1])):
+    pick = lambda v: v[:, ch] if isinstance(v, np.ndarray) and v.ndim == 2 else v
+    ref = oracle.tv_df1([pick(v) for v in ref_b], [pick(v) for v in ref_a], x[:, ch], memory=[.125] * (na - 1), zero=.125)
+    assert same_bits(got[:, ch], ref), (case, pb, pa, N, C, layout, gain, ch)
