@@ -178,6 +178,9 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
 #define ALZ_TVP_B 16   // samples per batch (12 and 8 measured slower or equal)
 #endif
 typedef const double __attribute__((address_space(4))) *tv_uniform_t;
+typedef double tv_vec8 __attribute__((ext_vector_type(8)));
+typedef tv_vec8 tv_vec8_u __attribute__((aligned(8)));        // a series starts wherever the batch does
+typedef const tv_vec8_u __attribute__((address_space(4))) *tv_uniform8_t;
 
 template <bool FULL, int B>
 __device__ __forceinline__ void tvp_fill(const TvSide &sd, int k, int64_t c, int64_t n0, int cnt, bool negate_back,
@@ -185,16 +188,7 @@ __device__ __forceinline__ void tvp_fill(const TvSide &sd, int k, int64_t c, int
   if (sd.kind[k] != 2) {
 #pragma unroll
     for (int u = 0; u < B; ++u) out[u] = sd.value[k];
-  } else if (sd.sc[k] == 0 && sd.sn[k] == 1) {               // one series for the whole bank, contiguous
-    tv_uniform_t s = (tv_uniform_t)(uintptr_t)(sd.series[k] + n0);
-#pragma unroll
-    for (int u = 0; u < B; ++u) out[u] = (FULL || u < cnt) ? s[u] : 0.0;
-  } else if (sd.sc[k] == 0) {                                 // one series for the whole bank, strided
-    tv_uniform_t s = (tv_uniform_t)(uintptr_t)(sd.series[k] + n0 * sd.sn[k]);
-    const int64_t sn = sd.sn[k];
-#pragma unroll
-    for (int u = 0; u < B; ++u) out[u] = (FULL || u < cnt) ? s[u * sn] : 0.0;
-  } else {                                                    // a series per channel
+  } else {                                   // a series: per channel, or one for the bank (channel stride 0)
     const char *q = (const char *)(sd.series[k] + c * sd.sc[k] + n0 * sd.sn[k]);
     const int64_t step = sd.sn[k] * 8;
 #pragma unroll
@@ -224,23 +218,25 @@ __global__ __launch_bounds__(64) void k_tvp(TvArgs p) {
   char *yp = (char *)(p.y + c * p.syc);
   const int64_t sx8 = p.sxn * 8, sy8 = p.syn * 8;
 
-  auto batch = [&](auto full_tag, int64_t n0, int cnt) {
+  auto load_x = [&](auto full_tag, int64_t n0, int cnt, double (&xv)[B]) {
     constexpr bool FULL = decltype(full_tag)::value;
-    double xv[B], cb[NB][B], ca[NA][B];
-    {
-      const char *q = xp + n0 * sx8;
+    const char *q = xp + n0 * sx8;
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        xv[u] = (FULL || u < cnt) ? *(const double *)q : 0.0;
-        q += sx8;
-      }
+    for (int u = 0; u < B; ++u) {
+      xv[u] = (FULL || u < cnt) ? *(const double *)q : 0.0;
+      q += sx8;
     }
+  };
+  auto batch = [&](auto full_tag, int64_t n0, int cnt, double (&xv)[B], auto look_ahead) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    double cb[NB][B], ca[NA][B];
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if ((PB >> k) & 1u) tvp_fill<FULL, B>(p.b, k, c, n0, cnt, false, cb[k]);
 #pragma unroll
     for (int k = 1; k < NA; ++k)
       if ((PA >> (k - 1)) & 1u) tvp_fill<FULL, B>(p.a, k, c, n0, cnt, p.a.negated[k] != 0, ca[k]);
+    look_ahead();
     auto steps = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;         // 0 none, 1 divide, 2 negate
       char *q = yp + n0 * sy8;
@@ -271,9 +267,27 @@ __global__ __launch_bounds__(64) void k_tvp(TvArgs p) {
     else if (p.gain_mode == 1) steps(std::integral_constant<int, 1>{});
     else steps(std::integral_constant<int, 2>{});
   };
-  int64_t n0 = 0;
-  for (; n0 + B <= p.n; n0 += B) batch(std::true_type{}, n0, B);
-  if (n0 < p.n) batch(std::false_type{}, n0, (int)(p.n - n0));
+  // The input rows of the NEXT full batch are requested before the steps of the current one (two
+  // register sets that swap roles), unconditionally -- the last batch is requested twice: behind a
+  // branch the compiler's waitcnt pass would have to drain every outstanding load at the join.
+  // A per-channel coefficient series is still loaded by the batch that uses it (its loads come
+  // before the look-ahead in program order, so waiting for them leaves the look-ahead in flight).
+  const int64_t nfull = p.n / B;
+  if (nfull > 0) {
+    double xa[B], xb[B];
+    load_x(std::true_type{}, 0, B, xa);
+    for (int64_t i = 0;;) {
+      batch(std::true_type{}, i * B, B, xa, [&] { load_x(std::true_type{}, ((i + 1 < nfull) ? i + 1 : nfull - 1) * B, B, xb); });
+      if (++i >= nfull) break;
+      batch(std::true_type{}, i * B, B, xb, [&] { load_x(std::true_type{}, ((i + 1 < nfull) ? i + 1 : nfull - 1) * B, B, xa); });
+      if (++i >= nfull) break;
+    }
+  }
+  if (nfull * B < p.n) {
+    double xt[B];
+    load_x(std::false_type{}, nfull * B, (int)(p.n - nfull * B), xt);
+    batch(std::false_type{}, nfull * B, (int)(p.n - nfull * B), xt, [] {});
+  }
 #pragma unroll
   for (int k = 1; k < NB; ++k)
     if (k < p.nb) p.xh[(int64_t)(k - 1) * p.channels + c] = d[k];
