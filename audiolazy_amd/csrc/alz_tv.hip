@@ -161,18 +161,18 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
 //  * full batches and the ragged tail are separate instantiations of the batch body (no per-step
 //    bounds tests in the full one), fully unrolled, so the delay lines rotate by renaming;
 //  * the coefficient values of a batch are put in registers BEFORE the dependent steps by one
-//    wave-uniform branch per tap and batch: a constant is copied, a series shared by the bank
-//    (channel stride 0) is read with scalar loads from the constant address space, and only a
-//    per-channel series costs vector loads (running pointers, no multiplies);
+//    wave-uniform branch per tap and batch: a constant is copied, a series is loaded with vector
+//    loads (running pointers, no multiplies) -- also a series shared by the bank, all lanes at one
+//    address: scalar loads from the constant address space were tried for those and cost far more
+//    than they saved (33 vs 55 Gsamples/s at 4096 channels);
+//  * the input rows of the NEXT batch are requested before the steps of the current one;
 //  * denominator terms are subtracted (acc - a_k[n] * y[n-k] is acc + (-a_k[n]) * y[n-k] bit for
 //    bit; the negation is a source modifier), so nothing is negated per value except a series the
 //    host already negated (ALZ_TV_NEGATED, the int-0 rule), which is negated back;
 //  * the gain mode (none / negate / divide) picks one of three step bodies per batch.
-// Same terms, same order, same roundings as k_tv.  Tried on top of this and not kept: the next
-// batch's loads issued before the steps of the current one (two register sets, compiler-untracked
-// loads with a counted s_waitcnt; staging shared series in SGPRs) -- slower, the scalar loads and
-// SGPR spills cost more than the latency they hid (19 vs 27 Gsamples/s at 4096 channels); a second
-// wave per block touching the rows a few batches ahead; narrower waves (4..32 channels per wave).
+// Same terms, same order, same roundings as k_tv.  Also tried and not kept: look-ahead
+// for the series too (two full register sets), compiler-untracked look-ahead loads with a counted
+// s_waitcnt, shared series staged in SGPRs, a second wave per block touching rows ahead, narrower waves.
 // ---------------------------------------------------------------------------
 #ifndef ALZ_TVP_B
 #define ALZ_TVP_B 16   // samples per batch (12 and 8 measured slower or equal)
