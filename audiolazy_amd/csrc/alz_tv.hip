@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_tv(TvArgs p) {
 // s_waitcnt, shared series staged in SGPRs, a second wave per block touching rows ahead, narrower waves.
 // ---------------------------------------------------------------------------
 #ifndef ALZ_TVP_B
-#define ALZ_TVP_B 16   // samples per batch (12 and 8 measured slower or equal)
+#define ALZ_TVP_B 16   // samples per batch (8 and 12 measured slower, 24 equal)
 #endif
 typedef const double __attribute__((address_space(4))) *tv_uniform_t;
 typedef double tv_vec8 __attribute__((ext_vector_type(8)));
