@@ -7,14 +7,13 @@ moving average).  The elementwise pre/post stages are plain
 lazy Stream operations (the same CPython float operations as the reference, so the results
 are identical); the lowpass / moving-average filter in the middle runs on the GPU engine.
 """
-import collections
 import math
 
 from .filters import z, lowpass
 from .strategy import StrategyDict
 from .stream import Stream
 
-__all__ = ["envelope", "maverage", "amdf"]
+__all__ = ["envelope", "maverage", "amdf", "clip"]
 
 envelope = StrategyDict("envelope")
 
@@ -42,26 +41,31 @@ envelope.default = envelope.rms
 maverage = StrategyDict("maverage")
 
 
+def _running_mean(sig, size, zero):
+  """Running sum over a ring of the last ``size`` scaled samples: per input item, the oldest term
+  leaves the sum, the new one (``item * (1 / size)``) enters it -- in that order, which fixes the
+  roundings (reference :553-565)."""
+  scale = 1. / size
+  ring, at = [zero * scale] * size, 0
+  acc = zero
+  for item in sig:
+    acc -= ring[at]
+    term = item * scale
+    ring[at] = term
+    at = at + 1 if at + 1 < size else 0
+    acc += term
+    yield acc
+
+
 @maverage.strategy("deque")
 def maverage(size):
-  """Moving average kept as a running sum over a deque of ``x / size`` terms (reference :525-559):
-  a callable ``(sig, zero=0.) -> Stream``.  Not a filter object (no algebra, no frequency
-  response) and, being a running sum, not the same roundings as the filter strategies; it runs
-  on the host exactly like the reference's."""
-  size_inv = 1. / size
-
-  def maverage_filter(sig, zero=0.):
-    def gen():
-      data = collections.deque((zero * size_inv for _ in range(size)), maxlen=size)
-      mean_value = zero
-      for el in sig:
-        mean_value -= data.popleft()
-        new_value = el * size_inv
-        data.append(new_value)
-        mean_value += new_value
-        yield mean_value
-    return Stream(gen())
-  return maverage_filter
+  """Moving average kept as a running sum of ``x / size`` terms (reference :525-566): a callable
+  ``(sig, zero=0.) -> Stream``.  Not a filter object (no algebra, no frequency response) and,
+  being a running sum, not the same roundings as the filter strategies; it runs on the host like
+  the reference's."""
+  if size < 1:
+    raise IndexError("pop from an empty deque")      # what the reference's empty window raises
+  return lambda sig, zero=0.: Stream(_running_mean(sig, size, zero))
 
 
 @maverage.strategy("recursive", "feedback")
@@ -80,11 +84,38 @@ maverage.default = maverage.deque
 
 
 def amdf(lag, size):
-  """Average Magnitude Difference Function for a fixed lag (reference :677-716): the comb
-  difference ``(1 - z ** -lag).linearize()`` on the GPU engine, ``abs``, then ``maverage(size)``.
-  Returns a callable ``(sig, zero=0.) -> Stream``."""
-  filt = (1 - z ** -lag).linearize()
+  """Average Magnitude Difference Function for a fixed lag (reference :677-716): the magnitude of
+  the comb difference ``x[n] - x[n - lag]`` (on the GPU engine), averaged over ``size`` samples by
+  whatever ``maverage``'s default strategy is when the result is called.  Returns a callable
+  ``(sig, zero=0.) -> Stream``."""
+  difference = (1 - z ** -lag).linearize()
 
-  def amdf_filter(sig, zero=0.):
-    return maverage(size)(abs(filt(sig, zero=zero)), zero=zero)
-  return amdf_filter
+  def run(sig, zero=0.):
+    magnitude = abs(difference(sig, zero=zero))
+    return maverage(size)(magnitude, zero=zero)
+  return run
+
+
+def _clip_rule(low, high):
+  """The per-item rule of ``clip`` as (kind, function); the three kinds differ in what happens to
+  a NaN and to an item equal to a limit, so they are kept apart exactly as the reference's three
+  expressions do (:638-647): one-sided rules keep an item only if it is strictly inside (a NaN
+  becomes the limit), the two-sided rule replaces an item only if it is strictly outside (a NaN
+  passes)."""
+  if low is None and high is None:
+    return "none", None
+  if low is None:
+    return "high", lambda v: v if v < high else high
+  if high is None:
+    return "low", lambda v: v if v > low else low
+  if high < low:
+    raise ValueError("Higher clipping limit is smaller than lower one")
+  return "both", lambda v: high if v > high else (low if v < low else v)
+
+
+def clip(sig, low=-1., high=1.):
+  """Saturate a signal at ``low`` / ``high`` (either may be None: one-sided, or no clipping at
+  all); ``high < low`` is a ValueError (reference :619-647).  Host-side Stream form;
+  :func:`audiolazy_amd.maps.clip_block` applies the same rules to device blocks."""
+  kind, rule = _clip_rule(low, high)
+  return Stream(sig) if kind == "none" else Stream(sig).map(rule)

@@ -13,6 +13,7 @@ here: without the library or a GPU the calls raise.
 """
 import ctypes
 import itertools
+import weakref
 
 import numpy as np
 
@@ -93,6 +94,41 @@ def memory_to_hist(memory, lm, zero=0.0):
   if len(out) < lm:
     out = [zero] * (lm - len(out)) + out
   return out
+
+
+def stage_memories(memory, nas, zero=0.0):
+  """``memory`` as every cascade stage sees it: one [m1 .. m_lm] list per stage (each stage gets
+  the same argument, reference lazy_filters.py:989, and applies the padding rule with its own
+  order; a callable is called once per stage).  None stays None.  Evaluated at call time, like
+  the reference evaluates ``memory`` before it builds its generator (:185-195)."""
+  if memory is None:
+    return None
+  if callable(memory) and not hasattr(memory, "__iter__"):
+    return [memory_to_hist(memory, na - 1, zero) for na in nas]
+  items = list(itertools.islice(iter(memory), max(max(nas) - 1, 0)))
+  return [memory_to_hist(items, na - 1, zero) for na in nas]
+
+
+def call_sections(sections, seq, memory=None, zero=0., block=None):
+  """The filter call protocol for one cascade of LTI sections [(b, a), ...]: ``memory`` is read
+  now, the input is not touched until the result is iterated (the reference's generator pulls
+  its first sample at the first ``next``); the first item then tells whether samples are scalars
+  or rows of C values (C parallel streams, reference tests/test_filters_extdep.py:49-89)."""
+  from .stream import Stream
+  hists = stage_memories(memory, [len(a) for _, a in sections], zero)
+
+  def gen():
+    it = iter(seq)
+    for first in it:
+      break
+    else:
+      return
+    n_inputs = len(first) if hasattr(first, "__len__") else 1
+    bank = FilterBank(sections, n_inputs=n_inputs)
+    bank.reset(zero=zero, _hists=hists)
+    for item in bank._run(itertools.chain([first], it), block):
+      yield item
+  return Stream(gen())
 
 
 def mix_sets(y, n_sets, n_inputs, layout="time", out=None, device=0):
@@ -240,6 +276,8 @@ class FilterBank(object):
                                  self.a.ctypes.data_as(_dp), self.device, ctypes.byref(handle)))
     self._h = handle
     self._L = L
+    self._live = None      # weak reference to the generator of the latest __call__
+    self._fused = False
 
   # -- construction helpers ------------------------------------------------
   @classmethod
@@ -273,12 +311,14 @@ class FilterBank(object):
         pass
 
   # -- state ---------------------------------------------------------------
-  def reset(self, memory=None, zero=0.0):
+  def reset(self, memory=None, zero=0.0, _hists=None):
     """Start a new stream: the reference's ``memory`` / ``zero`` call arguments
     (lazy_filters.py:149-157, 185-195, 243-250), forwarded unchanged to every
     cascade stage like CascadeFilter does (:989)."""
     zero_arr = np.asarray(zero, dtype=np.float64)
-    if memory is None and zero_arr.ndim == 0:
+    if _hists is None:
+      _hists = stage_memories(memory, self.na, zero)
+    if _hists is None and zero_arr.ndim == 0:
       _ffi.check(self._L.alz_bank_reset(self._h, float(zero)))
       return
     _ffi.check(self._L.alz_bank_reset(self._h, float(zero_arr.ravel()[0]) if zero_arr.size else 0.0))
@@ -287,19 +327,11 @@ class FilterBank(object):
     xh = np.repeat(zc[:, None], max(self.thx, 1), axis=1).copy()
     yh = np.empty((C, max(self.thy, 1)))
     off = 0
-    if callable(memory) and not hasattr(memory, "__iter__"):
-      mem_items = None
-    else:
-      mem_items = None if memory is None else list(itertools.islice(iter(memory), max(self.na) - 1))
-    for na in self.na:
-      lm = na - 1
-      if memory is not None and mem_items is None:
-        hist = memory_to_hist(memory, lm, zero)   # callable: called once per stage
-      else:
-        hist = memory_to_hist(mem_items, lm, zero)
+    for s_i, na in enumerate(self.na):
+      hist = [zero] * (na - 1) if _hists is None else _hists[s_i]
       for k, item in enumerate(hist):
         yh[:, off + k] = np.broadcast_to(np.asarray(item, dtype=np.float64), (C,))
-      off += lm
+      off += na - 1
     self.set_state(xh, yh)
 
   def set_state(self, xh, yh):
@@ -322,6 +354,7 @@ class FilterBank(object):
     two fused ops instead of four), no longer bit-identical to the reference (differences around
     1e-13 normalised; the contract is 1e-6).  Off by default."""
     _ffi.check(self._L.alz_bank_set_fused(self._h, 1 if on else 0))
+    self._fused = bool(on)
     return self
 
   @property
@@ -399,30 +432,48 @@ class FilterBank(object):
     sample).
     """
     from .stream import Stream
-    self.reset(memory=memory, zero=zero)
+    # every call owns its state, like every reference call owns its generator's locals: while a
+    # Stream of an earlier call is still alive the new call runs on a copy of the bank
+    live = self._live() if self._live is not None else None
+    runner = self._clone() if (live is not None and live.gi_frame is not None) else self
+    runner.reset(memory=memory, zero=zero)
+    g = runner._run(seq, block)
+    runner._live = weakref.ref(g)
+    return Stream(g)
+
+  def _clone(self):
+    """A bank with the same coefficients and its own device state."""
+    edges_b, edges_a = np.cumsum([0] + self.nb), np.cumsum([0] + self.na)
+    secs = [(self.b[:, edges_b[i]:edges_b[i + 1]], self.a[:, edges_a[i]:edges_a[i + 1]])
+            for i in range(len(self.nb))]
+    twin = FilterBank(secs, n_inputs=self.n_inputs, mode=self.mode, device=self.device)
+    if self._fused:
+      twin.set_fused(True)
+    return twin
+
+  def _run(self, seq, block=None):
+    """Generator behind the call protocol: pulls ``block`` items, filters them, yields them."""
     scalar_out = self.channels == 1
     block = block_size() if block is None else block
-
-    def gen():
-      it = iter(seq)
-      scalars = False
-      if self.n_inputs == 1:      # scalar items go through np.fromiter: no list of Python floats
-        for first in it:
-          scalars = not hasattr(first, "__len__")
-          it = itertools.chain([first], it)
-          break
-      while True:
-        if scalars:
-          x = np.fromiter(itertools.islice(it, block), dtype=np.float64).reshape(-1, 1)
-        else:
-          chunk = list(itertools.islice(it, block))
-          x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), self.n_inputs)
-        if x.shape[0] == 0:
-          return
-        y = self.process(x, layout="time")
-        if scalar_out:
-          yield from y[:, 0].tolist()
-        else:
-          for row in y:
-            yield row
-    return Stream(gen())
+    it = iter(seq)
+    scalars = False
+    if self.n_inputs == 1:      # scalar items go through np.fromiter: no list of Python floats
+      for first in it:
+        scalars = not hasattr(first, "__len__")
+        it = itertools.chain([first], it)
+        break
+    while True:
+      if scalars:
+        x = np.fromiter(itertools.islice(it, block), dtype=np.float64).reshape(-1, 1)
+      else:
+        chunk = list(itertools.islice(it, block))
+        x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), self.n_inputs)
+      if x.shape[0] == 0:
+        return
+      y = self.process(x, layout="time")
+      if scalar_out:
+        for v in y[:, 0].tolist():
+          yield v
+      else:
+        for row in y:
+          yield row

@@ -3,7 +3,10 @@
 // every process call launches HIP kernels or fails.
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
+#include <tuple>
 
 #include "alz_common.h"
 
@@ -15,6 +18,19 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
+}
+
+int ensure_dynamic_lds(const void *fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void *, int>, int> done;   // (kernel, device) -> largest size set
+  int dev = 0;
+  ALZ_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  int &have = done[std::make_tuple(fn, dev)];
+  if (have >= bytes) return ALZ_OK;
+  ALZ_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+  return ALZ_OK;
 }
 
 }  // namespace alz

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
 #pragma unroll
         for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kCSlot + j * 1040);
       };
-      const bool on = !(p.dbg & 1);
+      const bool on = !ALZ_DBG(p, 1);
       for (int t = 0; t < D && t < nt && on; ++t) queue_tile(t);
       {
         const int64_t after = ((nt < D ? nt : D) - 1);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
     } else {
       __builtin_amdgcn_s_barrier();
       for (int64_t t = 0; t < n_iv; ++t) {
-        if (t >= store_lag && t - store_lag < nt && !(p.dbg & 4)) {
+        if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4)) {
           const int64_t tt = t - store_lag;
           const char *ys = yring + (int)(tt % 2) * kCSlot;
           double *yt = yg + tt * y_tile;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       }
     };
     auto do_sections = [&](double (&v)[16]) {
-      if (!(p.dbg & 2)) {
+      if (!ALZ_DBG(p, 2)) {
         if constexpr (SPW == 2) {
           if (wave == 0)
             section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1>(
@@ -655,7 +655,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = tiles;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
   p.c_first = 0; p.mode = io.mode; p.nsec = nsec;
-  static const int dbg_env = getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0;
+  static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
@@ -663,12 +663,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   }
   const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * kCSlot : (size_t)kCRing * kCSlot;
   if (pipe) {
-    static bool attr[2][3][3] = {};
-    const int pi = pb[0] == 3 ? 0 : pb[0] == 5 ? 1 : 2;
-    if (!attr[cm][pi][pipe_env]) {
-      ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr[cm][pi][pipe_env] = true;
-    }
+    const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 64 * pipe_waves : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());

@@ -8,6 +8,17 @@
 
 #include "../../include/alz.h"
 
+// Ablation switches (timing experiments that produce WRONG output) exist only in builds made with
+// -DALZ_ABLATE (tools/variant builds loaded through ALZ_LIBRARY); in the shipped library the tests
+// below are compile-time false and ALZ_WAVE_DEBUG in the environment does nothing.
+#ifdef ALZ_ABLATE
+#define ALZ_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#define ALZ_DBG_ENV() (getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0)
+#else
+#define ALZ_DBG(p, bit) false
+#define ALZ_DBG_ENV() 0
+#endif
+
 namespace alz {
 
 // thread-local last-error message (alz_last_error)
@@ -20,6 +31,11 @@ int fail(int code, const std::string &msg);
     if (e__ != hipSuccess)                                                               \
       return ::alz::fail(ALZ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernel `fn` on the CURRENT device, remembered
+// per (kernel, device, size) under a mutex: a process may drive several devices and several
+// threads may create banks at once (alz_api.hip).
+int ensure_dynamic_lds(const void *fn, int bytes);
 
 // One cascaded section as the kernels see it.  Device arrays are tap-major so
 // that lane == channel reads are coalesced:

@@ -238,9 +238,13 @@ __global__ __launch_bounds__(64) void k_generic(KArgs p, double *xh_new, double 
   }
 }
 
-__global__ void k_copy_state(double *dst, const double *src, int64_t count) {
+// rows [0, rows) x channels [c_first, c_first + c_count) of a [rows][channels] state slab
+__global__ void k_copy_state(double *dst, const double *src, int64_t rows, int64_t channels,
+                             int64_t c_first, int64_t c_count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) dst[i] = src[i];
+  if (i >= rows * c_count) return;
+  const int64_t at = (i / c_count) * channels + c_first + i % c_count;
+  dst[at] = src[at];
 }
 
 // ---------------------------------------------------------------------------
@@ -317,12 +321,14 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
     const int64_t ny = (int64_t)(sec.na - 1) * io.channels;
     double *xh_new = sec.xh + nx, *yh_new = sec.yh + ny;
     hipLaunchKernelGGL(k_generic, grid, block, 0, stream, p, xh_new, yh_new);
-    if (nx > 0)
-      hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream,
-                         sec.xh, xh_new, nx);
-    if (ny > 0)
-      hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, stream,
-                         sec.yh, yh_new, ny);
+    // only the channels this launch covered have a new history (the others' rows are stale)
+    const int64_t cx = (int64_t)(sec.nb - 1) * io.c_count, cy = (int64_t)(sec.na - 1) * io.c_count;
+    if (cx > 0)
+      hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((cx + 255) / 256)), dim3(256), 0, stream,
+                         sec.xh, xh_new, (int64_t)(sec.nb - 1), io.channels, io.c_first, io.c_count);
+    if (cy > 0)
+      hipLaunchKernelGGL(k_copy_state, dim3((unsigned)((cy + 255) / 256)), dim3(256), 0, stream,
+                         sec.yh, yh_new, (int64_t)(sec.na - 1), io.channels, io.c_first, io.c_count);
     *kernel_name = "k_generic";
   }
   ALZ_HIP_CHECK(hipGetLastError());

@@ -145,6 +145,21 @@ __global__ __launch_bounds__(64) void k_acorr_dense(const double *__restrict__ s
   r_out[idx] = acc;
 }
 
+// k_acorr_global: the same (frame, lag) pairs straight from global memory -- the catch-all for
+// frames too long to stage (acorr's default lag list is the whole block, lazy_analysis.py:309-310).
+__global__ __launch_bounds__(64) void k_acorr_global(const double *__restrict__ sig, int64_t n_frames,
+                                                      int frame_len, int64_t hop, int P,
+                                                      double *__restrict__ r_out) {
+  const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (idx >= n_frames * P) return;
+  const int64_t f = idx / P;
+  const int i = (int)(idx - f * P);
+  const double *fr = sig + f * hop;
+  double acc = 0.0;
+  for (int n = 0; n < frame_len - i; ++n) acc = acc + fr[n] * fr[n + i];
+  r_out[idx] = acc;
+}
+
 // k_acorr_lane<P>: one lane per frame, P = max_lag + 1 accumulators per lane.  Per sample the
 // lane needs ONE new value (its window fr[n .. n+P-1] slides in registers, rotated by unrolling
 // P steps) for P multiply-adds: no LDS, no cross-lane traffic, f64-issue-bound.  Every lag still
@@ -423,11 +438,15 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_lane launch failed");
     return true;
   }
-  if (P > 64) return false;
-  const int nfr_max = 64 / P + 2;
+  const int nfr_max = 64 / P + 2;     // frames one wave's 64 (frame, lag) pairs can touch
   const size_t lds = (size_t)nfr_max * (((frame_len + 15) / 32) * 32 + 16) * sizeof(double);
-  if (lds > 64 * 1024) return false;
   const int64_t total = n_frames * P;
+  if (lds > 64 * 1024) {
+    hipLaunchKernelGGL(k_acorr_global, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, sig, n_frames,
+                       frame_len, hop, P, r_out);
+    if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_global launch failed");
+    return true;
+  }
   hipLaunchKernelGGL(k_acorr_dense, dim3((unsigned)((total + 63) / 64)), dim3(64), lds, st, sig, n_frames,
                      frame_len, hop, P, r_out);
   if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_dense launch failed");

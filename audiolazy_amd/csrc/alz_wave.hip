@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   const int64_t nt = p.n_tiles;
 
   // prologue: tiles 0 .. kRing-2 into slots 0 .. kRing-2
-  for (int t = 0; t < kRing - 1 && t < nt && !(p.dbg & 1); ++t) {
+  for (int t = 0; t < kRing - 1 && t < nt && !ALZ_DBG(p, 1); ++t) {
 #pragma unroll
     for (int j = 0; j < kChunks; ++j)
       dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     const int slot = (int)(i % kRing);
     // refill the slot freed by tile i-1 with tile i+kRing-1
     const int64_t tn = i + kRing - 1;
-    if (tn < nt && !(p.dbg & 1)) {
+    if (tn < nt && !ALZ_DBG(p, 1)) {
       const int sn = (int)(tn % kRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     }
 
     char *tile = smem + slot * kSlotBytes;
-    if (!(p.dbg & 2)) {
+    if (!ALZ_DBG(p, 2)) {
       // element e(u) = u*G + cl (TIME) or cl*T + u (CHAN); byte = e*8 + (e/128)*16 (chunk pad)
       // (T and G divide 128, so the pad term splits into a per-lane part and a per-u part)
       const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     // the finished tile leaves as eight 1 KiB stores (all 64 lanes, 16 B each): all eight LDS
     // reads are issued back to back (one exposed LDS latency per tile instead of eight)
     double *yt = yg + i * y_tile;
-    if (!(p.dbg & 4)) {
+    if (!ALZ_DBG(p, 4)) {
       dbl2 v[kChunks];
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
@@ -482,14 +482,14 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
 
-    for (int t = 0; t < kXRing - 1 && t < nt && !(p.dbg & 1); ++t) queue_tile(t);
+    for (int t = 0; t < kXRing - 1 && t < nt && !ALZ_DBG(p, 1); ++t) queue_tile(t);
     wait_vm((int)((nt < kXRing - 1 ? nt : kXRing - 1) - 1) * kChunks);   // tile 0 has landed
     feed_forward(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < nt; ++i) {
-      if (i >= 1 && !(p.dbg & 4)) store_tile(i - 1);
-      if (i + kXRing - 1 < nt && !(p.dbg & 1)) queue_tile(i + kXRing - 1);
+      if (i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+      if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
         // of the kXRing-2 tiles finished since (a count above the 6-bit vmcnt range is clamped in
@@ -497,11 +497,11 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
         const int64_t dma_after = last - (i + 1);
         const int64_t stores_after = i < kXRing - 2 ? i : kXRing - 2;
-        wait_vm((p.dbg & 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
-        if (!(p.dbg & 2)) feed_forward(i + 1);
+        wait_vm(ALZ_DBG(p, 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
+        if (!ALZ_DBG(p, 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+      if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
     }
     store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();        // y of tile i done, p of tile i+1 ready
+      if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();        // y of tile i done, p of tile i+1 ready
     }
     if (lane < G) {
       if (p.na > 1) p.yh[0 * p.channels + c] = m1;
@@ -691,20 +691,16 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.map_input = io.map_input;
   p.n_sets = io.n_sets;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
-  static const int dbg_env = getenv("ALZ_WAVE_DEBUG") ? atoi(getenv("ALZ_WAVE_DEBUG")) : 0;
+  static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
                    : (size_t)kRing * kSlotBytes;
   if (groups <= 256) lds = 96 * 1024;
-  static bool attr_set[6][2][64] = {};
-  const int gi = duo ? (sec.any_div ? 5 : io.fused ? 4 : 3) : g == 16 ? 0 : g == 32 ? 1 : 2;
-  const unsigned key = (sec.present_b << 2 | sec.present_a) & 63;
-  if (!attr_set[gi][cm][key]) {
-    ALZ_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      96 * 1024));
-    attr_set[gi][cm][key] = true;
+  {
+    const int rc = ensure_dynamic_lds((const void *)fn, 96 * 1024);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(duo ? 128 : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());

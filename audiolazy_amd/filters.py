@@ -150,18 +150,10 @@ class LinearFilter(object):
       return Stream(timevar.run(self.numlist, self.denlist, seq, memory=memory, zero=zero))
     if self.denpoly[0] == 0:
       raise ZeroDivisionError("Invalid filter gain")
-    from .bank import FilterBank
-    # the reference's vector-valued idiom: items that are rows of C values are C parallel streams
-    # through the same filter (``zero`` a row, ``memory`` a list of rows)
-    import itertools
-    it = iter(seq)
-    n_inputs = 1
-    for first in it:
-      if hasattr(first, "__len__"):
-        n_inputs = len(first)
-      it = itertools.chain([first], it)
-      break
-    return FilterBank([(self.numlist or [0.], self.denlist)], n_inputs=n_inputs)(it, memory=memory, zero=zero)
+    from .bank import call_sections
+    # (items that are rows of C values are C parallel streams through the same filter -- the
+    # reference's vector-valued idiom; call_sections looks at the first item when it is pulled)
+    return call_sections([(self.numlist or [0.], self.denlist)], seq, memory=memory, zero=zero)
 
 
 class ZFilter(LinearFilter):
@@ -350,8 +342,8 @@ class CascadeFilter(FilterList):
     seq = args[0]
     members = self.callables
     if members and all(isinstance(f, LinearFilter) and f.is_lti() for f in members):
-      from .bank import FilterBank, sections_of
-      return FilterBank(sections_of(members), n_inputs=1)(seq, *args[1:], **kwargs)
+      from .bank import call_sections, sections_of
+      return call_sections(sections_of(members), seq, *args[1:], **kwargs)
     data = seq
     for f in members:
       data = f(data, *args[1:], **kwargs)

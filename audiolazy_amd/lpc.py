@@ -80,8 +80,6 @@ def acorr(blk, max_lag=None):
     max_lag = len(blk) - 1
   if len(blk) == 0:
     return [0.] * (max_lag + 1)
-  if max_lag > 63:
-    raise NotImplementedError("acorr: more than 64 lags is outside the engine's gate")
   return acorr_frames(blk, len(blk), max_lag)[0].tolist()
 
 
@@ -116,14 +114,43 @@ def _kautocor(blk, order, device=0):
   return filt
 
 
+def _nautocor(blk, order, device=0):
+  """lpc.nautocor: the autocorrelation normal equations solved with numpy.linalg.pinv (reference
+  lazy_lpc.py:188-225).  The lags come from the GPU (bit-exact ``acorr``); the small dense solve
+  is the same NumPy call the reference makes, on the host."""
+  from .filters import ZFilter
+  lags = np.asarray(acorr(blk, order), dtype=np.float64)
+  idx = np.abs(np.subtract.outer(np.arange(order), np.arange(order)))
+  normal = lags[idx] if order > 0 else np.zeros((0, 0))
+  solved = np.dot(np.linalg.pinv(normal), -lags[1:].reshape(-1, 1)) if order > 0 else np.zeros((0, 1))
+  coefs = solved[:, 0].tolist()
+  filt = ZFilter([1] + coefs)
+  filt.error = float(lags[0]) + sum(r * c for r, c in zip(lags[1:].tolist(), coefs))
+  return filt
+
+
+def _autocor(blk, order, device=0):
+  """lpc.autocor, the reference's default strategy (lazy_lpc.py:140-185): the pseudo-inverse form
+  below order 100, Levinson-Durbin above it with the pseudo-inverse as the ParCorError fallback."""
+  if order < 100:
+    return _nautocor(blk, order, device=device)
+  try:
+    return _kautocor(blk, order, device=device)
+  except ParCorError:
+    return _nautocor(blk, order, device=device)
+
+
 def _make_lpc():
   from .strategy import StrategyDict
   sd = StrategyDict("lpc")
-  sd.strategy("kautocor")(_kautocor)
+  sd.strategy("autocor", "acorr", "autocorrelation", "auto_correlation")(_autocor)
+  sd.strategy("nautocor", "nacorr", "nautocorrelation", "nauto_correlation")(_nautocor)
+  sd.strategy("kautocor", "kacorr", "kautocorrelation", "kauto_correlation")(_kautocor)
   return sd
 
 
-# Only the strategy BASELINE/SURVEY put on the hot path is here; the reference's default
-# (``lpc.autocor`` -> numpy.linalg.pinv, lazy_lpc.py:178-225) and the covariance methods are
-# out of scope.
+# The autocorrelation-method strategies, with the reference's default (``lpc(blk, order)`` is
+# ``lpc.autocor``).  ``kautocor`` is the one BASELINE/SURVEY put on the hot path (batched:
+# ``kautocor_frames``); the covariance methods (``covar`` / ``kcovar``) are out of scope (SURVEY.md
+# section 2).
 lpc = _make_lpc()

@@ -239,44 +239,64 @@ def _mix_starts(deltas):
   return starts
 
 
+class _MixSchedule(object):
+  """State of one Streamix: the tracks not yet started (in the order added, each with its delta),
+  the voices sounding now, and the mixer's clock.  The clock is a counter that starts at 0.5,
+  gains 1 per output sample and loses a track's delta when that track starts; a track starts as
+  soon as the clock has reached its delta (`_mix_starts` is the closed form of this rule)."""
+  _END = object()
+
+  def __init__(self, zero):
+    self.pending = collections.deque()
+    self.voices = []
+    self.clock = 0.5
+    self.zero = zero
+
+  def admit_due(self):
+    while self.pending and self.pending[0][0] <= self.clock:
+      delta, voice = self.pending.popleft()
+      self.clock -= delta
+      self.voices.append(voice)
+
+  def sum_voices(self):
+    """One sample of every sounding voice added to ``zero`` in the order the voices were added;
+    voices that have ended are dropped (they contribute nothing to this sample)."""
+    total, alive = self.zero, []
+    for voice in self.voices:
+      item = next(voice, self._END)
+      if item is not self._END:
+        total += item
+        alive.append(voice)
+    self.voices = alive
+    return total
+
+
 class Streamix(Stream):
   """Stream mixer: iterables that enter at their own times, summed sample by sample in the
-  order they were added, ``data = zero; data += next(snd)`` (reference lazy_stream.py:633-724).
+  order they were added, starting from ``zero`` (reference lazy_stream.py:633-724).
   ``add(delta, data)``: ``delta`` samples (may be float) after the previously added one.
   ``keep=True`` keeps yielding ``zero`` when nothing is left to play.  For tracks that are
   arrays, :func:`audiolazy_amd.bank.mix_tracks` does the same sum on the GPU."""
 
   def __init__(self, keep=False, zero=0.):
-    self._waiting = collections.deque()
-    self._playing = []
     self.keep = keep
+    self._schedule = _MixSchedule(zero)
+    super(Streamix, self).__init__(self._samples())
 
-    def data_generator():
-      count = 0.5
-      while True:
-        while self._waiting and count >= self._waiting[0][0]:
-          delta, newdata = self._waiting.popleft()
-          self._playing.append(newdata)
-          count -= delta
-        data = zero
-        finished = []
-        for snd in self._playing:
-          try:
-            data += next(snd)
-          except StopIteration:
-            finished.append(snd)
-        for snd in finished:
-          self._playing.remove(snd)
-        if not (self.keep or self._playing or self._waiting):
-          return
-        yield data
-        count += 1.
-    super(Streamix, self).__init__(data_generator())
+  def _samples(self):
+    sched = self._schedule
+    while True:
+      sched.admit_due()
+      sample = sched.sum_voices()
+      if not (sched.voices or sched.pending or self.keep):
+        return                      # everything has played out (the last sum was of nothing)
+      yield sample
+      sched.clock += 1.
 
   def add(self, delta, data):
     if delta < 0:
       raise ValueError("Delta time should be always positive")
-    self._waiting.append((delta, iter(data)))
+    self._schedule.pending.append((delta, iter(data)))
 
 
 class StreamTeeHub(Stream):
