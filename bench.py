@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's config.
 
-Workload (configs[1]): a 4096-channel biquad IIR bank (one resonator per
-channel, 50 Hz .. 20 kHz log-spaced at 48 kHz), float64, 1 Mi-sample blocks,
-time-major [N, C] rows (the reference's vector-valued-sample layout), one
-MI355X per rank.  A "step" is one pass of the bank over one block of synthetic
-uniform(-1, 1) noise that is already resident in HBM; filter state carries over
-from step to step, so K steps are one continuous K*N-sample stream per channel.
+Primary workload (configs[1]): a 4096-channel biquad IIR bank (one resonator per channel,
+50 Hz .. 20 kHz log-spaced at 48 kHz), float64, 1 Mi-sample blocks, time-major [N, C] rows (the
+reference's vector-valued-sample layout), one MI355X per rank.  A "step" is one pass of the bank
+over one block of synthetic uniform(-1, 1) noise that is already resident in HBM; filter state
+carries over from step to step, so K steps are one continuous K*N-sample stream per channel.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; channels are
-   sharded with no data-path collective -> "scaling": "weak")
+  (N > 1: launched by torch.distributed.run, one rank per GPU; channels are sharded with no
+   data-path collective.  Default "scaling": "weak" -- every rank owns a configs[1]-sized shard of
+   an N x 4096-channel bank; --scaling strong divides configs[1]'s 4096 channels over the ranks,
+   and the default run reports that figure too, as secondary.strong_scaling.)
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries
+  "secondary":    configs[2] (FIR-256 x 8192, bit-exact and FMA mode), configs[3] (gammatone bank),
+                  configs[4] (LPC frames) and the narrow-bank (512-channel) figure, each timed with
+                  the same protocol and checked against the oracle,
+  "cpu_baseline": the reference's own CPython path (generated DF-I generator fed by random.uniform
+                  noise through a blocks(4096) consumer) on the host cores, next to the C port.
+Exit status is non-zero when any parity check says MISMATCH.
 """
 import argparse
 import json
@@ -26,25 +33,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector peak (FMA = 2 flop), same guide / SURVEY.md 8d
 ALG_BYTES_PER_SAMPLE = 16.0    # 8 B read + 8 B written per channel-sample
 
 
+# ---------------------------------------------------------------------------------------------
+# workload definitions
+# ---------------------------------------------------------------------------------------------
 def resonator_coefs(C, fs=48000.0):
-  """resonator.z_exp(fc, fc/10) per channel (reference lazy_filters.py:1245-1276),
-  designed by audiolazy_amd's own host-side mirror when present."""
+  """resonator.z_exp(fc, fc/10) per channel (reference lazy_filters.py:1245-1276), designed by
+  audiolazy_amd's own host-side mirror of the reference's closed form."""
+  from audiolazy_amd.filters import resonator
   fc = np.geomspace(50.0, 20000.0, C)
-  try:
-    from audiolazy_amd.filters import resonator
-    filts = [resonator.z_exp(2 * np.pi * f / fs, 2 * np.pi * f / 10 / fs) for f in fc]
-    b = np.array([fl.numlist for fl in filts], dtype=np.float64)
-    a = np.array([fl.denlist for fl in filts], dtype=np.float64)
-    return b, a
-  except ImportError:
-    w, bw = 2 * np.pi * fc / fs, 2 * np.pi * fc / 10 / fs
-    r = np.exp(-bw / 2)
-    a = np.stack([np.ones(C), -2 * r * np.cos(w), r * r], axis=1)
-    g = (1 - r * r) / 2
-    return np.stack([g, np.zeros(C), -g], axis=1), a
+  filts = [resonator.z_exp(2 * np.pi * f / fs, 2 * np.pi * f / 10 / fs) for f in fc]
+  b = np.array([fl.numlist for fl in filts], dtype=np.float64)
+  a = np.array([fl.denlist for fl in filts], dtype=np.float64)
+  return b, a
 
 
 def fir_taps(ntaps=256, fc=0.1):
@@ -59,119 +63,346 @@ def fir_taps(ntaps=256, fc=0.1):
   return np.array(out)
 
 
-def cpu_baseline(b, a, n_samples, budget_s=12.0):
-  """The oracle (a C port of the reference's generated loop, 1 thread) on a bounded
-  sample of the same workload: 64 channels x n_samples, repeated until ~budget_s."""
-  from oracle import oracle
-  C = 64
-  n = min(n_samples, 1 << 20)
-  rng = np.random.default_rng(1)
-  x = rng.uniform(-1, 1, (C, n))
-  sel = np.linspace(0, b.shape[0] - 1, C).astype(int)
-  bs, as_ = np.ascontiguousarray(b[sel]), np.ascontiguousarray(a[sel])
-  oracle.bank([3], [3], bs, as_, x[:, :1024], layout="chan")  # warm
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the reference's path on the host cores (rank 0, N = 1, bounded sample)
+# ---------------------------------------------------------------------------------------------
+def _py_channel(job):
+  """One process's share of the reference path: white_noise -> filt -> .blocks(4096)."""
+  from oracle import pyref
+  b, a, n, seed, passes = job
+  t0 = time.perf_counter()
+  done = 0
+  for p in range(passes):
+    done += pyref.consume_blocks(pyref.df1(b, a, pyref.noise(n, seed + p)), 4096)
+  return done, time.perf_counter() - t0
+
+
+def cpu_baseline(b, a, budget_s=3.5):
+  """Four figures, each on a bounded sample of configs[1] (about `budget_s` seconds apiece):
+    py_1proc   the reference's per-sample path, one process, one channel at a time;
+    py_pool    the same in multiprocessing.Pool(os.cpu_count()), independent seeded channels;
+    py_rows    the reference's vector-valued-sample idiom: items are ndarray rows of all C channels,
+               coefficients are repeat(ndarray) series (tests/test_filters_extdep.py:49-89) -- the
+               strongest number the unmodified reference can produce;
+    c_port     oracle/alz_oracle.c (the same DF-I statement compiled with gcc), 1 thread.
+  Must run BEFORE torch / HIP are initialised in this process (the pool forks)."""
+  import itertools
+  import multiprocessing
+  from oracle import oracle, pyref
+  C = b.shape[0]
+  cores = os.cpu_count() or 1
+  sel = lambda i: ([float(v) for v in b[i]], [float(v) for v in a[i]])
+  legs = {}
+
+  # (i) one process
+  n1 = 1 << 19
+  bb, aa = sel(C // 2)
+  _py_channel((bb, aa, 1 << 14, 1, 1))                      # warm (imports, exec)
+  done, el = 0, 0.0
+  while el < budget_s:
+    d, e = _py_channel((bb, aa, n1, 1234 + done, 1))
+    done, el = done + d, el + e
+  legs["py_1proc"] = {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1,
+                      "sample": "1 channel at a time x %d samples, %d passes" % (n1, done // n1)}
+
+  # (ii) every core, one channel per process per pass
+  per = max(1 << 16, int(legs["py_1proc"]["value"] * 1e9 * budget_s) // (1 << 16) * (1 << 16))
+  jobs = [sel(int(i * (C - 1) / max(cores - 1, 1))) + (per, 99 + i, 1) for i in range(cores)]
+  ctx = multiprocessing.get_context("fork")
+  with ctx.Pool(cores) as pool:
+    pool.map(_py_channel, [(bb, aa, 1 << 10, 7, 1)] * cores)   # start every worker
+    t0 = time.perf_counter()
+    res = pool.map(_py_channel, jobs, chunksize=1)
+    el = time.perf_counter() - t0
+  tot = sum(r[0] for r in res)
+  legs["py_pool"] = {"value": tot / el / 1e9, "unit": "Gsamples/s", "cores": cores,
+                     "per_process_Msamples_s": float(np.mean([r[0] / r[1] for r in res]) / 1e6),
+                     "sample": "%d processes x 1 channel x %d samples" % (cores, per)}
+
+  # (iii) rows of all channels as samples, per-channel coefficients as repeat(ndarray) series
+  rows = 2048
+  rng = np.random.default_rng(20260924)
+  x = rng.uniform(-1, 1, (rows, C))
+  rep = itertools.repeat
+  nz = lambda col: not np.all(col == 0)
+  bs = [rep(np.ascontiguousarray(b[:, k])) if nz(b[:, k]) else 0.0 for k in range(b.shape[1])]
+  as_ = [1.0] + [rep(np.ascontiguousarray(a[:, k])) if nz(a[:, k]) else 0.0 for k in range(1, a.shape[1])]
+  zero = np.zeros(C)
   done, t0 = 0, time.perf_counter()
   while True:
-    oracle.bank([3], [3], bs, as_, x, layout="chan")
-    done += C * n
+    done += pyref.consume_blocks(pyref.df1(bs, as_, iter(x), zero=zero), 4096) * C
     el = time.perf_counter() - t0
     if el >= budget_s:
       break
-  return {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1, "kind": "port",
-          "sample": "oracle/alz_oracle.c DF-I loop, %d of the %d channels x %d samples, channel-major, "
-                    "%d passes, 1 thread (host has %d logical cores)" % (C, b.shape[0], n, done // (C * n),
-                                                                         os.cpu_count() or 0)}
+  legs["py_rows"] = {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1,
+                     "sample": "%d-channel ndarray rows x %d rows, %d passes (NumPy elementwise per sample)"
+                               % (C, rows, done // (rows * C))}
+
+  # (iv) the C port
+  Cc, n = 64, 1 << 18
+  xs = rng.uniform(-1, 1, (Cc, n))
+  pick = np.linspace(0, C - 1, Cc).astype(int)
+  bsel, asel = np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick])
+  oracle.bank([3], [3], bsel, asel, xs[:, :1024], layout="chan")
+  done, t0 = 0, time.perf_counter()
+  while True:
+    oracle.bank([3], [3], bsel, asel, xs, layout="chan")
+    done += Cc * n
+    el = time.perf_counter() - t0
+    if el >= budget_s:
+      break
+  legs["c_port"] = {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1,
+                    "sample": "oracle/alz_oracle.c, %d of the %d channels x %d samples, %d passes"
+                              % (Cc, C, n, done // (Cc * n))}
+  head = legs["py_pool"]
+  return {"value": head["value"], "unit": "Gsamples/s", "cores": cores, "kind": "port",
+          "sample": "the reference's CPython path restated (oracle/pyref.py: the generated DF-I generator of "
+                    "lazy_filters.py:197-260 executed by this interpreter, fed by random.uniform noise, consumed "
+                    "through blocks(4096)) on resonators of configs[1]: " + head["sample"]
+                    + "; legs = one process / all cores / vector-valued rows / C port",
+          "legs": legs}
 
 
-def side_workload(args, alz, torch, dev, rank, world, local, red_dev):
-  """configs[3] (gammatone bank) and configs[4] (LPC frames): same timing protocol, own metric."""
-  import torch.distributed as dist
-  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-  g = torch.Generator(device=dev).manual_seed(20260924 + rank)
-  if args.workload == "gammatone":
-    B, S, N = 256, 64, 1 << 16            # 512 streams over 8 GPUs -> 64 streams per GPU, all bands local
-    s_, Hz = alz.sHz(48000)
-    fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
-    bank = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz, device=local)
-    bank.reset()
-    x = torch.empty((S, N), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=g)
-    y = torch.empty((B * S, N), dtype=torch.float64, device=dev)
-    step = lambda: bank.process(x, layout="chan", out=y)
-    units, unit_name = float(B) * S * N, "Gsamples/s"
-    alg_bytes = (8.0 + 8.0 / B) * B * S * N
-    metric = "Gsamples/s (band x stream x sample outputs) through the ERB gammatone bank"
-    workload = ("configs[3]: ERB gammatone filterbank (gammatone.slaney, 4-section cascades), %d bands x %d "
-                "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
-                "x [S, N] -> y [B, S, N]" % (B, S, N))
-  else:
-    F, L, order = 65536, 480, 16
-    sig = torch.empty((F * L,), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0, generator=g)
-    from audiolazy_amd.lpc import kautocor_frames
-    step = lambda: kautocor_frames(sig, L, order)
-    units, unit_name = float(F), "Gframes/s"
-    alg_bytes = 3984.0 * F
-    metric = "Gframes/s through lpc.kautocor (autocorrelation + Levinson-Durbin, order 16, 10 ms frames)"
-    workload = "configs[4]: lazy_lpc order-16 on %d concurrent 480-sample frames, float64" % F
+# ---------------------------------------------------------------------------------------------
+# GPU side
+# ---------------------------------------------------------------------------------------------
+class Ctx(object):
+  """Process-group / device context shared by the workloads."""
 
-  def sync_all():
-    torch.cuda.synchronize(dev)
-    if world > 1:
-      dist.barrier()
-    torch.cuda.synchronize(dev)
-  for _ in range(args.warmup):
-    step()
-  sync_all()
-  t0 = time.perf_counter()
-  for s in range(args.steps):
-    ev[s][0].record()
-    step()
-    ev[s][1].record()
-  sync_all()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-  parity = None
-  if rank == 0 and not args.no_parity_check:
-    try:   # the oracle is a checker, never a dependency of the timed path
-      from oracle import oracle
-      if args.workload == "gammatone":
-        nchk = 256
-        bank.reset()
-        xs = x[:, :nchk].contiguous()
-        got = bank.process(xs, layout="chan").cpu().numpy()
-        k = alz.gammatone_erb_constants(4)[0]
-        bands = [alz.gammatone.slaney(fc, k * alz.erb(fc, Hz)) for fc in fcs]
-        nbs, nas = [len(f.numlist) for f in bands[0]], [len(f.denlist) for f in bands[0]]
-        bcat = np.repeat(np.array([sum((f.numlist for f in band), []) for band in bands]), S, axis=0)
-        acat = np.repeat(np.array([sum((f.denlist for f in band), []) for band in bands]), S, axis=0)
-        ref = oracle.bank(nbs, nas, bcat, acat, np.tile(xs.cpu().numpy(), (B, 1)), layout="chan")
-        parity = "bit-exact" if np.array_equal(got.view(np.uint64), ref.view(np.uint64)) else "MISMATCH"
+  def __init__(self, args):
+    import torch
+    self.torch = torch
+    self.rank = int(os.environ.get("RANK", "0"))
+    self.world = int(os.environ.get("WORLD_SIZE", "1"))
+    self.local = int(os.environ.get("LOCAL_RANK", "0"))
+    self.dist = None
+    if args.backend == "gloo":
+      self.local %= max(torch.cuda.device_count(), 1)   # test mode: ranks may share a GPU
+    if self.world > 1:
+      import torch.distributed as dist
+      os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+      if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
       else:
-        nf = 256
-        coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order)
-        rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
-        worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
-        parity = ("coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)" % worst
-                  if worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs) else "MISMATCH (%.3g)" % worst)
-    except Exception as exc:
-      parity = "unchecked (%s)" % exc
-  if rank == 0:
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    print(json.dumps({
-      "metric": metric, "value": world * units * args.steps / elapsed / 1e9, "unit": unit_name,
-      "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-      "config": {"workload": workload, "kernel": bank.last_kernel if args.workload == "gammatone" else "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)",
-                 "parity_spot_check": parity},
-      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms_avg": k_ms,
-                   "algorithmic_bytes_per_launch": alg_bytes}}))
-  if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+        dist.init_process_group("gloo")
+      self.dist = dist
+    torch.cuda.set_device(self.local)
+    self.dev = torch.device("cuda", self.local)
+    self.red_dev = self.dev if args.backend == "nccl" else torch.device("cpu")
+
+  def sync_all(self):
+    self.torch.cuda.synchronize(self.dev)
+    if self.world > 1:
+      self.dist.barrier()
+    self.torch.cuda.synchronize(self.dev)
+
+  def timed(self, step, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
+    Returns (elapsed seconds, mean per-step device time in ms from HIP events on the launch stream)."""
+    torch = self.torch
+    for _ in range(warmup):
+      step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    self.sync_all()
+    t0 = time.perf_counter()
+    for s in range(steps):
+      ev[s][0].record()                  # same stream the kernels are launched on (torch's current)
+      step()
+      ev[s][1].record()
+    self.sync_all()
+    elapsed = time.perf_counter() - t0
+    if self.world > 1:
+      t = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
+      self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+      elapsed = float(t.item())
+    return elapsed, sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+
+  def noise(self, shape, seed_off=0):
+    torch = self.torch
+    g = torch.Generator(device=self.dev).manual_seed(20260924 + self.rank + 1000 * seed_off)
+    x = torch.empty(shape, dtype=torch.float64, device=self.dev)
+    rows = shape[0]
+    step_rows = max(1, rows // 16)
+    for r0 in range(0, rows, step_rows):   # chunked fill keeps the generator's temporaries small
+      x[r0:r0 + step_rows].uniform_(-1.0, 1.0, generator=g)
+    return x
+
+
+def bits_equal(a, b):
+  return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def norm_err(got, ref, axis):
+  """max over channels of max_n |got - ref| / max_n |ref| (SURVEY.md 8d's error definition)."""
+  den = np.abs(ref).max(axis=axis)
+  den[den == 0] = 1.0
+  return float((np.abs(got - ref).max(axis=axis) / den).max())
+
+
+def hbm_roof(alg_bytes, k_ms):
+  ach = alg_bytes / (k_ms * 1e-3) / 1e9
+  return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+          "traffic": None, "kernel_ms_avg": k_ms, "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, time_parallel=None):
+  """Channels [c_lo, c_lo + C) of a c_total-channel resonator bank on this rank."""
+  torch = ctx.torch
+  b_all, a_all = resonator_coefs(c_total)
+  b, a = b_all[c_lo:c_lo + C], a_all[c_lo:c_lo + C]
+  bank = alz.FilterBank([(b, a)], n_inputs=C, device=ctx.local)
+  if args.fused:
+    bank.set_fused(True)
+  if time_parallel is not None:
+    bank.set_time_parallel(time_parallel)
+  bank.reset()
+  shape = (N, C) if args.layout == "time" else (C, N)
+  x = ctx.noise(shape)
+  y = torch.empty(shape, dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout=args.layout, out=y), steps, warmup)
+  kernel = bank.last_kernel
+  exact = not args.fused and not (time_parallel and "k_scan" in kernel)
+  parity = "skipped (--no-parity-check)"
+  if check and ctx.rank == 0 and not args.no_parity_check:
+    # the WHOLE bank width on a fresh stream, against the oracle
+    from oracle import oracle
+    nchk = min(N, args.parity_samples)
+    bank.reset()
+    xs = x[:nchk].contiguous() if args.layout == "time" else x[:, :nchk].contiguous()
+    got = bank.process(xs, layout=args.layout).cpu().numpy()
+    ref = oracle.bank([3], [3], b, a, xs.cpu().numpy(), layout=args.layout)
+    if bits_equal(got, ref):
+      parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk)
+    elif not exact:
+      err = norm_err(got, ref, 0 if args.layout == "time" else 1)
+      parity = ("not bit-exact by design (%s): max normalised error %.3g vs oracle, %d channels x %d samples "
+                "(contract 1e-6)" % ("FMA mode" if args.fused else "time-parallel mode", err, C, nchk))
+      if not err <= 1e-6:
+        parity = "MISMATCH: " + parity
+    else:
+      parity = "MISMATCH"
+  # yardstick, outside the timed region: a plain device-to-device copy of the same block
+  d2d = None
+  if ctx.rank == 0 and check:
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    y.copy_(x)
+    c0.record()
+    for _ in range(3):
+      y.copy_(x)
+    c1.record()
+    torch.cuda.synchronize(ctx.dev)
+    d2d = 3 * 2.0 * x.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+  del x, y, bank
+  torch.cuda.empty_cache()
+  roof = hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)
+  if d2d is not None:
+    roof["d2d_copy_same_block_GBps"] = d2d
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": kernel, "parity": parity, "roofline": roof,
+          "C": C, "N": N}
+
+
+def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
+  torch = ctx.torch
+  taps = fir_taps()
+  bank = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C, device=ctx.local)
+  if fused:
+    bank.set_fused(True)
+  bank.reset()
+  x = ctx.noise((N, C), 1)
+  y = torch.empty((N, C), dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="time", out=y), steps, warmup)
+  kernel = bank.last_kernel
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nchk = min(N, 512)
+    bank.reset()
+    xs = x[:nchk].contiguous()
+    got = bank.process(xs, layout="time").cpu().numpy()
+    ref = oracle.bank([256], [1], taps.reshape(1, -1), np.ones((1, 1)), xs.cpu().numpy(), layout="time")
+    if bits_equal(got, ref):
+      parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk)
+    elif fused:
+      err = norm_err(got, ref, 0)
+      parity = "FMA mode, not bit-exact by design: max normalised error %.3g vs oracle (contract 1e-6)" % err
+      if not err <= 1e-6:
+        parity = "MISMATCH: " + parity
+    else:
+      parity = "MISMATCH"
+  del x, y, bank
+  torch.cuda.empty_cache()
+  flops = 511.0 * C * N   # 256 mul + 255 add per output sample (an FMA counts as its two operations)
+  tf = flops / (k_ms * 1e-3) / 1e12
+  roof = {"bound": "valu_f64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": tf / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms_avg": k_ms,
+          "algorithmic_flops_per_launch": flops,
+          "hbm_GBps": ALG_BYTES_PER_SAMPLE * C * N / (k_ms * 1e-3) / 1e9}
+  if not fused:
+    roof["note"] = ("bit-exact mode: separately rounded v_mul_f64 + v_add_f64, two instructions per tap, so at "
+                    "most half of the FMA peak by construction (39.3 TFLOP/s)")
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": kernel, "parity": parity, "roofline": roof,
+          "C": C, "N": N}
+
+
+def wl_gammatone(ctx, args, alz, steps, warmup):
+  torch = ctx.torch
+  B, S, N = 256, 64, 1 << 16            # 512 streams over 8 GPUs -> 64 streams per GPU, all bands local
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
+  bank = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz, device=ctx.local)
+  bank.reset()
+  x = ctx.noise((S, N), 2)
+  y = torch.empty((B * S, N), dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="chan", out=y), steps, warmup)
+  kernel = bank.last_kernel
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nchk = 512
+    bank.reset()
+    xs = x[:, :nchk].contiguous()
+    got = bank.process(xs, layout="chan").cpu().numpy()
+    k = alz.gammatone_erb_constants(4)[0]
+    bands = [alz.gammatone.slaney(fc, k * alz.erb(fc, Hz)) for fc in fcs]
+    nbs, nas = [len(f.numlist) for f in bands[0]], [len(f.denlist) for f in bands[0]]
+    bcat = np.repeat(np.array([sum((f.numlist for f in band), []) for band in bands]), S, axis=0)
+    acat = np.repeat(np.array([sum((f.denlist for f in band), []) for band in bands]), S, axis=0)
+    ref = oracle.bank(nbs, nas, bcat, acat, np.tile(xs.cpu().numpy(), (B, 1)), layout="chan")
+    parity = ("bit-exact vs oracle, %d bands x %d streams x %d samples" % (B, S, nchk)
+              if bits_equal(got, ref) else "MISMATCH")
+  del x, y, bank
+  torch.cuda.empty_cache()
+  return {"units": float(B) * S * N, "elapsed": elapsed, "kernel": kernel, "parity": parity,
+          "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N}
+
+
+def wl_lpc(ctx, args, alz, steps, warmup):
+  from audiolazy_amd.lpc import kautocor_frames
+  F, L, order = 65536, 480, 16
+  sig = ctx.noise((F * L,), 3)
+  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order), steps, warmup)
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nf = 4096
+    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order)
+    rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
+    worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
+    ok = worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs)
+    parity = ("%d frames: coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)"
+              % (nf, worst)) if ok else "MISMATCH (%.3g)" % worst
+  del sig
+  ctx.torch.cuda.empty_cache()
+  return {"units": float(F), "elapsed": elapsed, "parity": parity,
+          "kernel": "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)",
+          "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
+
+
+def entry(res, world, steps, unit, workload):
+  """A secondary-workload record: same fields as the main line's core."""
+  return {"workload": workload, "value": world * res["units"] * steps / res["elapsed"] / 1e9, "unit": unit,
+          "steps": steps, "ms_per_step": res["elapsed"] / steps * 1e3, "kernel": res["kernel"],
+          "parity": res["parity"], "roofline": res["roofline"]}
 
 
 def main():
@@ -179,14 +410,20 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=10)
   ap.add_argument("--warmup", type=int, default=2)
-  ap.add_argument("--channels", type=int, default=4096, help="channels per GPU")
+  ap.add_argument("--channels", type=int, default=4096, help="channels per GPU (weak) / in total (strong)")
   ap.add_argument("--log2-samples", type=int, default=20, help="block length per channel = 2**this")
   ap.add_argument("--layout", choices=["time", "chan"], default="time")
+  ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-secondary", action="store_true", help="skip configs[2..4] and the narrow-bank run")
   ap.add_argument("--no-parity-check", action="store_true",
-                  help="skip the post-run 4096-sample parity launch (keeps a rocprofv3 --stats average clean)")
+                  help="skip the post-run parity launches (keeps a rocprofv3 --stats average clean)")
+  ap.add_argument("--parity-samples", type=int, default=16384, help="samples per channel of the parity block")
   ap.add_argument("--fused", action="store_true",
-                  help="opt-in FMA mode of the streaming kernel: NOT bit-exact (reported as such); default off")
+                  help="opt-in FMA mode of the streaming kernels: NOT bit-exact (reported as such); default off")
+  ap.add_argument("--time-parallel", type=int, default=None,
+                  help="force the time-parallel (chunked state propagation) kernel on (1) / off (0) for the "
+                       "biquad bank; default: the engine's own choice (bit-exact kernels)")
   ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                   help="process-group backend for N > 1 (nccl = RCCL; gloo lets tests run several ranks on one GPU)")
   ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc"], default="biquad",
@@ -194,171 +431,129 @@ def main():
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
 
-  import torch
-  import audiolazy_amd as alz
-  alz.load_library()  # raises loudly when libalzhip.so is missing: there is no CPU path
-
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
-  local = int(os.environ.get("LOCAL_RANK", "0"))
-  if args.backend == "gloo":
-    local %= max(torch.cuda.device_count(), 1)   # test mode: ranks may share a GPU
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if args.backend == "nccl":
-      dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-      dist.init_process_group("gloo")
-  torch.cuda.set_device(local)
-  dev = torch.device("cuda", local)
-  red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the max-time all-reduce lives
-
-  if args.workload in ("gammatone", "lpc"):
-    return side_workload(args, alz, torch, dev, rank, world, local, red_dev)
   C, N = args.channels, 1 << args.log2_samples
-  if args.workload == "fir":
-    if args.channels == 4096 and args.log2_samples == 20:   # configs[2] defaults
-      C, N = 8192, 1 << 18
-    b, a = fir_taps(), np.array([1.0])
-    bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
-    nsec = ([256], [1])
-  else:
-    # the global bank has world*C channels; this rank owns the contiguous shard [rank*C, (rank+1)*C)
-    b_all, a_all = resonator_coefs(world * C)
-    b, a = b_all[rank * C:(rank + 1) * C], a_all[rank * C:(rank + 1) * C]
-    bank = alz.FilterBank([(b, a)], n_inputs=C, device=local)
-    nsec = ([3], [3])
-  if args.fused:
-    bank.set_fused(True)
-  bank.reset()
 
-  shape = (N, C) if args.layout == "time" else (C, N)
-  g = torch.Generator(device=dev).manual_seed(20260924 + rank)
-  x = torch.empty(shape, dtype=torch.float64, device=dev)
-  rows = shape[0]
-  step_rows = max(1, rows // 16)
-  for r0 in range(0, rows, step_rows):   # chunked fill keeps the generator's temporaries small
-    x[r0:r0 + step_rows].uniform_(-1.0, 1.0, generator=g)
-  y = torch.empty(shape, dtype=torch.float64, device=dev)
+  # the CPU legs fork a process pool: run them before torch / HIP exist in this process
+  cpu = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "biquad":
+    cpu = cpu_baseline(*resonator_coefs(C))
 
-  def sync_all():
-    torch.cuda.synchronize(dev)
-    if world > 1:
-      dist.barrier()
-    torch.cuda.synchronize(dev)
+  import audiolazy_amd as alz
+  alz.load_library()  # raises loudly when libalzhip.so is missing: there is no CPU path
+  ctx = Ctx(args)
 
-  for _ in range(args.warmup):
-    bank.process(x, layout=args.layout, out=y)
-  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for _ in range(args.steps)]
-  sync_all()
-  t0 = time.perf_counter()
-  for s in range(args.steps):
-    ev[s][0].record()                  # same stream the kernel is launched on (torch's current)
-    bank.process(x, layout=args.layout, out=y)
-    ev[s][1].record()
-  sync_all()
-  elapsed = time.perf_counter() - t0
-  kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
-  kernel_name = bank.last_kernel
-
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-  # yardstick, outside the timed region: a plain device-to-device copy of the same block
-  d2d_gbps = None
-  if rank == 0:
-    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    y.copy_(x)
-    c0.record()
-    for _ in range(3):
-      y.copy_(x)
-    c1.record()
-    torch.cuda.synchronize(dev)
-    d2d_gbps = 3 * 2.0 * x.numel() * 8 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-
-  # spot parity: 4 channels of the last block against the oracle would need the whole
-  # stream history; instead re-run a fresh 4096-sample block and compare bit for bit
-  parity = None
-  if rank == 0 and args.no_parity_check:
-    parity = "skipped (--no-parity-check)"
-  elif rank == 0:
+  secondary = {}
+  if args.workload == "biquad":
+    if args.scaling == "strong":
+      from audiolazy_amd.sharding import shard_range
+      lo, hi = shard_range(C, world, rank)
+      res = wl_biquad(ctx, args, alz, hi - lo, N, lo, C, args.steps, args.warmup, time_parallel=args.time_parallel)
+      total_units = float(C) * N
+      workload = ("configs[1], strong scaling: the %d-channel biquad IIR bank (resonator.z_exp per channel) divided "
+                  "over %d rank(s), 48 kHz float64, %d-sample blocks" % (C, world, N))
+    else:
+      res = wl_biquad(ctx, args, alz, C, N, rank * C, world * C, args.steps, args.warmup,
+                      time_parallel=args.time_parallel)
+      total_units = float(world) * C * N
+      workload = ("configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), 48 kHz float64, "
+                  "%d-sample blocks, 1 MI355X per rank" % (C, N))
+    metric, unit = "Gsamples/s through ZFilter IIR biquad bank", "Gsamples/s"
+    config = {"workload": workload, "channels_per_gpu": res["C"], "block_samples": N,
+              "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+    # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the figure
+    # is the committed rocprofv3 --pmc measurement of this kernel (tools/pmc_traffic.py), scaled
     try:
-      from oracle import oracle
-      nchk = 4096
-      bank.reset()
-      xs = x[:nchk].contiguous() if args.layout == "time" else x[:, :nchk].contiguous()
-      ys = bank.process(xs, layout=args.layout).cpu().numpy()
-      ref = oracle.bank(nsec[0], nsec[1], b, a, xs.cpu().numpy(), layout=args.layout)
-      if np.array_equal(ys.view(np.uint64), ref.view(np.uint64)):
-        parity = "bit-exact"
-      elif args.fused:
-        ax = 0 if args.layout == "time" else 1
-        nerr = float((np.abs(ys - ref).max(axis=ax) / np.abs(ref).max(axis=ax)).max())
-        parity = "fused mode, not bit-exact: max normalised error %.3g (contract 1e-6)" % nerr
-      else:
-        parity = "MISMATCH"
-    except Exception as exc:  # the oracle is a checker, never a dependency of the timed path
-      parity = "unchecked (%s)" % exc
-
-  if rank == 0:
-    samples = float(world) * C * N * args.steps
-    value = samples / elapsed / 1e9
-    k_avg_ms = sum(kernel_ms) / len(kernel_ms)
-    achieved = ALG_BYTES_PER_SAMPLE * C * N / (k_avg_ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel_ms_avg": k_avg_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N,
-            "d2d_copy_same_block_GBps": d2d_gbps}
-    # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
-    # from inside this process): measured traffic / algorithmic ratio of the same kernel at
-    # 2**18-sample blocks, scaled to this launch's algorithmic bytes
-    try:
-      pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-      if args.workload == "biquad" and pmc["kernel"].split("<")[0] in kernel_name:
-        roof["traffic"] = pmc["traffic_over_algorithmic"] * ALG_BYTES_PER_SAMPLE * C * N
-        roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes, x%.5f of algorithmic)" \
-                                 % pmc["traffic_over_algorithmic"]
+      pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+      if pmc["kernel"].split("<")[0] in res["kernel"]:
+        roof["traffic"] = pmc["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"]
+        roof["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
+                                  "same kernel at %s-sample blocks (%s), x%.5f of algorithmic"
+                                  % (pmc.get("block_samples", "?"), pmc.get("file", "profiles/pmc_traffic.json"),
+                                     pmc["traffic_over_algorithmic"]))
     except (OSError, KeyError, ValueError):
       pass
-    workload = ("configs[1]: %d-channel biquad IIR bank (resonator.z_exp per channel), 48 kHz float64, "
-                "%d-sample blocks, 1 MI355X per rank" % (C, N))
-    metric = "Gsamples/s through ZFilter IIR biquad bank"
-    if args.workload == "fir":
-      # 256 mul + 255 add per output sample, unfused (bit-exact mode): FP64 vector issue is the
-      # roof (78.6 TFLOP/s spec, MI355X_MICROARCH.md / SURVEY.md 8d), not HBM
-      flops = 511.0 * C * N
-      tf = flops / (k_avg_ms * 1e-3) / 1e12
-      roof = {"bound": "valu_f64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-              "traffic": None, "kernel_ms_avg": k_avg_ms, "algorithmic_flops_per_launch": flops,
-              "hbm_GBps": achieved,
-              "note": "unfused mul + add halves the FMA spec (39.3); under this FP64 load the engine clock "
-                      "sits at 2.0 GHz, not 2.4 (GRBM_GUI_ACTIVE), which puts the unfused roof at 32.8 "
-                      "TFLOP/s with the VALUs 87 % busy: profiles/r01_pmc_fir.txt"}
-      workload = ("configs[2]: 256-tap FIR lowpass (Hamming-windowed sinc, shared taps) x %d channels, "
-                  "float64, %d-sample blocks, 1 MI355X per rank" % (C, N))
-      metric = "Gsamples/s through ZFilter FIR-256 bank"
+    if not args.no_secondary and (C, N) == (4096, 1 << 20):
+      if world == 1:
+        r = wl_fir(ctx, args, alz, 8192, 1 << 18, 5, 1, fused=False)
+        secondary["fir256_bit_exact"] = entry(r, 1, 5, "Gsamples/s", "configs[2]: 256-tap FIR lowpass (Hamming-"
+                                              "windowed sinc, shared taps) x 8192 channels x 2^18 samples, float64")
+        r = wl_fir(ctx, args, alz, 8192, 1 << 18, 5, 1, fused=True)
+        secondary["fir256_fma"] = entry(r, 1, 5, "Gsamples/s", "configs[2] in the opt-in FMA mode (alz_bank_set_fused)")
+        r = wl_gammatone(ctx, args, alz, 10, 2)
+        secondary["gammatone"] = entry(r, 1, 10, "Gsamples/s", "configs[3]: ERB gammatone filterbank (gammatone.slaney), "
+                                       "256 bands x 64 input streams per GPU (512 over 8), 2^16-sample blocks")
+        r = wl_lpc(ctx, args, alz, 20, 3)
+        secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
+                                 "480-sample frames")
+        if hasattr(alz.FilterBank, "set_time_parallel"):
+          for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel")):
+            r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
+            secondary[key] = entry(r, 1, 5, "Gsamples/s", "one GPU's share of configs[1] sharded over 8: 512 channels "
+                                   "x 2^20 samples" + (", time-parallel kernel (opt-in, not bit-exact)" if mode else ""))
+      elif args.scaling == "weak" and C % world == 0:
+        from audiolazy_amd.sharding import shard_range
+        lo, hi = shard_range(C, world, rank)
+        tp = 1 if hasattr(alz.FilterBank, "set_time_parallel") else None
+        r = wl_biquad(ctx, args, alz, hi - lo, N, lo, C, 5, 1, check=False, time_parallel=tp)
+        e = entry(r, 1, 5, "Gsamples/s", "configs[1]'s 4096 channels divided over %d ranks (strong scaling), "
+                  "%d channels per GPU" % (world, hi - lo))
+        e["value"] = float(C) * N * 5 / r["elapsed"] / 1e9
+        secondary["strong_scaling"] = e
+  elif args.workload == "fir":
+    if (C, N) == (4096, 1 << 20):   # configs[2] defaults
+      C, N = 8192, 1 << 18
+    res = wl_fir(ctx, args, alz, C, N, args.steps, args.warmup, fused=args.fused)
+    total_units = float(world) * C * N
+    metric, unit = "Gsamples/s through ZFilter FIR-256 bank", "Gsamples/s"
+    config = {"workload": "configs[2]: 256-tap FIR lowpass (Hamming-windowed sinc, shared taps) x %d channels, "
+                          "float64, %d-sample blocks, 1 MI355X per rank" % (C, N),
+              "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]",
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  elif args.workload == "gammatone":
+    res = wl_gammatone(ctx, args, alz, args.steps, args.warmup)
+    total_units = float(world) * res["units"]
+    metric, unit = "Gsamples/s (band x stream x sample outputs) through the ERB gammatone bank", "Gsamples/s"
+    config = {"workload": "configs[3]: ERB gammatone filterbank (gammatone.slaney, 4-section cascades), %d bands x %d "
+                          "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
+                          "x [S, N] -> y [B, S, N]" % (res["B"], res["S"], res["N"]),
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  else:
+    res = wl_lpc(ctx, args, alz, args.steps, args.warmup)
+    total_units = float(world) * res["units"]
+    metric, unit = "Gframes/s through lpc.kautocor (autocorrelation + Levinson-Durbin, order 16, 10 ms frames)", "Gframes/s"
+    config = {"workload": "configs[4]: lazy_lpc order-16 on %d concurrent 480-sample frames, float64" % res["F"],
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+
+  bad = False
+  if rank == 0:
     out = {
-      "metric": metric,
-      "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps,
-      "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "f64", "data": "synthetic",
-      "config": {"workload": workload,
-                 "channels_per_gpu": C, "block_samples": N,
-                 "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
-                 "kernel": kernel_name, "parity_spot_check": parity},
-      "roofline": roof,
+      "metric": metric, "value": total_units * args.steps / res["elapsed"] / 1e9, "unit": unit,
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": res["elapsed"] / args.steps * 1e3,
+      "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+      "dtype": "f64", "data": "synthetic", "config": config, "roofline": roof,
     }
-    if not args.no_cpu_baseline and world == 1 and args.workload == "biquad":
-      out["cpu_baseline"] = cpu_baseline(b, a, N)
+    if secondary:
+      out["secondary"] = secondary
+    if cpu is not None:
+      out["cpu_baseline"] = cpu
     print(json.dumps(out))
+    checks = [config.get("parity_spot_check") or ""] + [e["parity"] for e in secondary.values()]
+    bad = any(str(c).startswith("MISMATCH") for c in checks)
+    if bad:
+      print("bench.py: PARITY MISMATCH -- the number above is not a valid result", file=sys.stderr)
   if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+    ctx.dist.barrier()
+    ctx.dist.destroy_process_group()
+  if bad:
+    sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -196,3 +196,47 @@ def test_kautocor_zero_frame_is_parcor_error():
   # lazy_lpc.py:132-133
   c, e, st = oracle.kautocor_frames(np.zeros(32), 1, 32, 32, 4)
   assert st[0] == -4
+
+
+# ---------------------------------------------------------------------------
+# oracle/pyref.py: the generated CPython generator restated (bench.py's reference-path CPU legs)
+# ---------------------------------------------------------------------------
+def test_pyref_generated_loop_bit_exact_vs_reference():
+  from oracle import pyref
+  base = unhex(FILT["x"])
+  for case in FILT["cases"]:
+    x = unhex(case["x"]) if "x" in case else base[:case["x_len"]]
+    mem = None if case["memory"] is None else unhex(case["memory"])
+    y = list(pyref.df1(unhex(case["b"]), unhex(case["a"]), x, memory=mem, zero=unhex(case["zero"])))
+    assert same_bits(y, unhex(case["y"])), case["tag"]
+
+
+def test_pyref_series_coefficients_bit_exact_vs_reference():
+  from oracle import pyref
+  tv = load_golden("timevar.json")
+  x = unhex(tv["x"])
+
+  def coef(c):
+    return unhex(c["series"]) if "series" in c else unhex(c["const"])
+  for case in tv["direct"]:
+    b, a = [coef(c) for c in case["b"]], [coef(c) for c in case["a"]]
+    if hasattr(a[0], "__iter__"):
+      continue          # a series a0 is normalised away by the filter algebra before the loop exists
+    mem = None if case["memory"] is None else unhex(case["memory"])
+    y = list(pyref.df1(b, a, x, memory=mem, zero=unhex(case["zero"])))
+    ref = unhex(case["y"])
+    assert same_bits(y[:len(ref)], ref)
+
+
+def test_pyref_source_is_the_documented_statement():
+  # SURVEY.md appendix A (hooked _exec_eval): resonator.z_exp(1000 Hz, 100 Hz)
+  from oracle import pyref
+  src, names = pyref.df1_source([0.0065023341711623606, 0.0, -0.0065023341711623606],
+                                [1, -1.9699963111457524, 0.9869953316576753])
+  assert names == []
+  assert ("m0 = 0.0065023341711623606 * d0 + -0.0065023341711623606 * d2 + --1.9699963111457524 * m1 "
+          "+ -0.9869953316576753 * m2") in src
+  assert "m1 , m2 , = memory" in src and "d1 = d2 = zero" in src
+  src, names = pyref.df1_source([[.1, .2]], [1, [.3, .4]])
+  assert names == ["b0", "a1"] and "m0 = next(b0) * d0 + -next(a1) * m1" in src
+  assert pyref.consume_blocks(pyref.noise(10000, 1), 4096) == 10000
