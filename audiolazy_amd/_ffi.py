@@ -46,6 +46,7 @@ SIGNATURES = {
   "alz_bank_process_host": (_int, [_vp, _dp, _dp, _i64, _int, _i64, _i64]),
   "alz_bank_sync": (_int, [_vp]),
   "alz_bank_set_fused": (_int, [_vp, _int]),
+  "alz_bank_set_time_parallel": (_int, [_vp, _i64]),
   "alz_bank_last_kernel": (ctypes.c_char_p, [_vp]),
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),

@@ -278,6 +278,7 @@ class FilterBank(object):
     self._L = L
     self._live = None      # weak reference to the generator of the latest __call__
     self._fused = False
+    self._time_parallel = 0
 
   # -- construction helpers ------------------------------------------------
   @classmethod
@@ -355,6 +356,17 @@ class FilterBank(object):
     1e-13 normalised; the contract is 1e-6).  Off by default."""
     _ffi.check(self._L.alz_bank_set_fused(self._h, 1 if on else 0))
     self._fused = bool(on)
+    return self
+
+  def set_time_parallel(self, chunk=True):
+    """Opt into the time-parallel mode for narrow banks (alz_bank_set_time_parallel): the time axis
+    of every block is cut into chunks that run side by side (zero-state pass, propagation of the
+    chunk states, replay).  ``chunk``: True / -1 = chunk length chosen by the engine, False / 0 =
+    off, a positive int = samples per chunk.  Not bit-identical to the reference (the contract's
+    1e-6 with orders of magnitude to spare); off by default."""
+    n = -1 if chunk is True else 0 if not chunk else int(chunk)
+    _ffi.check(self._L.alz_bank_set_time_parallel(self._h, n))
+    self._time_parallel = n
     return self
 
   @property
@@ -449,6 +461,8 @@ class FilterBank(object):
     twin = FilterBank(secs, n_inputs=self.n_inputs, mode=self.mode, device=self.device)
     if self._fused:
       twin.set_fused(True)
+    if self._time_parallel:
+      twin.set_time_parallel(self._time_parallel)
     return twin
 
   def _run(self, seq, block=None):

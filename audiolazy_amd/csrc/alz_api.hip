@@ -51,6 +51,8 @@ struct alz_bank {
   std::vector<alz::SectionDev> sec;
   double zero = 0.0;
   int fused = 0;
+  int64_t time_parallel = 0;            // 0 off (default), -1 automatic chunk length, > 0 chunk length
+  std::vector<alz::ScanScratch> scan;   // per section: chunk states and the cached transition matrices
   // staging for process_host and for out-of-place generic sections
   double *stage_x = nullptr, *stage_y = nullptr, *scratch = nullptr;
   uint64_t stage_x_bytes = 0, stage_y_bytes = 0, scratch_bytes = 0;
@@ -268,6 +270,7 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
     boff += nb[s];
     aoff += na[s];
   }
+  h->scan.resize((size_t)n_sections);
   *out = h;
   return ALZ_OK;
 }
@@ -282,6 +285,11 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->stage_x) (void)hipFree(h->stage_x);
   if (h->stage_y) (void)hipFree(h->stage_y);
   if (h->scratch) (void)hipFree(h->scratch);
+  for (alz::ScanScratch &sc : h->scan) {
+    if (sc.vxh) (void)hipFree(sc.vxh);
+    if (sc.vyh) (void)hipFree(sc.vyh);
+    if (sc.power) (void)hipFree(sc.power);
+  }
   delete h;
   return ALZ_OK;
 }
@@ -427,7 +435,16 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       const char *name = "";
       io.c_first = c_first;
       io.c_count = c_count;
-      int rc = (generic || !whole) ? ALZ_OK : alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
+      int rc = ALZ_OK;
+      if (h->time_parallel != 0 && whole && !generic) {
+        // opt-in time-parallel mode: whole chunks of the whole bank; the ragged rest continues
+        // serially from the state the replay pass left
+        rc = alz::launch_scan(sec, s, io, st, h->time_parallel < 0 ? 0 : h->time_parallel, &h->scan[(size_t)s],
+                              &done_n, &name);
+        if (rc) return rc;
+        if (done_n > 0) done_c = c_count;
+      }
+      if (done_c == 0 && !generic && whole) rc = alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
       if (rc) return rc;
       if (done_c > 0) note(name);
       if (done_c < c_count) {  // channels the streaming kernel did not take, whole time range
@@ -454,7 +471,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   // fused cascade: all sections in one pass over the full tiles of the full channel groups;
   // the ragged remainder (and every other cascade) goes section by section
   int64_t fused_n = 0, fused_c = 0;
-  if (h->n_sections >= 2 && x_dev != y_dev) {
+  if (h->n_sections >= 2 && x_dev != y_dev && h->time_parallel == 0) {
     io.n = n;
     io.x = x_dev; io.y = y_dev;
     io.sxn = sxn; io.sxc = sxc; io.syn = syn; io.syc = syc;
@@ -509,6 +526,13 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
 int alz_bank_set_fused(alz_bank_t *h, int on) {
   if (!h) return fail(ALZ_E_ARG, "NULL handle");
   h->fused = on ? 1 : 0;
+  return ALZ_OK;
+}
+
+int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  if (chunk_len < -1) return fail(ALZ_E_ARG, "chunk length must be -1 (automatic), 0 (off) or positive");
+  h->time_parallel = chunk_len;
   return ALZ_OK;
 }
 

@@ -93,5 +93,29 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
 // can and reports how much that was; the caller finishes the rest with launch_section
 int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
                 int64_t *done_samples, int64_t *done_channels, const char **kernel_name);
+// the same kernels over n_chunks chunks of the time axis at once (blockIdx.y = chunk): chunk j covers
+// samples [j * chunk_len, (j + 1) * chunk_len) of io.x / io.y and keeps its state in slot
+// j * io.channels + c of vxh / vyh (arrays of [taps - 1][n_chunks * io.channels]); `nostore` runs the
+// recurrence for its end state only.  *taken = false (nothing launched) when the shape is not one
+// the streaming kernels cover completely.
+struct WaveChunks {
+  int64_t n_chunks, chunk_len;
+  bool nostore;
+  double *vxh, *vyh;
+};
+int launch_wave_chunks(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const WaveChunks &ch,
+                       bool *taken, const char **kernel_name);
+// alz_scan.hip: time-parallel execution of one biquad-class section (chunked state propagation:
+// zero-state pass, per-channel scan of the chunk states, replay); opt-in, not bit-exact.
+struct ScanScratch {                 // owned by the bank handle, grown on demand
+  double *vxh = nullptr, *vyh = nullptr;
+  uint64_t v_bytes = 0;
+  double *power = nullptr;           // [4][channels] transition matrix A^chunk_len per channel
+  uint64_t power_bytes = 0;
+  int64_t power_len = 0;             // chunk length the cached matrix belongs to (0: none)
+  int power_section = -1;
+};
+int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
+                int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name);
 
 }  // namespace alz

@@ -320,7 +320,7 @@ __device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double 
   }
 }
 
-template <int PH>
+template <int PH, bool FMA>
 __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, double (&xr)[kRingG][kRingK],
                                           double (&acc)[kFirR], const double (&tap)[kRingK],
                                           double (&tap_next)[kRingK]) {
@@ -333,38 +333,48 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
 #define ALZ_RING_X(j) xr[(((j) / K) + NG - PH) % NG][(j) % K]
 #pragma unroll
     for (int r = 0; r < R; r += 4) {
-      const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
-      const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
-      const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
-      const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
-      acc[r] = acc[r] + m0;
-      acc[r + 1] = acc[r + 1] + m1;
-      acc[r + 2] = acc[r + 2] + m2;
-      acc[r + 3] = acc[r + 3] + m3;
+      if constexpr (FMA) {
+        // opt-in throughput mode (alz_bank_set_fused): one v_fma_f64 per tap and output, same ascending
+        // tap order, one rounding per term instead of two -- not the reference's doubles
+        acc[r] = __builtin_fma(tap[kk], ALZ_RING_X(r - kk + (K - 1)), acc[r]);
+        acc[r + 1] = __builtin_fma(tap[kk], ALZ_RING_X(r + 1 - kk + (K - 1)), acc[r + 1]);
+        acc[r + 2] = __builtin_fma(tap[kk], ALZ_RING_X(r + 2 - kk + (K - 1)), acc[r + 2]);
+        acc[r + 3] = __builtin_fma(tap[kk], ALZ_RING_X(r + 3 - kk + (K - 1)), acc[r + 3]);
+      } else {
+        const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
+        const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
+        const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
+        const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
+        acc[r] = acc[r] + m0;
+        acc[r + 1] = acc[r + 1] + m1;
+        acc[r + 2] = acc[r + 2] + m2;
+        acc[r + 3] = acc[r + 3] + m3;
+      }
     }
 #undef ALZ_RING_X
   }
 }
 
 // NG is even: the two tap buffers swap roles with the parity of the phase
-template <int PH>
+template <int PH, bool FMA>
 __device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb, double (&xr)[kRingG][kRingK],
                                            double (&acc)[kFirR], double (&tap_a)[kRingK], double (&tap_b)[kRingK],
                                            bool &done) {
   if constexpr (PH < kRingG) {
     if (!done) {
-      if constexpr (PH % 2 == 0) ring_step<PH>(q, t0, kb, xr, acc, tap_a, tap_b);
-      else ring_step<PH>(q, t0, kb, xr, acc, tap_b, tap_a);
+      if constexpr (PH % 2 == 0) ring_step<PH, FMA>(q, t0, kb, xr, acc, tap_a, tap_b);
+      else ring_step<PH, FMA>(q, t0, kb, xr, acc, tap_b, tap_a);
       kb += kRingK;
       done = kb >= q.p->nb;
     }
-    ring_steps<PH + 1>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+    ring_steps<PH + 1, FMA>(q, t0, kb, xr, acc, tap_a, tap_b, done);
   }
 }
 
 #ifndef ALZ_FIR_WAVES
 #define ALZ_FIR_WAVES 2
 #endif
+template <bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_FIR_WAVES, ALZ_FIR_WAVES)))
 void k_fir_ring(FArgs p) {
   constexpr int R = kFirR, K = kRingK, NG = kRingG;
@@ -399,7 +409,7 @@ void k_fir_ring(FArgs p) {
     double tap_a[K], tap_b[K];
     ring_load_taps(q, 0, tap_a);
     while (!done) {
-      ring_steps<0>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+      ring_steps<0, FMA>(q, t0, kb, xr, acc, tap_a, tap_b, done);
       if constexpr (NG % 2 != 0) {                           // odd ring: the roles end up swapped
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) { const double t = tap_a[kk]; tap_a[kk] = tap_b[kk]; tap_b[kk] = t; }
@@ -567,8 +577,11 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     if (getenv("ALZ_FIR_S")) {
       hipLaunchKernelGGL(k_fir_s, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
       shared_name = "k_fir_s";
+    } else if (io.fused) {
+      hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gy), dim3(64), 0, stream, p);
+      shared_name = "k_fir_ring<fma>";
     } else {
-      hipLaunchKernelGGL(k_fir_ring, dim3(gx, gy), dim3(64), 0, stream, p);
+      hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gy), dim3(64), 0, stream, p);
       shared_name = "k_fir_ring";
     }
   }

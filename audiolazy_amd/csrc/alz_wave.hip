@@ -49,6 +49,11 @@ struct WArgs {
   const double *b, *a;
   double *xh, *yh;
   int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores, 8 no tile barriers (wrong output!)
+  // time-parallel mode (alz_scan.hip): blockIdx.y = chunk j of the time axis.  Chunk j reads / writes
+  // at element offset j * chunk_x / j * chunk_y and keeps its state in the slot of "virtual channel"
+  // j * chunk_c + c of the state arrays (whose stride `channels` is then n_chunks * chunk_c).
+  // All three are 0 in an ordinary launch (gridDim.y == 1).
+  int64_t chunk_x, chunk_y, chunk_c;
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -113,7 +118,9 @@ __device__ __forceinline__ double wave_step(double d0, double d1, double d2, dou
 }
 
 // G: channels per wave (16, 32 or 64).  CM: channel-major layout.
-template <int G, bool CM, unsigned PB, unsigned PA>
+// NOSTORE: pass 1 of the time-parallel mode -- the recurrence runs for its end state only; no output
+// tile and no input history is written.
+template <int G, bool CM, unsigned PB, unsigned PA, bool NOSTORE = false>
 __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 8192 / (8 * G);          // samples per channel per tile
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   const int cl = lane & (G - 1);
   const bool real = lane < G;
   const int64_t c = c0 + cl;
+  const int64_t sc = (int64_t)blockIdx.y * p.chunk_c + c;     // state slot (== c unless time-parallel)
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   double b0 = 0, b1 = 0, b2 = 0, na1 = 0, na2 = 0;
   if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
@@ -162,10 +170,10 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   if (PB & 4u) b2 = p.b[2 * p.n_sets + set];
   if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
   if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
-  double d1 = (p.nb > 1) ? p.xh[0 * p.channels + c] : 0.0;
-  double d2 = (p.nb > 2) ? p.xh[1 * p.channels + c] : 0.0;
-  double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
-  double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+  double d1 = (p.nb > 1) ? p.xh[0 * p.channels + sc] : 0.0;
+  double d2 = (p.nb > 2) ? p.xh[1 * p.channels + sc] : 0.0;
+  double m1 = (p.na > 1) ? p.yh[0 * p.channels + sc] : 0.0;
+  double m2 = (p.na > 2) ? p.yh[1 * p.channels + sc] : 0.0;
 
   // Consume the coefficient/state loads here, before any DMA is queued: hipcc then waits for
   // them now, its own vmcnt scoreboard is empty for the rest of the kernel, and it places no
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(na1), "+v"(na2));
   asm volatile("" : "+v"(d1), "+v"(d2), "+v"(m1), "+v"(m2));
 
-  const double *xg = p.x + x_off;
-  double *yg = p.y + y_off;
+  const double *xg = p.x + x_off + (int64_t)blockIdx.y * p.chunk_x;
+  double *yg = p.y + y_off + (int64_t)blockIdx.y * p.chunk_y;
   const int64_t nt = p.n_tiles;
 
   // prologue: tiles 0 .. kRing-2 into slots 0 .. kRing-2
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
           // every step, so lane group r = lane / G keeps the y of step (u0 + r) and a single
           // ds_write_b64 stores 64 / G consecutive rows of the tile.
           constexpr int RPW = 64 / G;  // rows per write
-          if ((u + 1) % RPW == 0) {
+          if (!NOSTORE && (u + 1) % RPW == 0) {
             double yw = yv[u - (RPW - 1)];
 #pragma unroll
             for (int r = 1; r < RPW; ++r) yw = (lane / G == r) ? yv[u - (RPW - 1) + r] : yw;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     // the finished tile leaves as eight 1 KiB stores (all 64 lanes, 16 B each): all eight LDS
     // reads are issued back to back (one exposed LDS latency per tile instead of eight)
     double *yt = yg + i * y_tile;
-    if (!ALZ_DBG(p, 4)) {
+    if (!NOSTORE && !ALZ_DBG(p, 4)) {
       dbl2 v[kChunks];
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
@@ -301,10 +309,12 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the asm stores are invisible to hipcc
 
   if (real) {
-    if (p.nb > 1) p.xh[0 * p.channels + c] = d1;
-    if (p.nb > 2) p.xh[1 * p.channels + c] = d2;
-    if (p.na > 1) p.yh[0 * p.channels + c] = m1;
-    if (p.na > 2) p.yh[1 * p.channels + c] = m2;
+    if (!NOSTORE) {
+      if (p.nb > 1) p.xh[0 * p.channels + sc] = d1;
+      if (p.nb > 2) p.xh[1 * p.channels + sc] = d2;
+    }
+    if (p.na > 1) p.yh[0 * p.channels + sc] = m1;
+    if (p.na > 2) p.yh[1 * p.channels + sc] = m2;
   }
 }
 
@@ -344,7 +354,7 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // DIV = true divides the finished sum by a0 (``(...) / gain``, lazy_filters.py:236-240): the banks
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
-template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false>
+template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false>
 __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   const int cl = lane & 15, q = lane >> 4;
   const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
   const int64_t c = c0 + cl;
+  const int64_t sc = (int64_t)blockIdx.y * p.chunk_c + c;     // state slot (== c unless time-parallel)
   const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
@@ -399,11 +410,11 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
     if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
     if (PB & 4u) b2 = p.b[2 * p.n_sets + set];
-    double d1 = (p.nb > 1) ? p.xh[0 * p.channels + c] : 0.0;   // x[-1], x[-2] of the stream
-    double d2 = (p.nb > 2) ? p.xh[1 * p.channels + c] : 0.0;
+    double d1 = (p.nb > 1) ? p.xh[0 * p.channels + sc] : 0.0;   // x[-1], x[-2] of the stream
+    double d2 = (p.nb > 2) ? p.xh[1 * p.channels + sc] : 0.0;
     asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(d1), "+v"(d2));
-    const double *xg = p.x + x_off;
-    double *yg = p.y + y_off;
+    const double *xg = p.x + x_off + (int64_t)blockIdx.y * p.chunk_x;
+    double *yg = p.y + y_off + (int64_t)blockIdx.y * p.chunk_y;
 
     auto queue_tile = [&](int64_t t) {
       const int s = (int)(t % kXRing);
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < nt; ++i) {
-      if (i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+      if (!NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
@@ -496,19 +507,19 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         // wait_vm: waiting for a few more of the oldest operations is always safe)
         const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
         const int64_t dma_after = last - (i + 1);
-        const int64_t stores_after = i < kXRing - 2 ? i : kXRing - 2;
+        const int64_t stores_after = NOSTORE ? 0 : (i < kXRing - 2 ? i : kXRing - 2);
         wait_vm(ALZ_DBG(p, 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
         if (!ALZ_DBG(p, 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
     }
-    store_tile(nt - 1);
+    if (!NOSTORE) store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
-    if (q == 3) {
+    if (!NOSTORE && q == 3) {
       const char *xs = xring + (int)((nt - 1) % kXRing) * kDuoSlot + lane_off;
-      if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
-      if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
+      if (p.nb > 1) p.xh[0 * p.channels + sc] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
+      if (p.nb > 2) p.xh[1 * p.channels + sc] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
@@ -516,8 +527,8 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     double na1 = 0, na2 = 0;
     if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
     if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
-    double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
-    double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+    double m1 = (p.na > 1) ? p.yh[0 * p.channels + sc] : 0.0;
+    double m2 = (p.na > 2) ? p.yh[1 * p.channels + sc] : 0.0;
     double a0 = 1.0;
     if constexpr (DIV) a0 = p.a[0 * p.n_sets + set];
     asm volatile("" : "+v"(na1), "+v"(na2), "+v"(m1), "+v"(m2), "+v"(a0));
@@ -578,7 +589,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
             m1 = acc;
             t2 = t2n;
           }
-          if ((u & 3) == 3) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;
+          if (!NOSTORE && (u & 3) == 3) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -586,8 +597,8 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();        // y of tile i done, p of tile i+1 ready
     }
     if (lane < G) {
-      if (p.na > 1) p.yh[0 * p.channels + c] = m1;
-      if (p.na > 2) p.yh[1 * p.channels + c] = m2;
+      if (p.na > 1) p.yh[0 * p.channels + sc] = m1;
+      if (p.na > 2) p.yh[1 * p.channels + sc] = m2;
     }
   }
 #undef ALZ_EOFF
@@ -598,10 +609,10 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
 // ---------------------------------------------------------------------------
 typedef void (*wave_fn)(WArgs);
 
-template <int G, bool CM>
+template <int G, bool CM, bool NOSTORE = false>
 static wave_fn pick_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_wave<G, CM, PB_, PA_>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_wave<G, CM, PB_, PA_, NOSTORE>;
   ALZ_PAT(1, 1)  // b0           / a1        lowpass.pole, highpass.pole
   ALZ_PAT(3, 1)  // b0 b1        / a1        lowpass.z, highpass.z
   ALZ_PAT(1, 3)  // b0           / a1 a2     resonator.poles_exp, lowpass.pole**2, gammatone poles
@@ -609,16 +620,18 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   ALZ_PAT(5, 3)  // b0    b2     / a1 a2     resonator.z_exp
   ALZ_PAT(7, 3)  // b0 b1 b2     / a1 a2     general biquad
   ALZ_PAT(1, 2)  // b0           /    a2
-  ALZ_PAT(7, 0)  // 3-tap FIR
-  ALZ_PAT(3, 0)  // 2-tap FIR
+  if constexpr (!NOSTORE) {
+    ALZ_PAT(7, 0)  // 3-tap FIR
+    ALZ_PAT(3, 0)  // 2-tap FIR
+  }
 #undef ALZ_PAT
   return nullptr;
 }
 
-template <bool CM, bool FMA, bool DIV = false>
+template <bool CM, bool FMA, bool DIV = false, bool NOSTORE = false>
 static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV, NOSTORE>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
@@ -634,8 +647,11 @@ static wave_fn pick_wave(int g, bool cm, unsigned pb, unsigned pa) {
 // channel groups) and reports that part; the caller finishes the rest with k_small.
 //   *done_tiles_samples: samples per channel consumed (multiple of the tile length)
 //   *done_channels:      channels covered (multiple of G), starting at channel 0
-int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
-                int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+// With `ch` (time-parallel mode, alz_scan.hip) the launch covers ch->n_chunks chunks of ch->chunk_len
+// samples at once, every chunk from / into its own state slot of ch->vxh / ch->vyh; it then takes
+// either the whole bank (all channels, whole chunks) or nothing.
+static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const WaveChunks *ch,
+                            int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
   *done_samples = 0;
   *done_channels = 0;
   if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform)) return ALZ_OK;
@@ -646,12 +662,14 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   // 16-byte pieces: base pointers 16-byte aligned and even leading dimensions
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
   if ((ldx | ldy) & 1) return ALZ_OK;
+  // lanes that run a recurrence: the channels, times the chunks in time-parallel mode
+  const int64_t lanes = ch ? ch->n_chunks * io.channels : io.channels;
   // group width: keep at least ~256 waves in flight for small banks
-  // measured on MI355X (gpurun_out/sizes.log): the two-wave kernel (G = 16) wins below ~12k
-  // channels, the single-wave kernel with 64 real lanes from 16k up
+  // measured on MI355X (profiles/r02_bank_width_sweep.log): the two-wave kernel (G = 16) wins below
+  // ~12k channels, the single-wave kernel with 64 real lanes from 16k up
   int g = 64;
-  if (io.channels < 64 * 256) g = 32;
-  if (io.channels < 48 * 256) g = 16;
+  if (lanes < 64 * 256) g = 32;
+  if (lanes < 48 * 256) g = 16;
   static const int g_env = getenv("ALZ_G") ? atoi(getenv("ALZ_G")) : 0;   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
   if (sec.any_div) g = 16;      // a0 != 1 somewhere: only the two-wave kernel has the dividing form
@@ -662,18 +680,30 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
     while (g > 16 && io.n_inputs % g) g /= 2;
     if (io.n_inputs % g) return ALZ_OK;
   }
+  if (ch) {
+    if (sec.any_div) return ALZ_OK;
+    if (g == 32) g = 16;                       // the store-less kernels exist for G = 64 and G = 16
+    if (g == 64 && io.channels % 64) g = 16;
+    if (io.channels % g) return ALZ_OK;        // a group must not straddle two chunks
+  }
   const int64_t groups = io.channels / g;
   const int t = 8192 / (8 * g);
-  const int64_t tiles = io.n / t;
+  const int64_t tiles = (ch ? ch->chunk_len : io.n) / t;
   if (groups == 0 || tiles == 0) return ALZ_OK;
+  if (ch && tiles * t != ch->chunk_len) return ALZ_OK;
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
+  const bool nostore = ch && ch->nostore;
   wave_fn duo = nullptr;
   if (g == 16 && sec.any_div) {
     duo = cm ? pick_duo_pattern<true, false, true>(sec.present_b, sec.present_a)
              : pick_duo_pattern<false, false, true>(sec.present_b, sec.present_a);
     if (!duo) return ALZ_OK;
-  } else if (g == 16 && duo_env) {
+  } else if (g == 16 && nostore) {
+    duo = cm ? pick_duo_pattern<true, false, false, true>(sec.present_b, sec.present_a)
+             : pick_duo_pattern<false, false, false, true>(sec.present_b, sec.present_a);
+    if (!duo) return ALZ_OK;
+  } else if (g == 16 && (duo_env || ch)) {
     if (io.fused)
       duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
@@ -681,7 +711,13 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
       duo = cm ? pick_duo_pattern<true, false>(sec.present_b, sec.present_a)
                : pick_duo_pattern<false, false>(sec.present_b, sec.present_a);
   }
-  wave_fn fn = duo ? duo : pick_wave(g, cm, sec.present_b, sec.present_a);
+  wave_fn fn = duo;
+  if (!fn && nostore)
+    fn = g != 64 ? nullptr
+                 : cm ? pick_pattern<64, true, true>(sec.present_b, sec.present_a)
+                      : pick_pattern<64, false, true>(sec.present_b, sec.present_a);
+  else if (!fn)
+    fn = pick_wave(g, cm, sec.present_b, sec.present_a);
   if (!fn) return ALZ_OK;
 
   WArgs p;
@@ -691,23 +727,47 @@ int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.map_input = io.map_input;
   p.n_sets = io.n_sets;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
+  p.chunk_x = p.chunk_y = p.chunk_c = 0;
+  if (ch) {
+    p.channels = lanes;                         // stride of the per-chunk state arrays
+    p.chunk_c = io.channels;
+    p.chunk_x = ch->chunk_len * (cm ? 1 : ldx);
+    p.chunk_y = ch->chunk_len * (cm ? 1 : ldy);
+    p.xh = ch->vxh; p.yh = ch->vyh;
+  }
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
                    : (size_t)kRing * kSlotBytes;
-  if (groups <= 256) lds = 96 * 1024;
+  const int64_t blocks = groups * (ch ? ch->n_chunks : 1);
+  if (blocks <= 256) lds = 96 * 1024;
   {
     const int rc = ensure_dynamic_lds((const void *)fn, 96 * 1024);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(duo ? 128 : 64), lds, stream, p);
+  if (ch && ch->n_chunks > 65535) return ALZ_OK;
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? 128 : 64), lds,
+                     stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
   *done_channels = groups * g;
-  *kernel_name = duo ? (sec.any_div ? "k_duo<16,div>" : io.fused ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  *kernel_name = duo ? (sec.any_div ? "k_duo<16,div>" : io.fused && !nostore ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
   return ALZ_OK;
+}
+
+int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
+                int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+  return launch_wave_impl(sec, io, stream, nullptr, done_samples, done_channels, kernel_name);
+}
+
+int launch_wave_chunks(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const WaveChunks &ch,
+                       bool *taken, const char **kernel_name) {
+  int64_t dn = 0, dc = 0;
+  const int rc = launch_wave_impl(sec, io, stream, &ch, &dn, &dc, kernel_name);
+  *taken = rc == ALZ_OK && dc == io.channels && dn == ch.chunk_len;
+  return rc;
 }
 
 }  // namespace alz

@@ -254,7 +254,7 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
   if args.fused:
     bank.set_fused(True)
   if time_parallel is not None:
-    bank.set_time_parallel(time_parallel)
+    bank.set_time_parallel(True if time_parallel == 1 else time_parallel)
   bank.reset()
   shape = (N, C) if args.layout == "time" else (C, N)
   x = ctx.noise(shape)

@@ -107,10 +107,22 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev,
 int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host,
                           int64_t n, int layout, int64_t ldx, int64_t ldy);
 int alz_bank_sync(alz_bank_t *h);
-/* Opt-in fused mode: allow v_fma_f64 contraction in the streaming biquad kernel.  Results are then
- * NOT bit-identical to the reference generator (normalised differences ~1e-13, contract 1e-6);
+/* Opt-in fused mode: allow v_fma_f64 contraction -- in the streaming biquad kernel (half the
+ * recurrence chain) and in the shared-tap FIR kernel (one instruction per tap instead of two: the
+ * throughput mode of a feedback-free section, same ascending tap order).  Results are then NOT
+ * bit-identical to the reference generator (normalised differences ~1e-13, contract 1e-6);
  * default off.  No reference counterpart (CPython floats never fuse).                      */
 int alz_bank_set_fused(alz_bank_t *h, int on);
+/* Opt-in time-parallel mode for narrow banks (the reference's generator is one serial chain per
+ * channel, lazy_filters.py:251-257, so a bank of a few hundred channels cannot fill the GPU):
+ * biquad-class sections (nb, na <= 3, a0 == 1) are run as chunks of `chunk_len` samples in
+ * parallel -- zero-state pass, per-channel propagation of the chunk states through the section's
+ * transition matrix, replay from the true states.  chunk_len: 0 = off (default), -1 = chosen by
+ * the engine, > 0 = that many samples (rounded down to a multiple of 64).  Every sample is still
+ * the DF-I statement, but the chunk states carry a different rounding: results are NOT
+ * bit-identical (<= 1e-6 normalised by contract, ~1e-12 typical, ~1e-9 for poles at radius
+ * 0.9999).  Sections the mode does not cover run as usual.                                  */
+int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len);
 
 /* Name of the kernel variant the last process call dispatched to (diagnostic;
  * tests use it to prove the fast paths are the ones exercised).              */

@@ -27,7 +27,7 @@ def run(cmd, timeout=600):
 def check(line, n_gpus, steps, warmup):
   assert KEYS <= set(line), sorted(KEYS - set(line))
   assert (line["n_gpus"], line["steps"], line["warmup"]) == (n_gpus, steps, warmup)
-  assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+  assert line["higher_is_better"] is True and line["scaling"] in ("weak", "strong") and line["vs_baseline"] is None
   assert line["dtype"] == "f64" and line["data"] == "synthetic" and "workload" in line["config"]
   roof = line["roofline"]
   assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
@@ -38,9 +38,24 @@ def check(line, n_gpus, steps, warmup):
 def test_single_gpu_line_with_cpu_baseline():
   line = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--channels", "512", "--log2-samples", "14"])
   check(line, 1, 3, 1)
-  assert line["unit"] == "Gsamples/s" and line["config"]["parity_spot_check"] == "bit-exact"
+  assert line["unit"] == "Gsamples/s" and line["config"]["parity_spot_check"].startswith("bit-exact vs oracle, 512 channels")
   cpu = line["cpu_baseline"]
-  assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] == 1
+  assert {"value", "unit", "cores", "kind", "sample", "legs"} <= set(cpu) and cpu["kind"] == "port"
+  assert cpu["cores"] == os.cpu_count()
+  assert set(cpu["legs"]) == {"py_1proc", "py_pool", "py_rows", "c_port"}
+  assert all(leg["value"] > 0 for leg in cpu["legs"].values())
+  # the interpreter path is orders of magnitude below the C port of the same statement
+  assert cpu["legs"]["py_1proc"]["value"] < cpu["legs"]["c_port"]["value"]
+
+
+def test_mismatch_is_a_failure(tmp_path):
+  # a parity MISMATCH must end the run with a non-zero status (the value is not a result)
+  code = ("import sys, numpy as np; sys.argv = ['bench.py', '--steps', '1', '--warmup', '0', '--channels', '64', "
+          "'--log2-samples', '12', '--no-cpu-baseline']; import bench; "
+          "bench.bits_equal = lambda a, b: False; bench.main()")
+  out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+  assert "MISMATCH" in out.stdout
 
 
 @pytest.mark.parametrize("workload", ["fir", "gammatone", "lpc"])
@@ -58,6 +73,15 @@ def test_two_ranks_weak_scaling_path():
   check(line, 2, 2, 1)
   assert "cpu_baseline" not in line          # rank 0 at N = 1 only
   assert line["config"]["channels_per_gpu"] == 256
+
+
+def test_two_ranks_strong_scaling_path():
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", "29613", "bench.py", "--gpus", "2", "--steps", "2",
+         "--warmup", "1", "--channels", "512", "--log2-samples", "13", "--backend", "gloo", "--scaling", "strong"]
+  line = run(cmd)
+  check(line, 2, 2, 1)
+  assert line["scaling"] == "strong" and line["config"]["channels_per_gpu"] == 256
 
 
 def test_smoke_entry():

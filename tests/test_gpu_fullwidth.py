@@ -1,0 +1,166 @@
+"""GPU parity at BASELINE.json's full widths: the HIP path (through the C ABI) against the CPU
+oracle on every channel / band / frame of configs[1..4], not against itself.
+
+Bar: bit-exact (raw 64-bit patterns) for the DF-I kernels and acorr; Levinson-Durbin within 1e-9
+(normalised, the contract is 1e-6); the opt-in modes (FMA, time-parallel) within the stated
+tolerance.  Block lengths are what the C oracle finishes in seconds; the full 2^20-sample blocks
+are covered by the size-independent properties of test_gpu_bank.py (block-split invariance,
+exact power-of-two linearity) and by bench.py's own parity block.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def alz():
+  import audiolazy_amd
+  audiolazy_amd.load_library()
+  assert audiolazy_amd.device_count() >= 1, "no HIP device: the engine has no CPU path"
+  return audiolazy_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+  from oracle import oracle as o
+  return o
+
+
+@pytest.fixture(scope="module")
+def bench():
+  import bench as b
+  return b
+
+
+def same_bits(a, b):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  return a.shape == b.shape and bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)))
+
+
+def norm_err(got, ref, axis):
+  den = np.abs(ref).max(axis=axis)
+  den[den == 0] = 1.0
+  return float((np.abs(got - ref).max(axis=axis) / den).max())
+
+
+# ---- configs[1]: 4096-channel biquad bank -----------------------------------------------------
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_cfg2_biquad_bank_4096_channels_vs_oracle(alz, oracle, bench, layout):
+  import torch
+  C, N = 4096, 16384 + 37          # a ragged tail on top of the full tiles
+  b, a = bench.resonator_coefs(C)
+  rng = np.random.default_rng(20260924)
+  x = rng.uniform(-1, 1, (N, C) if layout == "time" else (C, N))
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset()
+  xd = torch.from_numpy(x).cuda()
+  y = bank.process(xd, layout=layout).cpu().numpy()
+  assert "k_duo" in bank.last_kernel
+  ref = oracle.bank([3], [3], b, a, x, layout=layout)
+  assert same_bits(y, ref)
+  # second block continues the stream (state carried on the device)
+  x2 = rng.uniform(-1, 1, x.shape)
+  y2 = bank.process(torch.from_numpy(x2).cuda(), layout=layout).cpu().numpy()
+  ax = 0 if layout == "time" else 1
+  ref2 = oracle.bank([3], [3], b, a, np.concatenate([x, x2], axis=ax), layout=layout)
+  assert same_bits(y2, ref2[N:] if layout == "time" else ref2[:, N:])
+
+
+def test_cfg2_fused_mode_within_contract(alz, oracle, bench):
+  import torch
+  C, N = 4096, 8192
+  b, a = bench.resonator_coefs(C)
+  x = np.random.default_rng(3).uniform(-1, 1, (N, C))
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  bank.reset()
+  y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
+  assert norm_err(y, oracle.bank([3], [3], b, a, x), 0) <= 1e-10
+
+
+# ---- configs[2]: 256-tap FIR x 8192 channels ---------------------------------------------------
+def test_cfg3_fir256_8192_channels_vs_oracle(alz, oracle, bench):
+  import torch
+  C, N = 8192, 2048
+  taps = bench.fir_taps()
+  x = np.random.default_rng(11).uniform(-1, 1, (N, C))
+  bank = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C)
+  bank.reset()
+  xd = torch.from_numpy(x).cuda()
+  y = bank.process(xd).cpu().numpy()
+  assert "k_fir_ring" in bank.last_kernel
+  ref = oracle.bank([256], [1], taps.reshape(1, -1), np.ones((1, 1)), x)
+  assert same_bits(y, ref)
+  # the opt-in FMA mode: same taps, fused accumulation, <= 1e-12 normalised against the bit-exact kernel
+  fused = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C).set_fused(True)
+  fused.reset()
+  yf = fused.process(xd).cpu().numpy()
+  assert "fma" in fused.last_kernel
+  assert norm_err(yf, y, 0) <= 1e-12
+  assert not same_bits(yf, y)        # it really is the other arithmetic
+
+
+# ---- configs[3]: 256 bands x 64 streams, every gammatone strategy ------------------------------
+@pytest.mark.parametrize("strategy", ["slaney", "klapuri", "sampled"])
+def test_cfg4_gammatone_bank_256x64_vs_oracle(alz, oracle, strategy):
+  import torch
+  B, S, N = 256, 64, 1024 + 16
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
+  bank = alz.gammatone_bank(fcs, S, strategy=strategy, Hz=Hz)
+  bank.reset()
+  x = np.random.default_rng(5).uniform(-1, 1, (S, N))
+  y = bank.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
+  k = alz.gammatone_erb_constants(4)[0]
+  bands = [getattr(alz.gammatone, strategy)(fc, k * alz.erb(fc, Hz)) for fc in fcs]
+  nbs = [max(len(band[s].numlist) for band in bands) for s in range(4)]
+  nas = [max(len(band[s].denlist) for band in bands) for s in range(4)]
+
+  def row(band, attr, sizes):
+    out = []
+    for s, n in enumerate(sizes):
+      lst = list(getattr(band[s], attr))
+      out += lst + [0.0] * (n - len(lst))
+    return out
+  bcat = np.repeat(np.array([row(band, "numlist", nbs) for band in bands]), S, axis=0)
+  acat = np.repeat(np.array([row(band, "denlist", nas) for band in bands]), S, axis=0)
+  ref = oracle.bank(nbs, nas, bcat, acat, np.tile(x, (B, 1)), layout="chan")
+  assert same_bits(y, ref), bank.last_kernel
+
+
+# ---- configs[4]: 65536 frames of lpc.kautocor --------------------------------------------------
+def test_cfg5_lpc_65536_frames_vs_oracle(alz, oracle):
+  import torch
+  from audiolazy_amd.lpc import kautocor_frames
+  from audiolazy_amd import _ffi
+  import ctypes
+  F, L, order = 65536, 480, 16
+  sig = np.random.default_rng(9).uniform(-1, 1, F * L)
+  sig[7 * L:8 * L] = 0.0                  # one silent frame: ParCorError in the reference
+  d = torch.from_numpy(sig).cuda()
+  coefs, err, status = kautocor_frames(d, L, order)
+  rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
+  st = status.cpu().numpy()
+  assert np.array_equal(st, rs) and st[7] == _ffi.E_PARCOR and np.count_nonzero(st) == 1
+  ok = st == 0
+  c, e = coefs.cpu().numpy(), err.cpu().numpy()
+  scale = np.abs(rc[ok]).max(axis=1, keepdims=True)
+  assert (np.abs(c[ok] - rc[ok]) / scale).max() <= 1e-9
+  assert (np.abs(e[ok] - re[ok]) / np.abs(re[ok])).max() <= 1e-9
+  # the autocorrelation half alone is bit-exact on every frame
+  r = torch.empty((F, order + 1), dtype=torch.float64, device="cuda")
+  L_ = _ffi.load()
+  _ffi.check(L_.alz_acorr_dev(d.data_ptr(), F, L, L, order, r.data_ptr(), 0,
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+  torch.cuda.synchronize()
+  ref_r = np.stack([oracle.acorr(sig[f * L:(f + 1) * L], order) for f in range(0, F, 257)])
+  assert same_bits(r.cpu().numpy()[::257], ref_r)
+
+
+def test_acorr_default_lag_list_long_block(alz, oracle):
+  # acorr(blk) with the reference's default max_lag = len(blk) - 1 (lazy_analysis.py:309-310)
+  blk = np.random.default_rng(2).uniform(-1, 1, 200).tolist()
+  got = alz.acorr(blk)
+  assert len(got) == 200 and same_bits(got, oracle.acorr(blk, 199))
+  big = np.random.default_rng(4).uniform(-1, 1, 5000).tolist()    # too long to stage in LDS
+  assert same_bits(alz.acorr(big, 100), oracle.acorr(big, 100))
