@@ -18,7 +18,8 @@ from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, c
 from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
 from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
 from .synth import white_noise, zeros, zeroes, ones, karplus_strong  # noqa: F401
-from .analysis import envelope, maverage, amdf  # noqa: F401
+from .analysis import envelope, envelope_block, maverage, amdf, clip  # noqa: F401
+from . import maps  # noqa: F401
 from .pcm import WavStream, chunks, decode_pcm, encode_pcm  # noqa: F401
 from .misc import dB10, dB20, freq2lag, lag2freq, almost_eq, line  # noqa: F401
 

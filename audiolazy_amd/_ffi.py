@@ -17,6 +17,9 @@ OK = 0
 TV_NEGATED = 1
 E_ARG, E_NONCAUSAL, E_ZERO_GAIN, E_PARCOR, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 TIME_MAJOR, CHAN_MAJOR = 0, 1
+MAP_OPS = {"abs": 1, "neg": 2, "sqrt": 3, "square": 4, "mul": 5, "add": 6, "sub": 7, "rsub": 8, "div": 9, "rdiv": 10,
+           "clip": 11, "clip_high": 12, "clip_low": 13, "add2": 20, "sub2": 21, "mul2": 22, "div2": 23}
+MAP_ZERODIV, MAP_DOMAIN = 1, 2
 BANK_DIAGONAL, BANK_OUTER = 0, 1
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -47,6 +50,8 @@ SIGNATURES = {
   "alz_bank_sync": (_int, [_vp]),
   "alz_bank_set_fused": (_int, [_vp, _int]),
   "alz_bank_set_time_parallel": (_int, [_vp, _i64]),
+  "alz_bank_set_input_map": (_int, [_vp, _int]),
+  "alz_map_dev": (_int, [_int, _vp, _vp, ctypes.c_double, ctypes.c_double, _i64, _vp, _vp, _int, _vp]),
   "alz_bank_last_kernel": (ctypes.c_char_p, [_vp]),
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),

@@ -109,7 +109,7 @@ def stage_memories(memory, nas, zero=0.0):
   return [memory_to_hist(items, na - 1, zero) for na in nas]
 
 
-def call_sections(sections, seq, memory=None, zero=0., block=None):
+def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=None):
   """The filter call protocol for one cascade of LTI sections [(b, a), ...]: ``memory`` is read
   now, the input is not touched until the result is iterated (the reference's generator pulls
   its first sample at the first ``next``); the first item then tells whether samples are scalars
@@ -125,6 +125,8 @@ def call_sections(sections, seq, memory=None, zero=0., block=None):
       return
     n_inputs = len(first) if hasattr(first, "__len__") else 1
     bank = FilterBank(sections, n_inputs=n_inputs)
+    if input_map:
+      bank.set_input_map(input_map)
     bank.reset(zero=zero, _hists=hists)
     for item in bank._run(itertools.chain([first], it), block):
       yield item
@@ -279,6 +281,7 @@ class FilterBank(object):
     self._live = None      # weak reference to the generator of the latest __call__
     self._fused = False
     self._time_parallel = 0
+    self._input_map = None
 
   # -- construction helpers ------------------------------------------------
   @classmethod
@@ -356,6 +359,17 @@ class FilterBank(object):
     1e-13 normalised; the contract is 1e-6).  Off by default."""
     _ffi.check(self._L.alz_bank_set_fused(self._h, 1 if on else 0))
     self._fused = bool(on)
+    return self
+
+  def set_input_map(self, op=None):
+    """Apply an elementwise stage to every input sample before the first section sees it:
+    ``"abs"`` (``filt(abs(sig))``, the shape of envelope.abs, reference lazy_analysis.py:468-493),
+    ``"neg"``, ``"square"`` (``x * x``: not the reference's ``x ** 2`` in the last bit, see
+    :mod:`audiolazy_amd.maps`) or None.  ``"abs"`` in front of one biquad-class section is fused
+    into the kernels' input reads; everything else costs one extra streaming pass."""
+    code = 0 if op is None else _ffi.MAP_OPS[op]
+    _ffi.check(self._L.alz_bank_set_input_map(self._h, code))
+    self._input_map = op
     return self
 
   def set_time_parallel(self, chunk=True):
@@ -463,6 +477,8 @@ class FilterBank(object):
       twin.set_fused(True)
     if self._time_parallel:
       twin.set_time_parallel(self._time_parallel)
+    if self._input_map:
+      twin.set_input_map(self._input_map)
     return twin
 
   def _run(self, seq, block=None):

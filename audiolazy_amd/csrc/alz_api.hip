@@ -51,6 +51,9 @@ struct alz_bank {
   std::vector<alz::SectionDev> sec;
   double zero = 0.0;
   int fused = 0;
+  int input_map = 0;                    // ALZ_MAP_ABS / NEG / SQUARE applied to every input sample, or 0
+  double *map_in = nullptr;             // the mapped input block when the stage is not fused into a kernel
+  uint64_t map_in_bytes = 0;
   int64_t time_parallel = 0;            // 0 off (default), -1 automatic chunk length, > 0 chunk length
   std::vector<alz::ScanScratch> scan;   // per section: chunk states and the cached transition matrices
   // staging for process_host and for out-of-place generic sections
@@ -285,6 +288,7 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->stage_x) (void)hipFree(h->stage_x);
   if (h->stage_y) (void)hipFree(h->stage_y);
   if (h->scratch) (void)hipFree(h->scratch);
+  if (h->map_in) (void)hipFree(h->map_in);
   for (alz::ScanScratch &sc : h->scan) {
     if (sc.vxh) (void)hipFree(sc.vxh);
     if (sc.vyh) (void)hipFree(sc.vyh);
@@ -381,8 +385,30 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
 
+  // the elementwise input stage: |x| rides on the section's own input reads where the kernels can
+  // do that for free (one biquad-class section, the streaming kernels and k_small); anything else
+  // gets the mapped block from one streaming pass (16 B/sample more traffic)
+  int pre_fused = 0;
+  if (h->input_map) {
+    const alz::SectionDev &s0 = h->sec[0];
+    const bool fusable = h->input_map == ALZ_MAP_ABS && h->n_sections == 1 && s0.nb <= 3 && s0.na <= 3 &&
+                         s0.uniform && (s0.present_b | s0.present_a) != 0 && h->time_parallel == 0 && !h->fused;
+    if (fusable) {
+      pre_fused = ALZ_MAP_ABS;
+    } else {
+      const uint64_t extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldx + h->n_inputs)
+                                                       : (uint64_t)((h->n_inputs - 1) * ldx + n);
+      int rc = grow(&h->map_in, &h->map_in_bytes, extent * 8);
+      if (rc) return rc;
+      rc = alz::launch_map(h->input_map, x_dev, nullptr, 0.0, 0.0, (int64_t)extent, h->map_in, nullptr, st);
+      if (rc) return rc;
+      x_dev = h->map_in;
+    }
+  }
+
   alz::BlockIO io;
   io.n = n;
+  io.pre_op = 0;
   io.channels = h->channels;
   io.n_inputs = h->n_inputs;
   io.n_sets = h->n_sets;
@@ -418,11 +444,13 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
         io.sxn = sxn;
         io.sxc = sxc;
         io.map_input = h->mode == ALZ_BANK_OUTER;
+        io.pre_op = pre_fused;
       } else {
         io.x = io.y;
         io.sxn = syn;
         io.sxc = syc;
         io.map_input = 0;
+        io.pre_op = 0;
       }
       if (generic && io.x == io.y) {
         // k_fir / k_generic read their history from the block, so they cannot overwrite it
@@ -526,6 +554,14 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
 int alz_bank_set_fused(alz_bank_t *h, int on) {
   if (!h) return fail(ALZ_E_ARG, "NULL handle");
   h->fused = on ? 1 : 0;
+  return ALZ_OK;
+}
+
+int alz_bank_set_input_map(alz_bank_t *h, int op) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  if (op != 0 && op != ALZ_MAP_ABS && op != ALZ_MAP_NEG && op != ALZ_MAP_SQUARE)
+    return fail(ALZ_E_ARG, "input map must be 0, ALZ_MAP_ABS, ALZ_MAP_NEG or ALZ_MAP_SQUARE");
+  h->input_map = op;
   return ALZ_OK;
 }
 

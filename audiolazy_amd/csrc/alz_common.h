@@ -72,6 +72,8 @@ struct BlockIO {
   int map_input;      // OUTER mode: this launch reads the n_inputs input channels
   double zero;        // what an all-zero section yields (lazy_filters.py:227-231)
   int fused;          // opt-in FMA contraction in the streaming kernels (not bit-exact)
+  int pre_op;         // elementwise stage fused into this section's input reads (ALZ_MAP_ABS) or 0;
+                      // honoured by launch_wave and the k_small path of launch_section only
 };
 
 // alz_iir.hip: any section shape, channels [c_first, c_first + c_count)
@@ -115,6 +117,9 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   int64_t power_len = 0;             // chunk length the cached matrix belongs to (0: none)
   int power_section = -1;
 };
+// alz_map.hip: one elementwise op over n contiguous doubles (see alz_map_dev)
+int launch_map(int op, const double *x, const double *y, double p0, double p1, int64_t n, double *out,
+               int *flags, hipStream_t stream);
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
                 int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name);
 

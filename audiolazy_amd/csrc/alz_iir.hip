@@ -39,6 +39,7 @@ struct KArgs {
   const double *b, *a;
   double *xh, *yh;
   double zero;
+  unsigned long long x_and;   // k_small: mask applied to every input sample (all ones, or abs: sign bit cleared)
 };
 
 __device__ __forceinline__ void lane_ids(const KArgs &p, int64_t c, int64_t &in, int64_t &set) {
@@ -106,14 +107,14 @@ __global__ __launch_bounds__(64) void k_small(KArgs p) {
     for (int u = 0; u < kUnroll; ++u) xv[u] = xp[(n + u) * p.sxn];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const double d0 = xv[u];
+      const double d0 = __longlong_as_double(__double_as_longlong(xv[u]) & (long long)p.x_and);
       const double m0 = small_step<PB, PA, DIV>(d0, d1, d2, m1, m2, b0, b1, b2, na1, na2, a0);
       yp[(n + u) * p.syn] = m0;
       m2 = m1; m1 = m0; d2 = d1; d1 = d0;
     }
   }
   for (; n < p.n; ++n) {
-    const double d0 = xp[n * p.sxn];
+    const double d0 = __longlong_as_double(__double_as_longlong(xp[n * p.sxn]) & (long long)p.x_and);
     const double m0 = small_step<PB, PA, DIV>(d0, d1, d2, m1, m2, b0, b1, b2, na1, na2, a0);
     yp[n * p.syn] = m0;
     m2 = m1; m1 = m0; d2 = d1; d1 = d0;
@@ -292,8 +293,11 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
   p.c_first = io.c_first; p.c_end = io.c_first + io.c_count;
   p.mode = io.mode; p.map_input = io.map_input; p.nb = sec.nb; p.na = sec.na;
   p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh; p.zero = io.zero;
+  p.x_and = io.pre_op == ALZ_MAP_ABS ? 0x7fffffffffffffffull : ~0ull;
   const dim3 grid((unsigned)((io.c_count + 63) / 64)), block(64);
   const bool nonempty = (sec.present_b | sec.present_a) != 0;
+  if (io.pre_op && !(io.pre_op == ALZ_MAP_ABS && sec.nb <= 3 && sec.na <= 3 && sec.uniform && nonempty))
+    return fail(ALZ_E_UNSUPPORTED, "input map reached a kernel that does not fuse it");   // (alz_api.hip maps first)
 
   if (sec.nb <= 3 && sec.na <= 3 && sec.uniform && nonempty) {
     small_fn fn = pick_small(sec.present_b, sec.present_a, sec.any_div);

@@ -103,6 +103,15 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
+// PRE: an elementwise stage fused into the section's input (alz_bank_set_input_map): 0 none, 1 abs --
+// ``lowpass(cutoff)(abs(sig))`` of envelope.abs (lazy_analysis.py:468-493).  abs is exact and, on the
+// operand of a v_mul_f64, a source modifier: the fused form costs no instruction.
+template <int PRE>
+__device__ __forceinline__ double pre_in(double v) {
+  if constexpr (PRE == 1) return __builtin_fabs(v);
+  return v;
+}
+
 template <unsigned PB, unsigned PA>
 __device__ __forceinline__ double wave_step(double d0, double d1, double d2, double m1, double m2,
                                             double b0, double b1, double b2, double na1,
@@ -120,7 +129,7 @@ __device__ __forceinline__ double wave_step(double d0, double d1, double d2, dou
 // G: channels per wave (16, 32 or 64).  CM: channel-major layout.
 // NOSTORE: pass 1 of the time-parallel mode -- the recurrence runs for its end state only; no output
 // tile and no input history is written.
-template <int G, bool CM, unsigned PB, unsigned PA, bool NOSTORE = false>
+template <int G, bool CM, unsigned PB, unsigned PA, bool NOSTORE = false, int PRE = 0>
 __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 8192 / (8 * G);          // samples per channel per tile
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
     // stores of the preceding ones (completion is in issue order)
     {
       const int64_t loads_after = (nt - 1 - i < kRing - 1) ? (nt - 1 - i) : (kRing - 1);
-      const int64_t stores_after = (i < kRing - 1) ? i : (kRing - 1);
+      const int64_t stores_after = NOSTORE ? 0 : ((i < kRing - 1) ? i : (kRing - 1));
       wait_vm((int)(loads_after + stores_after) * kChunks);
     }
 
@@ -227,10 +236,10 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
       constexpr int NCH = T / 8;
       double xr[3][8], pp[2][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xr[0][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(u));
+      for (int u = 0; u < 8; ++u) xr[0][u] = pre_in<PRE>(*reinterpret_cast<const double *>(rd + ALZ_EOFF(u)));
       if (NCH > 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xr[1][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF(8 + u));
+        for (int u = 0; u < 8; ++u) xr[1][u] = pre_in<PRE>(*reinterpret_cast<const double *>(rd + ALZ_EOFF(8 + u)));
       }
       // feed-forward of chunk 0 (not overlapped: once per tile)
 #pragma unroll
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
         if (k + 2 < NCH) {
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            xr[xl][u] = *reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u));
+            xr[xl][u] = pre_in<PRE>(*reinterpret_cast<const double *>(rd + ALZ_EOFF((k + 2) * 8 + u)));
         }
         __builtin_amdgcn_sched_barrier(0);
         double yv[8];
@@ -354,7 +363,7 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // DIV = true divides the finished sum by a0 (``(...) / gain``, lazy_filters.py:236-240): the banks
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
-template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false>
+template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0>
 __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kDuoSlot + lane_off;  // tile t-1
       char *ps = pring + (int)(t % kPRing) * kPYSlot + lane_off_p;
       auto xat = [&](int u) -> double {       // x[u] of this tile; u = -1, -2 reach into tile t-1
-        return *reinterpret_cast<const double *>(xs + ALZ_EOFF(u));
+        return pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(u)));
       };
       // sample 4j + q - d sits q - d steps after sample 4j; in TIME layout the 16-byte pad after
       // every 8 rows is crossed only for even j with q - d < 0 (adj), never otherwise
@@ -441,20 +450,20 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       double x0[16], x1[16], x2[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if constexpr (PB & 1u) x0[j] = *reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j));
+        if constexpr (PB & 1u) x0[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
         if constexpr (PB & 2u) {
-          if (j > 0) x1[j] = *reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j));
+          if (j > 0) x1[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
         }
         if constexpr (PB & 4u) {
-          if (j > 0) x2[j] = *reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j));
+          if (j > 0) x2[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j)));
         }
       }
       // j == 0: samples q - 1 and q - 2 may lie before the tile
       if constexpr ((PB & 6u) != 0) {
         double pm1, pm2;                        // x[-1], x[-2] relative to this tile
         if (t > 0) {
-          pm1 = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1));
-          pm2 = *reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2));
+          pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1)));
+          pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2)));
         } else {
           pm1 = d1;
           pm2 = d2;
@@ -518,8 +527,8 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
     if (!NOSTORE && q == 3) {
       const char *xs = xring + (int)((nt - 1) % kXRing) * kDuoSlot + lane_off;
-      if (p.nb > 1) p.xh[0 * p.channels + sc] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
-      if (p.nb > 2) p.xh[1 * p.channels + sc] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
+      if (p.nb > 1) p.xh[0 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
+      if (p.nb > 2) p.xh[1 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
@@ -609,10 +618,10 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
 // ---------------------------------------------------------------------------
 typedef void (*wave_fn)(WArgs);
 
-template <int G, bool CM, bool NOSTORE = false>
+template <int G, bool CM, bool NOSTORE = false, int PRE = 0>
 static wave_fn pick_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_wave<G, CM, PB_, PA_, NOSTORE>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_wave<G, CM, PB_, PA_, NOSTORE, PRE>;
   ALZ_PAT(1, 1)  // b0           / a1        lowpass.pole, highpass.pole
   ALZ_PAT(3, 1)  // b0 b1        / a1        lowpass.z, highpass.z
   ALZ_PAT(1, 3)  // b0           / a1 a2     resonator.poles_exp, lowpass.pole**2, gammatone poles
@@ -628,19 +637,20 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   return nullptr;
 }
 
-template <bool CM, bool FMA, bool DIV = false, bool NOSTORE = false>
+template <bool CM, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0>
 static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV, NOSTORE>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV, NOSTORE, PRE>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
 }
 
+template <int PRE>
 static wave_fn pick_wave(int g, bool cm, unsigned pb, unsigned pa) {
-  if (g == 16) return cm ? pick_pattern<16, true>(pb, pa) : pick_pattern<16, false>(pb, pa);
-  if (g == 32) return cm ? pick_pattern<32, true>(pb, pa) : pick_pattern<32, false>(pb, pa);
-  return cm ? pick_pattern<64, true>(pb, pa) : pick_pattern<64, false>(pb, pa);
+  if (g == 16) return cm ? pick_pattern<16, true, false, PRE>(pb, pa) : pick_pattern<16, false, false, PRE>(pb, pa);
+  if (g == 32) return cm ? pick_pattern<32, true, false, PRE>(pb, pa) : pick_pattern<32, false, false, PRE>(pb, pa);
+  return cm ? pick_pattern<64, true, false, PRE>(pb, pa) : pick_pattern<64, false, false, PRE>(pb, pa);
 }
 
 // Runs the streaming kernel over the part of the block it can take (full tiles of full
@@ -694,6 +704,11 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
   const bool nostore = ch && ch->nostore;
+  const bool pre_abs = io.pre_op == ALZ_MAP_ABS;
+  if (io.pre_op && (!pre_abs || ch || io.fused || sec.any_div)) return ALZ_OK;   // the caller maps the input first
+  // the single-wave kernel overtakes the two-wave one once a CU holds more than two workgroups' worth
+  // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
+  const bool prefer_single = g == 16 && lanes >= 8192 && !ch;
   wave_fn duo = nullptr;
   if (g == 16 && sec.any_div) {
     duo = cm ? pick_duo_pattern<true, false, true>(sec.present_b, sec.present_a)
@@ -703,7 +718,10 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
     duo = cm ? pick_duo_pattern<true, false, false, true>(sec.present_b, sec.present_a)
              : pick_duo_pattern<false, false, false, true>(sec.present_b, sec.present_a);
     if (!duo) return ALZ_OK;
-  } else if (g == 16 && (duo_env || ch)) {
+  } else if (g == 16 && pre_abs && duo_env && !prefer_single) {
+    duo = cm ? pick_duo_pattern<true, false, false, false, 1>(sec.present_b, sec.present_a)
+             : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a);
+  } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
     if (io.fused)
       duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
@@ -717,7 +735,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
                  : cm ? pick_pattern<64, true, true>(sec.present_b, sec.present_a)
                       : pick_pattern<64, false, true>(sec.present_b, sec.present_a);
   else if (!fn)
-    fn = pick_wave(g, cm, sec.present_b, sec.present_a);
+    fn = pre_abs ? pick_wave<1>(g, cm, sec.present_b, sec.present_a) : pick_wave<0>(g, cm, sec.present_b, sec.present_a);
   if (!fn) return ALZ_OK;
 
   WArgs p;

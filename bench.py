@@ -319,7 +319,7 @@ def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
     bank.reset()
     xs = x[:nchk].contiguous()
     got = bank.process(xs, layout="time").cpu().numpy()
-    ref = oracle.bank([256], [1], taps.reshape(1, -1), np.ones((1, 1)), xs.cpu().numpy(), layout="time")
+    ref = oracle.bank([256], [1], taps, np.ones(1), xs.cpu().numpy(), layout="time")
     if bits_equal(got, ref):
       parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk)
     elif fused:

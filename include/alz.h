@@ -182,6 +182,46 @@ int alz_pcm_decode_dev(const void *raw_dev, int bits, int keep, int64_t n_sample
 int alz_pcm_encode_dev(const double *in_dev, int64_t n, int dfmt, int big_endian, void *out_dev,
                        int *flags_dev, int device, void *stream);
 
+/* ---- elementwise stages around the filter ----------------------------------------------------- */
+/* The lazy per-sample Stream expressions the reference wraps around a filter call: the operator
+ * table of every Stream (lazy_stream.py:47-71: + - * / with a number or with another Stream, unary
+ * minus, abs), ``clip`` (lazy_analysis.py:619-647) and the squaring / root of ``envelope``
+ * (lazy_analysis.py:440-520), on a block of n contiguous float64 items: out[i] = op(x[i], ...).
+ * Every op is the IEEE operation CPython performs on the same operands (bit-identical results);
+ * ALZ_MAP_SQUARE is x * x, which is NOT what the reference's ``x ** 2`` (libm pow) returns for about
+ * one sample in a thousand (last bit) -- use it knowingly.  p0 / p1: the scalar operand, or the
+ * low / high clipping limits.  y_dev: second block of the two-operand ops (NULL otherwise).
+ * out_dev may alias x_dev.  *flags_dev (an int the caller zeroes, or NULL) collects
+ * ALZ_MAP_ZERODIV (a zero divisor: Python raises ZeroDivisionError) and ALZ_MAP_DOMAIN (root of a
+ * negative item: Python returns a complex number). */
+#define ALZ_MAP_ABS 1       /* abs(x)                                  */
+#define ALZ_MAP_NEG 2       /* -x                                      */
+#define ALZ_MAP_SQRT 3      /* x ** .5                                 */
+#define ALZ_MAP_SQUARE 4    /* x * x   (see above)                     */
+#define ALZ_MAP_MUL 5       /* x * p0  (== p0 * x)                     */
+#define ALZ_MAP_ADD 6       /* x + p0  (== p0 + x)                     */
+#define ALZ_MAP_SUB 7       /* x - p0                                  */
+#define ALZ_MAP_RSUB 8      /* p0 - x                                  */
+#define ALZ_MAP_DIV 9       /* x / p0                                  */
+#define ALZ_MAP_RDIV 10     /* p0 / x                                  */
+#define ALZ_MAP_CLIP 11     /* clip(x, low = p0, high = p1)            */
+#define ALZ_MAP_CLIP_HIGH 12 /* clip(x, None, high = p1)               */
+#define ALZ_MAP_CLIP_LOW 13 /* clip(x, low = p0, None)                 */
+#define ALZ_MAP_ADD2 20     /* x + y                                   */
+#define ALZ_MAP_SUB2 21     /* x - y                                   */
+#define ALZ_MAP_MUL2 22     /* x * y                                   */
+#define ALZ_MAP_DIV2 23     /* x / y                                   */
+#define ALZ_MAP_ZERODIV 1
+#define ALZ_MAP_DOMAIN 2
+int alz_map_dev(int op, const double *x_dev, const double *y_dev, double p0, double p1, int64_t n,
+                double *out_dev, int *flags_dev, int device, void *stream);
+/* The same stage as part of a bank: op (0 = none, ALZ_MAP_ABS, ALZ_MAP_NEG or ALZ_MAP_SQUARE) is
+ * applied to every input sample before the first section sees it -- ``filt(abs(sig))``, the shape of
+ * envelope.abs (lazy_analysis.py:468-493).  For a bank of one biquad-class section ALZ_MAP_ABS is
+ * fused into the kernels' input reads (no extra pass over the block); other shapes and ops run one
+ * streaming pass first.  The input history of the bank then holds mapped samples. */
+int alz_bank_set_input_map(alz_bank_t *h, int op);
+
 /* ---- time-varying filters ------------------------------------------------------------------ */
 /* One coefficient of a time-varying filter: a constant, or a series with one value per sample
  * (lazy_filters.py:202-204, 214-216: ``next(b_k) * d_k`` / ``-next(a_k) * m_k``). */

@@ -465,8 +465,57 @@ def timevar_algebra_cases():
   return out
 
 
+# --------------------------------------------------------------------------
+# 13. elementwise Stream stages around the filter: the operators of
+#     lazy_stream.py:47-71, abs, clip (lazy_analysis.py:619-647), ** .5 / ** 2, and the
+#     host-side callers maverage.deque (:523-566) and amdf (:677-716)
+# --------------------------------------------------------------------------
+def maps_cases():
+  from audiolazy import clip, maverage, amdf, envelope
+  inf, nan = float("inf"), float("nan")
+  x = noise(300, 909) + [0.0, -0.0, 1.0, -1.0, 2.5, -2.5, 0.5, -0.5, inf, -inf, nan]
+  y = noise(len(x), 910)                     # second operand: no zeros, no specials
+  xfin = [v for v in x if v == v and abs(v) != inf]
+  out = dict(x=hx(x), y=hx(y), xfin=hx(xfin), unary=[], scalar=[], binary=[], clip=[], callers=[])
+  out["unary"].append(dict(op="abs", r=hx(list(abs(Stream(x))))))
+  out["unary"].append(dict(op="neg", r=hx(list(-Stream(x)))))
+  out["unary"].append(dict(op="sqrt", x=hx([abs(v) for v in xfin]), r=hx(list(Stream(abs(v) for v in xfin) ** .5))))
+  out["unary"].append(dict(op="square_pow", x=hx(xfin), r=hx(list(Stream(xfin) ** 2))))
+  for c in (0.37, -3.0, 1e-3):
+    out["scalar"].append(dict(op="mul", c=hx(c), r=hx(list(Stream(x) * c))))
+    out["scalar"].append(dict(op="rmul", c=hx(c), r=hx(list(c * Stream(x)))))
+    out["scalar"].append(dict(op="add", c=hx(c), r=hx(list(Stream(x) + c))))
+    out["scalar"].append(dict(op="sub", c=hx(c), r=hx(list(Stream(x) - c))))
+    out["scalar"].append(dict(op="rsub", c=hx(c), r=hx(list(c - Stream(x)))))
+    out["scalar"].append(dict(op="div", c=hx(c), r=hx(list(Stream(x) / c))))
+    out["scalar"].append(dict(op="rdiv", c=hx(c), r=hx(list(c / Stream(y)))))   # (y has no zeros)
+  out["binary"].append(dict(op="add", r=hx(list(Stream(x) + Stream(y)))))
+  out["binary"].append(dict(op="sub", r=hx(list(Stream(x) - Stream(y)))))
+  out["binary"].append(dict(op="mul", r=hx(list(Stream(x) * Stream(y)))))
+  out["binary"].append(dict(op="div", r=hx(list(Stream(x) / Stream(y)))))
+  for low, high in ((-1., 1.), (-.5, .5), (None, .3), (-.3, None), (None, None), (0., 0.), (-.25, 2.)):
+    out["clip"].append(dict(low=None if low is None else hx(low), high=None if high is None else hx(high),
+                            r=hx(list(clip(x, low, high)))))
+  xs = noise(500, 911)
+  out["xs"] = hx(xs)
+  for size in (1, 4, 25):
+    for zero in (0., .25):
+      out["callers"].append(dict(fn="maverage.deque", size=size, zero=hx(zero),
+                                 r=hx(list(maverage.deque(size)(xs, zero=zero)))))
+  for lag, size in ((1, 4), (7, 16), (40, 10)):
+    out["callers"].append(dict(fn="amdf", lag=lag, size=size, zero=hx(0.),
+                               r=hx(list(amdf(lag, size)(xs)))))
+  for strat in ("rms", "abs", "squared"):
+    out["callers"].append(dict(fn="envelope." + strat, cutoff=hx(0.02),
+                               r=hx(list(getattr(envelope, strat)(xs, 0.02)))))
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-maps":
+    dump("maps.json", maps_cases())
+    sys.exit(0)
   dump("filters.json", filt_cases())
   dump("lfilter_grid.json", lfilter_grid())
   dump("containers.json", container_cases())
@@ -480,3 +529,4 @@ if __name__ == "__main__":
   dump("formats.json", formats_cases())
   dump("timevar.json", timevar_cases())
   dump("timevar_algebra.json", timevar_algebra_cases())
+  dump("maps.json", maps_cases())

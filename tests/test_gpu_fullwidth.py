@@ -89,7 +89,7 @@ def test_cfg3_fir256_8192_channels_vs_oracle(alz, oracle, bench):
   xd = torch.from_numpy(x).cuda()
   y = bank.process(xd).cpu().numpy()
   assert "k_fir_ring" in bank.last_kernel
-  ref = oracle.bank([256], [1], taps.reshape(1, -1), np.ones((1, 1)), x)
+  ref = oracle.bank([256], [1], taps, np.ones(1), x)
   assert same_bits(y, ref)
   # the opt-in FMA mode: same taps, fused accumulation, <= 1e-12 normalised against the bit-exact kernel
   fused = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C).set_fused(True)
