@@ -57,12 +57,16 @@ __device__ __forceinline__ void c_store16(double *gdst, cdbl2 v) {
   // every band from L2 -- should not be pushed out by it (+6 % on cfg4)
   asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
-__device__ __forceinline__ void c_wait_vm(int n) {
+__device__ __forceinline__ void c_wait_vm(int n) {   // n: a multiple of 4 (half-width tiles) or 8
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
     case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
     case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
     case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
@@ -345,17 +349,28 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 static constexpr int kPLag = ALZ_PIPE_OVERLAP + 1;
 
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
-template <bool CM, int SPW, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
+// G = channels per workgroup.  64: every lane of a stage wave is a channel, one workgroup fills a CU's
+// LDS.  32: half-width workgroups with 4 KiB tiles, so that TWO of them share a CU -- lanes 32..63 of
+// a stage wave are ghosts that mirror lanes 0..31 (a partially masked wave issues f64 ops ~36 % slower,
+// so EXEC stays full; ghosts read the same LDS words by broadcast and do not write).  A bank that is
+// only 256 workgroups wide at G = 64 (cfg4: 256 bands x 64 streams) then has two workgroups per CU
+// whose barrier intervals drift apart: one's section arithmetic runs while the other hands tiles over.
+template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
           unsigned PA2, unsigned PB3, unsigned PA3>
-__global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
+__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int G = 64, T = 16, NW = 4 / SPW;
+  constexpr int T = 16, NW = 4 / SPW;
+  constexpr int NCHK = G / 8;                    // 1 KiB DMA / store chunks per tile
+  constexpr int kSlot = G * 128 + NCHK * 16;     // tile + 16 bytes of pad per chunk
+  constexpr int kPiece = G * 16;                 // bytes per piece row of the lane-private hand-off layout
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
+  const int cl = lane & (G - 1);                 // the channel this lane computes (ghosts: lane - 32)
+  const bool real = lane < G;
   const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
-  const int64_t c = c0 + lane;
+  const int64_t c = c0 + cl;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const bool outer = p.mode == ALZ_BANK_OUTER;
   const int64_t in0 = outer ? c0 % p.n_inputs : c0;
@@ -366,12 +381,12 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
   constexpr int store_lag = kPLag * NW;
   const int64_t n_iv = (nt + store_lag + 1 + 5) / 6 * 6;    // a multiple of the 2- and 3-interval unrolls
   char *xring = smem;
-  char *qring = smem + kPXRing * kCSlot;                 // NW-1 hand-off rings, 2 slots each
-  char *yring = qring + (NW - 1) * 2 * kCSlot;
-  const int lane_off = CM ? (lane / 8) * 1040 + (lane % 8) * 128 : lane * 8;
+  char *qring = smem + kPXRing * kSlot;                  // NW-1 hand-off rings, 2 slots each
+  char *yring = qring + (NW - 1) * 2 * kSlot;
+  const int lane_off = CM ? (cl / 8) * 1040 + (cl % 8) * 128 : cl * 8;
   int swz[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
+  for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ cl) & 7) * 16 : 0;
 #define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
 
   if (wave >= NW) {
@@ -379,10 +394,11 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
     // (two waves, because loads and stores of one wave share one in-order vmcnt counter of 63)
     int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
     if (!CM) {
-      const int row = lane / 32, cp = lane % 32;
+      constexpr int PPR = G / 2;                            // 16-byte pieces per row
+      const int row = lane / PPR, cp = lane % PPR;
       x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
       y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
-      x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
+      x_chunk = (64 / PPR) * p.ldx; y_chunk = (64 / PPR) * p.ldy;
       x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
     } else {
       const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
@@ -398,20 +414,20 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       auto queue_tile = [&](int64_t t) {
         const int s = (int)(t % kPXRing);
 #pragma unroll
-        for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kCSlot + j * 1040);
+        for (int j = 0; j < NCHK; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlot + j * 1040);
       };
       const bool on = !ALZ_DBG(p, 1);
       for (int t = 0; t < D && t < nt && on; ++t) queue_tile(t);
       {
         const int64_t after = ((nt < D ? nt : D) - 1);
-        c_wait_vm(on ? (int)(after > 5 ? 5 : after) * 8 : 0);   // tile 0 has landed
+        c_wait_vm(on ? (int)(after > 5 ? 5 : after) * NCHK : 0);   // tile 0 has landed
       }
       __builtin_amdgcn_s_barrier();
       for (int64_t t = 0; t < n_iv; ++t) {
         if (t + D < nt && on) queue_tile(t + D);
         if (t + 1 < nt) {
           const int64_t last = (t + D < nt - 1) ? t + D : nt - 1;
-          c_wait_vm(on ? (int)(last - (t + 1)) * 8 : 0);     // tile t+1 has landed
+          c_wait_vm(on ? (int)(last - (t + 1)) * NCHK : 0);  // tile t+1 has landed
         }
         __builtin_amdgcn_s_barrier();
       }
@@ -421,13 +437,13 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       for (int64_t t = 0; t < n_iv; ++t) {
         if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4)) {
           const int64_t tt = t - store_lag;
-          const char *ys = yring + (int)(tt % 2) * kCSlot;
+          const char *ys = yring + (int)(tt % 2) * kSlot;
           double *yt = yg + tt * y_tile;
-          cdbl2 w[kCChunks];
+          cdbl2 w[NCHK];
 #pragma unroll
-          for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
+          for (int j = 0; j < NCHK; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
 #pragma unroll
-          for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+          for (int j = 0; j < NCHK; ++j) c_store16(yt + j * y_chunk, w[j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -472,14 +488,14 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
     auto read_tile = [&](int64_t tile, double (&v)[16]) {
       // input: stage 0 reads the DMA layout, the others the lane-private hand-off layout
       if (wave == 0) {
-        const char *src = xring + (int)(tile % kPXRing) * kCSlot + lane_off;
+        const char *src = xring + (int)(tile % kPXRing) * kSlot + lane_off;
 #pragma unroll
         for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double *>(src + ALZ_COFF(u));
       } else {
-        const char *src = qring + ((wave - 1) * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+        const char *src = qring + ((wave - 1) * 2 + (int)(tile % 2)) * kSlot + cl * 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * 1024);
+          const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * kPiece);
           v[2 * j] = w.x;
           v[2 * j + 1] = w.y;
         }
@@ -507,18 +523,19 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
       }
     };
     auto write_tile = [&](int64_t tile, const double (&v)[16]) {
+      if (G < 64 && !real) return;                          // ghost lanes hold the same doubles: one copy is written
       if (wave == NW - 1) {
-        char *dst = yring + (int)(tile % 2) * kCSlot + lane_off;
+        char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
 #pragma unroll
         for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
       } else {
-        char *dst = qring + (wave * 2 + (int)(tile % 2)) * kCSlot + lane * 16;
+        char *dst = qring + (wave * 2 + (int)(tile % 2)) * kSlot + cl * 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           cdbl2 w;
           w.x = v[2 * j];
           w.y = v[2 * j + 1];
-          *reinterpret_cast<cdbl2 *>(dst + j * 1024) = w;
+          *reinterpret_cast<cdbl2 *>(dst + j * kPiece) = w;
         }
       }
     };
@@ -574,13 +591,15 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2)) void k_pipe(CArgs p) {
         __builtin_amdgcn_s_barrier();
       }
     }
+    if (real) {
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) {
+      for (int j = 0; j < SPW; ++j) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k)
-        if (k < nbv[j] - 1) xhs[j][(int64_t)k * p.channels + c] = dx[j][k];
-      if (nav[j] > 1) yhs[j][0 * p.channels + c] = m1[j];
-      if (nav[j] > 2) yhs[j][1 * p.channels + c] = m2[j];
+        for (int k = 0; k < 7; ++k)
+          if (k < nbv[j] - 1) xhs[j][(int64_t)k * p.channels + c] = dx[j][k];
+        if (nav[j] > 1) yhs[j][0 * p.channels + c] = m1[j];
+        if (nav[j] > 2) yhs[j][1 * p.channels + c] = m2[j];
+      }
     }
   }
 #undef ALZ_COFF
@@ -604,12 +623,12 @@ static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
   return nullptr;
 }
 
-template <bool CM, int SPW>
+template <bool CM, int SPW, int G = 64>
 static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
 #define ALZ_PIPE(B0, A0, B1, A1, B2, A2, B3, A3)                                                 \
   if (pb[0] == B0 && pa[0] == A0 && pb[1] == B1 && pa[1] == A1 && pb[2] == B2 && pa[2] == A2 &&  \
       pb[3] == B3 && pa[3] == A3)                                                                \
-    return (casc_fn)k_pipe<CM, SPW, B0, A0, B1, A1, B2, A2, B3, A3>;
+    return (casc_fn)k_pipe<CM, SPW, G, B0, A0, B1, A1, B2, A2, B3, A3>;
   ALZ_PIPE(3, 3, 3, 3, 3, 3, 3, 3)        // gammatone.slaney
   ALZ_PIPE(5, 3, 1, 3, 5, 3, 1, 3)        // gammatone.klapuri
   ALZ_PIPE(0xFE, 3, 1, 3, 1, 3, 1, 3)     // gammatone.sampled
@@ -640,14 +659,29 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   const int64_t ldx = cm ? io.sxc : io.sxn, ldy = cm ? io.syc : io.syn;
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
   if ((ldx | ldy) & 1) return ALZ_OK;
-  if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0) return ALZ_OK;  // a wave = one band
-  const int64_t groups = io.channels / 64, tiles = io.n / 16;
-  if (groups == 0 || tiles == 0) return ALZ_OK;
   // ALZ_PIPE: 0 = single-wave k_casc, 1 = one section per stage wave, 2 = two sections per stage wave
   static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
+  // half-width workgroups (two per CU) when full-width ones would leave CUs with a single workgroup
+  static const int pipe_g_env = getenv("ALZ_PIPE_G") ? atoi(getenv("ALZ_PIPE_G")) : 0;
+  int g = 64;
+  if (nsec == 4 && pipe_env == 1 && io.channels % 32 == 0 && io.channels / 64 <= 256 &&
+      (io.mode != ALZ_BANK_OUTER || io.n_inputs % 32 == 0))
+    g = 32;
+  if (pipe_g_env == 64 || (pipe_g_env == 32 && nsec == 4 && pipe_env == 1 && io.channels % 32 == 0)) g = pipe_g_env;
+  if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % g) != 0) return ALZ_OK;  // a workgroup = channels of one band
+  const int64_t tiles = io.n / 16;
+  int64_t groups = io.channels / g;
+  if (groups == 0 || tiles == 0) return ALZ_OK;
   casc_fn pipe = nullptr;
-  if (nsec == 4 && pipe_env == 1) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
-  if (nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
+  if (nsec == 4 && pipe_env == 1 && g == 32) pipe = cm ? pick_pipe<true, 1, 32>(pb, pa) : pick_pipe<false, 1, 32>(pb, pa);
+  if (!pipe) {
+    if (g == 32 && (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0)) return ALZ_OK;
+    g = 64;
+    groups = io.channels / 64;
+    if (groups == 0) return ALZ_OK;
+  }
+  if (!pipe && nsec == 4 && pipe_env == 1) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
+  if (!pipe && nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
   const int pipe_waves = pipe_env == 2 ? 4 : 6;   // stage waves + loader + storer
   casc_fn fn = pipe ? pipe : (cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
   if (!fn) return ALZ_OK;
@@ -661,7 +695,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
   }
-  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * kCSlot : (size_t)kCRing * kCSlot;
+  const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
+  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
   if (pipe) {
     const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
     if (rc) return rc;
@@ -669,8 +704,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 64 * pipe_waves : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * 16;
-  *done_channels = groups * 64;
-  *kernel_name = pipe ? "k_pipe" : "k_casc";
+  *done_channels = groups * g;
+  *kernel_name = pipe ? (g == 32 ? "k_pipe<32>" : "k_pipe") : "k_casc";
   return ALZ_OK;
 }
 

@@ -77,6 +77,25 @@ def _py_channel(job):
   return done, time.perf_counter() - t0
 
 
+def usable_cores():
+  """Cores this process may actually run on: affinity mask and cgroup CPU quota (a container can
+  show 256 logical CPUs in os.cpu_count() and be allowed a handful)."""
+  n = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+  try:
+    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+    if quota != "max":
+      n = min(n, float(quota) / float(period))
+  except (OSError, ValueError):
+    try:
+      quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+      period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+      if quota > 0:
+        n = min(n, quota / period)
+    except (OSError, ValueError):
+      pass
+  return round(n, 2)
+
+
 def cpu_baseline(b, a, budget_s=3.5):
   """Four figures, each on a bounded sample of configs[1] (about `budget_s` seconds apiece):
     py_1proc   the reference's per-sample path, one process, one channel at a time;
@@ -91,6 +110,7 @@ def cpu_baseline(b, a, budget_s=3.5):
   from oracle import oracle, pyref
   C = b.shape[0]
   cores = os.cpu_count() or 1
+  usable = usable_cores()
   sel = lambda i: ([float(v) for v in b[i]], [float(v) for v in a[i]])
   legs = {}
 
@@ -117,7 +137,9 @@ def cpu_baseline(b, a, budget_s=3.5):
   tot = sum(r[0] for r in res)
   legs["py_pool"] = {"value": tot / el / 1e9, "unit": "Gsamples/s", "cores": cores,
                      "per_process_Msamples_s": float(np.mean([r[0] / r[1] for r in res]) / 1e6),
-                     "sample": "%d processes x 1 channel x %d samples" % (cores, per)}
+                     "sample": "Pool(os.cpu_count() = %d) x 1 channel x %d samples per process; the container's "
+                               "CPU allowance (cgroup quota / affinity) is %s cores, which is what bounds the sum"
+                               % (cores, per, usable)}
 
   # (iii) rows of all channels as samples, per-channel coefficients as repeat(ndarray) series
   rows = 2048
@@ -155,7 +177,7 @@ def cpu_baseline(b, a, budget_s=3.5):
                     "sample": "oracle/alz_oracle.c, %d of the %d channels x %d samples, %d passes"
                               % (Cc, C, n, done // (Cc * n))}
   head = legs["py_pool"]
-  return {"value": head["value"], "unit": "Gsamples/s", "cores": cores, "kind": "port",
+  return {"value": head["value"], "unit": "Gsamples/s", "cores": cores, "usable_cores": usable, "kind": "port",
           "sample": "the reference's CPython path restated (oracle/pyref.py: the generated DF-I generator of "
                     "lazy_filters.py:197-260 executed by this interpreter, fed by random.uniform noise, consumed "
                     "through blocks(4096)) on resonators of configs[1]: " + head["sample"]

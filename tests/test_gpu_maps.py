@@ -120,7 +120,7 @@ def test_fused_abs_in_front_of_the_lowpass_bank(alz, oracle, layout, C):
   bank = alz.FilterBank([(b, a)], n_inputs=C).set_input_map("abs")
   bank.reset()
   y = bank.process(torch.from_numpy(x).cuda(), layout=layout).cpu().numpy()
-  assert ("k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel) == (C >= 256), bank.last_kernel
+  assert "k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel, bank.last_kernel
   ref = oracle.bank([1], [2], b, a, np.abs(x), layout=layout)
   assert same_bits(y, ref), bank.last_kernel
   # the carried input history is the mapped one: a second block continues the reference's stream

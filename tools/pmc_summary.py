@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
       acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
-      if "k_wave" not in k and "k_small" not in k and "alz" not in k:
+      if "k_wave" not in k and "k_small" not in k and "alz" not in k and "k_fir" not in k:
         continue
       print(d, k)
       for c, v in sorted(cs.items()):
