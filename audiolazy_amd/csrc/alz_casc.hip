@@ -346,7 +346,6 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // neither direction of the hand-over waits in series with the arithmetic -- measured SLOWER (364 vs
 // 394 Gsamples/s on cfg4: all the LDS traffic of the six waves then lands at the start of the
 // interval), kept for A/B only.
-static constexpr int kPLag = ALZ_PIPE_OVERLAP + 1;
 
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
 // G = channels per workgroup.  64: every lane of a stage wave is a channel, one workgroup fills a CU's
@@ -357,12 +356,26 @@ static constexpr int kPLag = ALZ_PIPE_OVERLAP + 1;
 // whose barrier intervals drift apart: one's section arithmetic runs while the other hands tiles over.
 template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
           unsigned PA2, unsigned PB3, unsigned PA3>
-__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
+__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 16, NW = 4 / SPW;
   constexpr int NCHK = G / 8;                    // 1 KiB DMA / store chunks per tile
   constexpr int kSlot = G * 128 + NCHK * 16;     // tile + 16 bytes of pad per chunk
   constexpr int kPiece = G * 16;                 // bytes per piece row of the lane-private hand-off layout
+  // half-width workgroups do not overlap the fetch of the next tile with the arithmetic of the
+  // current one inside a wave (the second register set would push them past 128 VGPRs = 4 waves per
+  // SIMD, and with two workgroups of six waves on a CU a SIMD may have to host four): the other
+  // workgroup's waves are what runs meanwhile
+  constexpr int OVL = G == 32 ? 0 : ALZ_PIPE_OVERLAP;
+  constexpr int LAG = OVL + 1;
+  // OVL == 3: de-phased stages, two barriers per interval.  Even stages do their section arithmetic
+  // in the first half of an interval and their LDS hand-over (write the finished tile, fetch the next
+  // one) in the second half; odd stages the other way round.  At any time two stage waves compute
+  // while the other two (and the helpers) own the LDS pipe, instead of all six waves computing and
+  // then all six queueing 80 KiB of LDS traffic behind one barrier.  Stage w then works on tile
+  // t - kDeLag[w]; the storer writes out tile t - 5 in the second half.
+  constexpr bool DEPHASE = OVL == 3 && SPW == 1;
+  constexpr int kDeLag[4] = {0, 1, 3, 4};
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -376,9 +389,9 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CA
   const int64_t in0 = outer ? c0 % p.n_inputs : c0;
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
-  // stage w reads tile t - kPLag w (and, overlapped, computes tile t - kPLag w - 1) in interval t;
+  // stage w reads tile t - LAG w (and, overlapped, computes tile t - LAG w - 1) in interval t;
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
-  constexpr int store_lag = kPLag * NW;
+  constexpr int store_lag = DEPHASE ? 5 : LAG * NW;
   const int64_t n_iv = (nt + store_lag + 1 + 5) / 6 * 6;    // a multiple of the 2- and 3-interval unrolls
   char *xring = smem;
   char *qring = smem + kPXRing * kSlot;                  // NW-1 hand-off rings, 2 slots each
@@ -430,11 +443,13 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CA
           c_wait_vm(on ? (int)(last - (t + 1)) * NCHK : 0);  // tile t+1 has landed
         }
         __builtin_amdgcn_s_barrier();
+        if constexpr (DEPHASE) __builtin_amdgcn_s_barrier();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       __builtin_amdgcn_s_barrier();
       for (int64_t t = 0; t < n_iv; ++t) {
+        if constexpr (DEPHASE) __builtin_amdgcn_s_barrier();   // (first half: stage 3 writes the tile read below)
         if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4)) {
           const int64_t tt = t - store_lag;
           const char *ys = yring + (int)(tt % 2) * kSlot;
@@ -544,13 +559,44 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CA
       write_tile(tile, v);
     };
     __builtin_amdgcn_s_barrier();
-    if constexpr (ALZ_PIPE_OVERLAP == 2) {
+    if constexpr (DEPHASE) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = 0.0;
+      const bool even = (wave & 1) == 0;
+      const int lag = kDeLag[wave & 3];
+      if (wave == 0 && nt > 0) {                              // tile 0 is in the x ring (the loader saw to it)
+        read_tile(0, v);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      for (int64_t t = 0; t < n_iv; ++t) {
+        const int64_t a = t - lag;                            // the tile this stage computes in interval t
+        // ---- first half ----
+        if (even) {
+          if (a >= 0 && a < nt) do_sections(v);
+        } else {
+          if (a - 1 >= 0 && a - 1 < nt) write_tile(a - 1, v);  // finished in the second half of t - 1
+          if (a >= 0 && a < nt) read_tile(a, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- second half ----
+        if (even) {
+          if (a >= 0 && a < nt) write_tile(a, v);
+          if (a + 1 >= 0 && a + 1 < nt) read_tile(a + 1, v);
+        } else {
+          if (a >= 0 && a < nt) do_sections(v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (OVL == 2) {
       double va[16], vb[16], vc[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) va[u] = vb[u] = vc[u] = 0.0;
       // interval t: write out tile a - 2 (done in the previous interval), fetch tile a, work on tile a - 1
       auto interval = [&](int64_t t, double (&out)[16], double (&cur)[16], double (&nxt)[16]) {
-        const int64_t a = t - kPLag * wave;
+        const int64_t a = t - LAG * wave;
         if (a >= 2 && a - 2 < nt) write_tile(a - 2, out);
         if (a >= 0 && a < nt) read_tile(a, nxt);
         asm volatile("" ::: "memory");                        // LDS traffic is issued before the arithmetic
@@ -563,12 +609,12 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 3 : 1) void k_pipe(CA
         interval(t + 1, vb, vc, va);
         interval(t + 2, vc, va, vb);
       }
-    } else if constexpr (ALZ_PIPE_OVERLAP == 1) {
+    } else if constexpr (OVL == 1) {
       double va[16], vb[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) va[u] = vb[u] = 0.0;
       auto interval = [&](int64_t t, double (&cur)[16], double (&nxt)[16]) {
-        const int64_t ahead = t - kPLag * wave;               // tile to fetch; the one before it is in `cur`
+        const int64_t ahead = t - LAG * wave;               // tile to fetch; the one before it is in `cur`
         if (ahead >= 0 && ahead < nt) read_tile(ahead, nxt);
         asm volatile("" ::: "memory");                        // the reads are issued before the arithmetic
         if (ahead >= 1 && ahead - 1 < nt) work_tile(ahead - 1, cur);
@@ -663,11 +709,13 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
   // half-width workgroups (two per CU) when full-width ones would leave CUs with a single workgroup
   static const int pipe_g_env = getenv("ALZ_PIPE_G") ? atoi(getenv("ALZ_PIPE_G")) : 0;
+  // (measured on cfg4, 256 bands x 64 streams: two half-width workgroups per CU 258 Gsamples/s against
+  // 385 for one full-width one -- the ghost lanes double the arithmetic per sample and the per-interval
+  // skeleton does not shrink with the tile; kept for A/B runs only, ALZ_PIPE_G=32)
   int g = 64;
-  if (nsec == 4 && pipe_env == 1 && io.channels % 32 == 0 && io.channels / 64 <= 256 &&
+  if (pipe_g_env == 32 && nsec == 4 && pipe_env == 1 && io.channels % 32 == 0 &&
       (io.mode != ALZ_BANK_OUTER || io.n_inputs % 32 == 0))
     g = 32;
-  if (pipe_g_env == 64 || (pipe_g_env == 32 && nsec == 4 && pipe_env == 1 && io.channels % 32 == 0)) g = pipe_g_env;
   if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % g) != 0) return ALZ_OK;  // a workgroup = channels of one band
   const int64_t tiles = io.n / 16;
   int64_t groups = io.channels / g;

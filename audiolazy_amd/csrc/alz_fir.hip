@@ -263,9 +263,16 @@ void k_fir_s(FArgs p) {
 // "tap is +-0, hence absent from the sum" test is scalar too.
 // ---------------------------------------------------------------------------
 typedef const double __attribute__((address_space(4))) *const_taps_t;
+// register tile of the ring kernel: 48 output rows per lane (R = 32: 53.3 / 77.9 Gsamples/s bit-exact /
+// FMA on cfg3, R = 48: 55.2 / 82.5, R = 64 spills; profiles/r02_fir_tile_sweep.log)
+#ifndef ALZ_FIR_RING_R
+#define ALZ_FIR_RING_R 48
+#endif
+static constexpr int kRingR = ALZ_FIR_RING_R;
+static constexpr int kRingTB = 8 * kRingR;   // output rows per wave
 static constexpr int kRingK = kFirSK;
-static constexpr int kRingG = kFirR / kRingK + 2;
-static_assert(kFirR % kRingK == 0, "ring groups");
+static constexpr int kRingG = kRingR / kRingK + 2;
+static_assert(kRingR % kRingK == 0, "ring groups");
 
 __device__ __forceinline__ bool tap_absent(double t) {
   long long sh;
@@ -322,9 +329,9 @@ __device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double 
 
 template <int PH, bool FMA>
 __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, double (&xr)[kRingG][kRingK],
-                                          double (&acc)[kFirR], const double (&tap)[kRingK],
+                                          double (&acc)[kRingR], const double (&tap)[kRingK],
                                           double (&tap_next)[kRingK]) {
-  constexpr int R = kFirR, K = kRingK, NG = kRingG;
+  constexpr int R = kRingR, K = kRingK, NG = kRingG;
   ring_load_group(q, t0 - (kb + K) - (K - 1), xr[NG - 1 - PH]);   // unused after the last block
   ring_load_taps(q, kb + K, tap_next);                            // likewise (all 0.0 past the end)
 #pragma unroll
@@ -358,7 +365,7 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
 // NG is even: the two tap buffers swap roles with the parity of the phase
 template <int PH, bool FMA>
 __device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb, double (&xr)[kRingG][kRingK],
-                                           double (&acc)[kFirR], double (&tap_a)[kRingK], double (&tap_b)[kRingK],
+                                           double (&acc)[kRingR], double (&tap_a)[kRingK], double (&tap_b)[kRingK],
                                            bool &done) {
   if constexpr (PH < kRingG) {
     if (!done) {
@@ -377,7 +384,7 @@ __device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb
 template <bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_FIR_WAVES, ALZ_FIR_WAVES)))
 void k_fir_ring(FArgs p) {
-  constexpr int R = kFirR, K = kRingK, NG = kRingG;
+  constexpr int R = kRingR, K = kRingK, NG = kRingG;
   const int lane = threadIdx.x;
   RingCtx q;
   q.p = &p;
@@ -389,9 +396,9 @@ void k_fir_ring(FArgs p) {
   q.row_bytes = p.sxn * 8;
   q.taps = (const_taps_t)(uintptr_t)p.b;
   const double a0 = p.a[0];
-  const int64_t tb0 = (int64_t)blockIdx.y * kFirTB;
+  const int64_t tb0 = (int64_t)blockIdx.y * kRingTB;
 
-  for (int sub = 0; sub < kFirTB; sub += R) {
+  for (int sub = 0; sub < kRingTB; sub += R) {
     const int64_t t0 = tb0 + sub;
     if (t0 >= p.n) break;
     double acc[R];
@@ -577,12 +584,11 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     if (getenv("ALZ_FIR_S")) {
       hipLaunchKernelGGL(k_fir_s, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
       shared_name = "k_fir_s";
-    } else if (io.fused) {
-      hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gy), dim3(64), 0, stream, p);
-      shared_name = "k_fir_ring<fma>";
     } else {
-      hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gy), dim3(64), 0, stream, p);
-      shared_name = "k_fir_ring";
+      const unsigned gyr = (unsigned)((io.n + kRingTB - 1) / kRingTB);
+      if (io.fused) hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gyr), dim3(64), 0, stream, p);
+      else hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gyr), dim3(64), 0, stream, p);
+      shared_name = io.fused ? "k_fir_ring<fma>" : "k_fir_ring";
     }
   }
   else if (sec.shared_sets)
