@@ -1,6 +1,7 @@
 // alz_api.hip -- the C ABI of libalzhip.so (see include/alz.h): handles, state,
 // host/device block entry points.  No CPU compute path exists in this library:
 // every process call launches HIP kernels or fails.
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -61,6 +62,9 @@ struct alz_bank {
   uint64_t stage_x_bytes = 0, stage_y_bytes = 0, scratch_bytes = 0;
   const char *last_kernel = "";
   std::string last_kernels;
+  // process_host pipeline: copy-in / compute / copy-out streams and their hand-over events
+  hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> host_events;
 };
 
 namespace {
@@ -289,6 +293,9 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->stage_y) (void)hipFree(h->stage_y);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->map_in) (void)hipFree(h->map_in);
+  for (hipStream_t st : h->host_streams)
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : h->host_events) (void)hipEventDestroy(ev);
   for (alz::ScanScratch &sc : h->scan) {
     if (sc.vxh) (void)hipFree(sc.vxh);
     if (sc.vyh) (void)hipFree(sc.vyh);
@@ -541,6 +548,69 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   if (rc) return rc;
   rc = grow(&h->stage_y, &h->stage_y_bytes, (uint64_t)out_rows * lsy * 8);
   if (rc) return rc;
+  // Large blocks: pin the caller's arrays for the call and run copy-in, kernels and copy-out as a
+  // three-stage pipeline over chunks of the time axis (pinned, double-buffered staging).
+  // The link then carries both directions at once and at the pinned rate; small blocks (the filter
+  // call protocol's 4096-sample blocks) keep the plain synchronous path, whose latency is lower.
+  static const int pipe_env = getenv("ALZ_HOST_PIPE") ? atoi(getenv("ALZ_HOST_PIPE")) : 1;
+  const uint64_t total_bytes = ((uint64_t)in_rows * in_cols + (uint64_t)out_rows * out_cols) * 8;
+  if (pipe_env && total_bytes >= ((uint64_t)64 << 20) && n >= 8192) {
+    const uint64_t x_extent = ((uint64_t)(in_rows - 1) * ldx + in_cols) * 8;
+    const uint64_t y_extent = ((uint64_t)(out_rows - 1) * ldy + out_cols) * 8;
+    const hipError_t rx = hipHostRegister((void *)x_host, x_extent, hipHostRegisterDefault);
+    const bool x_ok = rx == hipSuccess || rx == hipErrorHostMemoryAlreadyRegistered;
+    hipError_t ry = hipErrorUnknown;
+    if (x_ok) ry = hipHostRegister((void *)y_host, y_extent, hipHostRegisterDefault);
+    const bool y_ok = ry == hipSuccess || ry == hipErrorHostMemoryAlreadyRegistered;
+    (void)hipGetLastError();
+    if (x_ok && y_ok) {
+      int64_t n_chunks = (int64_t)(total_bytes >> 26);            // ~64 MiB of traffic per chunk
+      if (n_chunks < 2) n_chunks = 2;
+      if (n_chunks > 16) n_chunks = 16;
+      int64_t step = ((n + n_chunks - 1) / n_chunks + 1023) / 1024 * 1024;
+      n_chunks = (n + step - 1) / step;
+      rc = ALZ_OK;
+      for (int i = 0; i < 3 && rc == ALZ_OK; ++i)
+        if (!h->host_streams[i] && hipStreamCreateWithFlags(&h->host_streams[i], hipStreamNonBlocking) != hipSuccess)
+          rc = fail(ALZ_E_HIP, "hipStreamCreate failed");
+      while (rc == ALZ_OK && (int64_t)h->host_events.size() < 2 * n_chunks) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = fail(ALZ_E_HIP, "hipEventCreate failed");
+        else h->host_events.push_back(ev);
+      }
+      hipStream_t s_in = h->host_streams[0], s_run = h->host_streams[1], s_out = h->host_streams[2];
+      const bool tm = layout == ALZ_TIME_MAJOR;
+      for (int64_t k = 0; k < n_chunks && rc == ALZ_OK; ++k) {
+        const int64_t t0 = k * step, len = (t0 + step <= n ? step : n - t0);
+        const double *src = tm ? x_host + t0 * ldx : x_host + t0;
+        double *dst = tm ? h->stage_x + t0 * lsx : h->stage_x + t0;
+        if (hipMemcpy2DAsync(dst, (size_t)lsx * 8, src, (size_t)ldx * 8, (size_t)(tm ? in_cols : len) * 8,
+                             (size_t)(tm ? len : in_rows), hipMemcpyHostToDevice, s_in) != hipSuccess ||
+            hipEventRecord(h->host_events[2 * k], s_in) != hipSuccess ||
+            hipStreamWaitEvent(s_run, h->host_events[2 * k], 0) != hipSuccess) {
+          rc = fail(ALZ_E_HIP, "host pipeline: copy-in failed");
+          break;
+        }
+        rc = alz_bank_process_dev(h, tm ? h->stage_x + t0 * lsx : h->stage_x + t0,
+                                  tm ? h->stage_y + t0 * lsy : h->stage_y + t0, len, layout, lsx, lsy, s_run);
+        if (rc) break;
+        double *out = tm ? y_host + t0 * ldy : y_host + t0;
+        const double *res = tm ? h->stage_y + t0 * lsy : h->stage_y + t0;
+        if (hipEventRecord(h->host_events[2 * k + 1], s_run) != hipSuccess ||
+            hipStreamWaitEvent(s_out, h->host_events[2 * k + 1], 0) != hipSuccess ||
+            hipMemcpy2DAsync(out, (size_t)ldy * 8, res, (size_t)lsy * 8, (size_t)(tm ? out_cols : len) * 8,
+                             (size_t)(tm ? len : out_rows), hipMemcpyDeviceToHost, s_out) != hipSuccess)
+          rc = fail(ALZ_E_HIP, "host pipeline: copy-out failed");
+      }
+      const hipError_t e1 = hipStreamSynchronize(s_in), e2 = hipStreamSynchronize(s_run), e3 = hipStreamSynchronize(s_out);
+      if (rx == hipSuccess) (void)hipHostUnregister((void *)x_host);
+      if (ry == hipSuccess) (void)hipHostUnregister((void *)y_host);
+      if (rc == ALZ_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+        rc = fail(ALZ_E_HIP, "host pipeline: stream synchronisation failed");
+      return rc;
+    }
+    if (rx == hipSuccess) (void)hipHostUnregister((void *)x_host);     // y could not be pinned: plain path
+  }
   ALZ_HIP_CHECK(hipMemcpy2D(h->stage_x, (size_t)lsx * 8, x_host, (size_t)ldx * 8, (size_t)in_cols * 8,
                             (size_t)in_rows, hipMemcpyHostToDevice));
   rc = alz_bank_process_dev(h, h->stage_x, h->stage_y, n, layout, lsx, lsy, nullptr);

@@ -420,6 +420,34 @@ def wl_lpc(ctx, args, alz, steps, warmup):
           "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
 
 
+def wl_envelope(ctx, args, alz, C, N, steps, warmup):
+  """envelope.abs for a whole bank: lowpass.pole(cutoff)(abs(x)) per channel with |x|
+  fused into the kernel's input reads -- the elementwise stage must not cost a pass over the block."""
+  torch = ctx.torch
+  cut = np.geomspace(2 * np.pi * 5 / 48000., 2 * np.pi * 200 / 48000., C)
+  filts = [alz.lowpass(float(c)) for c in cut]
+  b, a = np.array([f.numlist for f in filts]), np.array([f.denlist for f in filts])
+  bank = alz.FilterBank([(b, a)], n_inputs=C, device=ctx.local).set_input_map("abs")
+  bank.reset()
+  x = ctx.noise((N, C), 4)
+  y = torch.empty((N, C), dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="time", out=y), steps, warmup)
+  kernel = bank.last_kernel + " (|x| fused into the input reads)"
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nchk = min(N, args.parity_samples)
+    bank.reset()
+    xs = x[:nchk].contiguous()
+    got = bank.process(xs, layout="time").cpu().numpy()
+    ref = oracle.bank([1], [2], b, a, np.abs(xs.cpu().numpy()), layout="time")
+    parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk) if bits_equal(got, ref) else "MISMATCH"
+  del x, y, bank
+  torch.cuda.empty_cache()
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": kernel, "parity": parity,
+          "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
+
+
 def entry(res, world, steps, unit, workload):
   """A secondary-workload record: same fields as the main line's core."""
   return {"workload": workload, "value": world * res["units"] * steps / res["elapsed"] / 1e9, "unit": unit,
@@ -511,6 +539,9 @@ def main():
         r = wl_lpc(ctx, args, alz, 20, 3)
         secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
                                  "480-sample frames")
+        r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
+        secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
+                                          "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel")):
             r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
