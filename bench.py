@@ -450,9 +450,12 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
 
 def entry(res, world, steps, unit, workload):
   """A secondary-workload record: same fields as the main line's core."""
+  roof = dict(res["roofline"])
+  # the same fraction priced on the wall time of a step (launch gaps included), next to the kernel-time one
+  roof["frac_from_ms_per_step"] = roof["frac"] * roof["kernel_ms_avg"] / (res["elapsed"] / steps * 1e3)
   return {"workload": workload, "value": world * res["units"] * steps / res["elapsed"] / 1e9, "unit": unit,
           "steps": steps, "ms_per_step": res["elapsed"] / steps * 1e3, "kernel": res["kernel"],
-          "parity": res["parity"], "roofline": res["roofline"]}
+          "parity": res["parity"], "roofline": roof}
 
 
 def main():

@@ -1,29 +1,41 @@
 #!/bin/bash
-# Round-end measurement pass on the GPU box: bench lines for every workload, the rocprofv3 kernel
-# stats of the contract command, and the two PMC passes behind roofline.traffic (--light: bench
-# lines and kernel stats only).
+# Round-end measurement pass on the GPU box:
+#   1. the whole gpu test suite;
+#   2. the driver's command (python bench.py): primary line + secondaries + CPU legs;
+#   3. rocprofv3 --kernel-trace --stats of the same command (kernel stats + full dispatch rows);
+#   4. the two PMC passes behind roofline.traffic at the BENCHMARKED block size (2^20 samples);
+#   5. side measurements (channel-major layout, formats / time-varying kernels, host path).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout 300 python bench.py > $O/bench_full.json.log 2>$O/bench_full.err
-timeout 200 python bench.py --layout chan --no-cpu-baseline > $O/bench_chan.json.log 2>/dev/null
-timeout 200 python bench.py --workload fir --no-cpu-baseline > $O/bench_fir.json.log 2>/dev/null
-timeout 200 python bench.py --workload gammatone --no-cpu-baseline > $O/bench_gammatone.json.log 2>/dev/null
-timeout 200 python bench.py --workload lpc --no-cpu-baseline > $O/bench_lpc.json.log 2>/dev/null
-if [ "$1" != "--light" ]; then
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+timeout 600 python bench.py > $O/bench_full.json 2>$O/bench_full.err
+echo "bench rc=$?"
+timeout 200 python bench.py --layout chan --no-cpu-baseline --no-secondary > $O/bench_chan.json 2>/dev/null
+timeout 200 python bench.py --fused --no-cpu-baseline --no-secondary > $O/bench_fused.json 2>/dev/null
+timeout 200 python bench.py --channels 512 --time-parallel 1 --no-cpu-baseline --no-secondary > $O/bench_narrow_tp.json 2>/dev/null
 timeout 200 python tools/io_time.py > $O/io_time.log 2>&1
 timeout 200 python tools/tv_time.py > $O/tv_time.log 2>&1
-fi
-cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --no-cpu-baseline --no-parity-check > $O/stats.log 2>&1
+timeout 200 python tools/host_path_time.py > $O/host_path.log 2>&1
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --no-cpu-baseline --no-parity-check > $O/stats.log 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-parity-check > $O/pmc_$ctr.log 2>&1
+done
 cd $R
-if [ "$1" != "--light" ]; then
-timeout 400 bash tools/pmc_run.sh final_fetch FETCH_SIZE -- python $R/bench.py --log2-samples 18 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check
-timeout 400 bash tools/pmc_run.sh final_write WRITE_SIZE -- python $R/bench.py --log2-samples 18 --steps 3 --warmup 1 --no-cpu-baseline --no-parity-check
-python tools/pmc_traffic.py gpurun_out/pmc_final_fetch gpurun_out/pmc_final_write k_duo 4096 262144 > $O/pmc_traffic.json 2>$O/pmc_traffic.err
-fi
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE k_duo 4096 1048576 > $O/pmc_traffic.json 2>$O/pmc_traffic.err
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-find $O/stats -name "*kernel_trace.csv" -exec sh -c 'grep -E "Kernel_Name|k_duo" "$1" | cut -d, -f1-20 > '$O'/kernel_dispatches.csv' _ {} \;
-rm -rf $O/stats
-ls -la $O
+# dispatch rows of this library's kernels with EVERY column (LDS size, workgroup / grid size, registers)
+find $O/stats -name "*kernel_trace.csv" -exec sh -c 'grep -E "Kernel_Name|alz::" "$1" > '$O'/kernel_dispatches.csv' _ {} \;
+rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+python3 - <<'PY'
+import json
+d=json.load(open('gpurun_out/final/bench_full.json'))
+print(round(d['value'],1), round(d['roofline']['frac'],4), d['config']['parity_spot_check'])
+for k,v in d.get('secondary',{}).items(): print(' ', k, round(v['value'],3), v['unit'], round(v['roofline']['frac'],3), v['kernel'][:40], '|', v['parity'][:70])
+PY
+cat $O/pmc_traffic.json | head -20
+head -12 $O/kernel_stats.csv | cut -c1-160
