@@ -117,7 +117,7 @@ def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=Non
   from .stream import Stream
   hists = stage_memories(memory, [len(a) for _, a in sections], zero)
 
-  def gen():
+  def blocks_out():
     it = iter(seq)
     for first in it:
       break
@@ -128,9 +128,10 @@ def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=Non
     if input_map:
       bank.set_input_map(input_map)
     bank.reset(zero=zero, _hists=hists)
-    for item in bank._run(itertools.chain([first], it), block):
-      yield item
-  return Stream(gen())
+    for out in bank._blocks(itertools.chain([first], it), block):
+      yield out
+  # one Python-level resume per BLOCK, not per sample: the items of a block come out of a list
+  return Stream(itertools.chain.from_iterable(blocks_out()))
 
 
 def mix_sets(y, n_sets, n_inputs, layout="time", out=None, device=0):
@@ -463,9 +464,9 @@ class FilterBank(object):
     live = self._live() if self._live is not None else None
     runner = self._clone() if (live is not None and live.gi_frame is not None) else self
     runner.reset(memory=memory, zero=zero)
-    g = runner._run(seq, block)
+    g = runner._blocks(seq, block)
     runner._live = weakref.ref(g)
-    return Stream(g)
+    return Stream(itertools.chain.from_iterable(g))
 
   def _clone(self):
     """A bank with the same coefficients and its own device state."""
@@ -481,8 +482,9 @@ class FilterBank(object):
       twin.set_input_map(self._input_map)
     return twin
 
-  def _run(self, seq, block=None):
-    """Generator behind the call protocol: pulls ``block`` items, filters them, yields them."""
+  def _blocks(self, seq, block=None):
+    """Generator behind the call protocol: pulls ``block`` items, filters them on the GPU and yields
+    the results of the block as a list (scalars for a one-channel bank, rows otherwise)."""
     scalar_out = self.channels == 1
     block = block_size() if block is None else block
     it = iter(seq)
@@ -501,9 +503,4 @@ class FilterBank(object):
       if x.shape[0] == 0:
         return
       y = self.process(x, layout="time")
-      if scalar_out:
-        for v in y[:, 0].tolist():
-          yield v
-      else:
-        for row in y:
-          yield row
+      yield y[:, 0].tolist() if scalar_out else list(y)

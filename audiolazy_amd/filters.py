@@ -477,9 +477,8 @@ class ParallelFilter(FilterList):
           return
         x = np.asarray(chunk, dtype=np.float64).reshape(len(chunk), 1)
         y = bank.mixdown(bank.process(x, layout="time"), layout="time")
-        for v in y[:, 0].tolist():
-          yield v
-    return Stream(gen())
+        yield y[:, 0].tolist()
+    return Stream(itertools.chain.from_iterable(gen()))
 
 
 # ---------------------------------------------------------------------------

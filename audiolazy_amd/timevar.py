@@ -45,7 +45,14 @@ class _Pool(object):
 
 
 def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
-  """Generator of output samples for one input stream -- or, in the reference's vector-valued
+  """Iterator of output samples (see :func:`run_blocks`, whose per-block lists it chains: one
+  Python-level resume per block instead of one per sample)."""
+  return itertools.chain.from_iterable(run_blocks(numlist, denlist, seq, memory=memory, zero=zero, block=block,
+                                                  device=device))
+
+
+def run_blocks(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
+  """Generator of lists of output samples, one list per block, for one input stream -- or, in the reference's vector-valued
   idiom, for C parallel streams: items of ``seq`` that are rows of C values, ``zero`` a row,
   ``memory`` a list of rows, and coefficient Streams whose items are numbers (shared by the
   channels) or rows (one coefficient per channel, e.g. ``repeat(ndarray)``).
@@ -140,11 +147,7 @@ def run(numlist, denlist, seq, memory=None, zero=0., block=None, device=0):
                                     float(zero_row[0]), device, None))
     _ffi.check(L.alz_device_sync(device))
     y = d_y.download((n, C), np.float64)
-    if rows:
-      for row in y:
-        yield row
-    else:
-      yield from y[:, 0].tolist()
+    yield list(y) if rows else y[:, 0].tolist()      # one block of results (the caller chains the blocks)
     if n < len(chunk):
       return
 
