@@ -302,8 +302,11 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
       parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk)
     elif not exact:
       err = norm_err(got, ref, 0 if args.layout == "time" else 1)
+      # the reference's own per-sample test (almost_eq, lazy_misc.py:264-267: |a - b| <= 2**-23 |a + b|)
+      close = float(np.mean(np.abs(got - ref) <= 2.0 ** -23 * np.abs(got + ref)))
       parity = ("not bit-exact by design (%s): max normalised error %.3g vs oracle, %d channels x %d samples "
-                "(contract 1e-6)" % ("FMA mode" if args.fused else "time-parallel mode", err, C, nchk))
+                "(contract 1e-6); %.6f of the samples pass the reference's almost_eq"
+                % ("FMA mode" if args.fused else "time-parallel mode", err, C, nchk, close))
       if not err <= 1e-6:
         parity = "MISMATCH: " + parity
     else:

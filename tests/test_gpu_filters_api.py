@@ -226,3 +226,39 @@ def test_vector_valued_samples_like_the_reference(al):
   rows = np.array(list(filt(iter(x), zero=np.full(C, .125), memory=[np.arange(C) * .01, .5])))
   for c in range(C):
     assert same_bits(rows[:, c], list(filt(list(x[:, c]), zero=.125, memory=[c * .01, .5]))), c
+
+
+def test_calls_own_their_state_and_touch_their_input_lazily(al):
+  """Every filter call owns its state like every reference call owns its generator's locals, and
+  the input is not pulled before the result is iterated (reference lazy_filters.py:251-262)."""
+  from oracle import oracle
+  rng = np.random.default_rng(31)
+  xa, xb = rng.uniform(-1, 1, 300).tolist(), rng.uniform(-1, 1, 300).tolist()
+  b, a = [.2, .3], [1., -.5, .25]
+  ref_a, ref_b = oracle.df1(b, a, xa), oracle.df1(b, a, xb)
+  bank = al.FilterBank([(b, a)], n_inputs=1)
+  ya = bank(xa, block=64)
+  first = ya.take(10)                       # the first stream is alive (a block in, 10 items out) ...
+  yb = bank(xb, block=64)                   # ... when the same bank is called again
+  got_b = list(yb)
+  got_a = first + list(ya)
+  assert same_bits(got_a, ref_a) and same_bits(got_b, ref_b)
+  # laziness: nothing is pulled at call time, one block at the first next()
+  pulled = []
+
+  def source():
+    for v in xa:
+      pulled.append(v)
+      yield v
+  filt = al.ZFilter(b, a)
+  out = filt(source())
+  assert pulled == []
+  it = iter(out)
+  next(it)
+  assert 0 < len(pulled) <= al.block_size()
+  # a cascade passes rows (vector-valued samples) on like a single filter does
+  rows = rng.uniform(-1, 1, (50, 3))
+  casc = al.CascadeFilter(al.ZFilter(b, a), al.ZFilter([1., -1.], [1.]))
+  got = np.array(list(casc(iter(rows), zero=np.zeros(3))))
+  ref = oracle.bank([2, 2], [3, 1], np.array(b + [1., -1.]), np.array(a + [1.]), rows)
+  assert same_bits(got, ref)
