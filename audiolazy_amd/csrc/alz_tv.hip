@@ -489,6 +489,35 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
+  // a bank steered by control streams (every series shared by the channels): the two-wave kernel
+  // takes the full tiles, the lane-per-channel kernels below continue with the ragged rest
+  static const bool duo_off = getenv("ALZ_TV_DUO") && atoi(getenv("ALZ_TV_DUO")) == 0;
+  if (!duo_off && channels > 1 && layout == ALZ_TIME_MAJOR && nb <= 3 && na <= 3 && p.gain_mode == 0) {
+    int kind[5], negated[5];
+    double value[5];
+    const double *series[5];
+    bool ok = true;
+    for (int t = 0; t < 5; ++t) {
+      const alz::TvSide &sd = t < 3 ? p.b : p.a;
+      const int k = t < 3 ? t : t - 2;
+      kind[t] = sd.kind[k]; value[t] = sd.value[k]; series[t] = sd.series[k]; negated[t] = sd.negated[k];
+      if (sd.kind[k] == 2 && (sd.sc[k] != 0 || sd.sn[k] != 1)) ok = false;
+    }
+    int64_t done = 0;
+    if (ok) {
+      const int rc = alz::launch_tvduo(p.x, p.y, n, ldx, ldy, channels, nb, na, kind, value, series, negated, xh_dev,
+                                       yh_dev, (hipStream_t)stream, &done);
+      if (rc) { if (prev != device) (void)hipSetDevice(prev); return rc; }
+    }
+    if (done > 0) {
+      p.x += done * p.sxn; p.y += done * p.syn; p.n -= done;
+      for (int k = 0; k < alz::kTvMax; ++k) {
+        if (p.b.kind[k] == 2) p.b.series[k] += done * p.b.sn[k];
+        if (p.a.kind[k] == 2) p.a.series[k] += done * p.a.sn[k];
+      }
+      if (p.n == 0) { if (prev != device) (void)hipSetDevice(prev); return ALZ_OK; }
+    }
+  }
   const unsigned grid = (unsigned)((channels + 63) / 64);
   if (channels == 1 && nb <= 3 && na <= 3) {
     unsigned pb = 0, pa = 0;

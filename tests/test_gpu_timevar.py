@@ -168,3 +168,52 @@ def test_raw_abi_fuzz(al, case):
     pick = lambda v: v[:, ch] if isinstance(v, np.ndarray) and v.ndim == 2 else v
     ref = oracle.tv_df1([pick(v) for v in ref_b], [pick(v) for v in ref_a], x[:, ch], memory=[.125] * (na - 1), zero=.125)
     assert same_bits(got[:, ch], ref), (case, pb, pa, N, C, layout, gain, ch)
+
+
+# ---------------------------------------------------------------------------------------------------
+# k_tvduo (csrc/alz_tvduo.hip): a bank whose coefficient series are shared by the channels -- full
+# 64-row tiles on the two-wave streaming kernel, the ragged rest on the lane-per-channel kernels.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pattern", [(1, 1), (3, 1), (1, 3), (3, 3), (5, 3), (7, 3), (1, 2)])
+@pytest.mark.parametrize("C", [16, 256])
+def test_bank_steered_by_shared_series(al, pattern, C):
+  import torch
+  from audiolazy_amd import timevar
+  pb, pa = pattern
+  rng = np.random.default_rng(100 * pb + 10 * pa + C)
+  N1, N2 = 64 * 5 + 17, 64 * 3              # two blocks: tiles + ragged tail, then the stream goes on
+  N = N1 + N2
+  x = rng.uniform(-1, 1, (N, C))
+  nb = max(k + 1 for k in range(3) if (pb >> k) & 1)
+  na = 1 + max(k for k in (1, 2) if (pa >> (k - 1)) & 1)
+  kinds = ["series", "const", "series"]      # b0 b1 b2: a constant tap next to series taps
+  b_ref, a_ref = [], [1.]
+  for k in range(nb):
+    if not (pb >> k) & 1:
+      b_ref.append(0.)
+    elif kinds[k] == "const":
+      b_ref.append(.37)
+    else:
+      b_ref.append(rng.uniform(-.9, .9, N))
+  for k in range(1, na):
+    a_ref.append(rng.uniform(-.45, .45, N) if (pa >> (k - 1)) & 1 else 0.)
+  dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+  xh = torch.full((max(nb - 1, 1), C), .25, dtype=torch.float64, device="cuda")
+  yh = torch.full((max(na - 1, 1), C), -.125, dtype=torch.float64, device="cuda")
+  xh2, yh2 = xh.clone(), yh.clone()
+
+  def run(lo, hi, per_channel, xh_, yh_):
+    def tap(v):
+      if not isinstance(v, np.ndarray):
+        return v
+      return dev(np.repeat(v[lo:hi, None], C, axis=1)) if per_channel else dev(v[lo:hi])
+    return timevar.process_block([tap(v) for v in b_ref], [tap(v) for v in a_ref], dev(x[lo:hi]),
+                                 xh=xh_, yh=yh_, zero=.25).cpu().numpy()
+  y = np.concatenate([run(0, N1, False, xh, yh), run(N1, N, False, xh, yh)])
+  # the same values as per-channel series: the lane-per-channel kernel, which must give the same doubles
+  y_lane = np.concatenate([run(0, N1, True, xh2, yh2), run(N1, N, True, xh2, yh2)])
+  assert same_bits(y, y_lane)
+  assert torch.equal(xh, xh2) and torch.equal(yh, yh2)
+  for ch in (0, C // 2 + 1, C - 1):
+    ref = oracle.tv_df1(b_ref, a_ref, x[:, ch], memory=[-.125] * (na - 1), zero=.25)
+    assert same_bits(y[:, ch], ref), (pattern, ch)
