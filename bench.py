@@ -456,6 +456,44 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
           "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
+def wl_timevar(ctx, args, alz, C, N, steps, warmup):
+  """A bank steered by control streams: every channel runs the same time-varying
+  resonator, b0[n] x[n] + b2[n] x[n-2] - a1[n] y[n-1] - a2[n] y[n-2], whose coefficient series sweep
+  the centre frequency from 200 Hz to 4 kHz at 48 kHz -- ``resonator.z_exp(Stream(freqs), bw)`` called
+  with vector-valued samples.  One value per tap and sample for the whole bank."""
+  torch = ctx.torch
+  from audiolazy_amd import timevar
+  n = np.arange(N)
+  w = 2 * np.pi * np.geomspace(200., 4000., N) / 48000.
+  r = np.exp(-(2 * np.pi * 100. / 48000.) / 2)
+  g = (1 - r * r) / 2
+  series = {"b0": np.full(N, g) * (1 + 1e-3 * np.sin(n / 997.)), "a1": -2 * r * np.cos(w), "a2": np.full(N, r * r)}
+  dev = {k: torch.from_numpy(v).to(ctx.dev) for k, v in series.items()}
+  b = [dev["b0"], 0., -g]
+  a = [1., dev["a1"], dev["a2"]]
+  x = ctx.noise((N, C), 5)
+  xh = torch.zeros((2, C), dtype=torch.float64, device=ctx.dev)
+  yh = torch.zeros((2, C), dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: timevar.process_block(b, a, x, xh=xh, yh=yh), steps, warmup)
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nchk = 4096
+    xs = x[:nchk].contiguous()
+    got = timevar.process_block([dev["b0"][:nchk].contiguous(), 0., -g],
+                                [1., dev["a1"][:nchk].contiguous(), dev["a2"][:nchk].contiguous()], xs).cpu().numpy()
+    xs = xs.cpu().numpy()
+    pick = [0, 1, C // 2, C - 1]
+    ok = all(bits_equal(got[:, ch], np.array(oracle.tv_df1([series["b0"][:nchk], 0., -g],
+                                                             [1., series["a1"][:nchk], series["a2"][:nchk]], xs[:, ch])))
+             for ch in pick)
+    parity = ("bit-exact vs the pure-Python restatement, channels %s x %d samples" % (pick, nchk)) if ok else "MISMATCH"
+  del x
+  torch.cuda.empty_cache()
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvduo (two-wave streaming kernel, shared coefficient series)",
+          "parity": parity, "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
+
+
 def entry(res, world, steps, unit, workload):
   """A secondary-workload record: same fields as the main line's core."""
   roof = dict(res["roofline"])
@@ -553,6 +591,10 @@ def main():
         r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
         secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
                                           "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel")
+        r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1)
+        secondary["timevar_shared"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples "
+                                            "steered by three coefficient series shared by the channels (Stream coefficients, "
+                                            "lazy_filters.py:197-224)")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel")):
             r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
