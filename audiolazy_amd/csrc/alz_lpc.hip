@@ -225,7 +225,11 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 
 // LEV = true: Levinson-Durbin runs right away on the lane's P lags (still in registers) and the
 // kernel writes coefficients / error / status instead of the lags: lpc.kautocor in one launch.
-template <int P, bool LEV>
+// FMA = true (opt-in, ALZ_LPC_FUSED): every term is one v_fma_f64 instead of a separately rounded
+// multiply and add -- half the instructions of a kernel that is bound by FP64 issue (moving the same
+// 252 MB without computing takes 34 us, tools/ubench_stride.hip), same ascending order per lag, NOT the
+// reference's doubles (differences ~1e-16 relative per lag; the contract is 1e-6).
+template <int P, bool LEV, bool FMA = false>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
                                                      double *__restrict__ coefs, double *__restrict__ err,
@@ -291,9 +295,9 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
           for (int i = 0; i < P; ++i) {
             const double xe = (u - i >= 0) ? cur[u - i >= 0 ? u - i : 0] : hist[(i - u - 1) < H * 16 ? (i - u - 1) : 0];
             if constexpr (decltype(checked)::value) {
-              if (u - i >= 0 || 16 * c + u - i >= 0) acc[i] = acc[i] + xe * xm;
+              if (u - i >= 0 || 16 * c + u - i >= 0) acc[i] = FMA ? __builtin_fma(xe, xm, acc[i]) : acc[i] + xe * xm;
             } else {
-              acc[i] = acc[i] + xe * xm;
+              acc[i] = FMA ? __builtin_fma(xe, xm, acc[i]) : acc[i] + xe * xm;
             }
           }
         }
@@ -501,16 +505,16 @@ __global__ __launch_bounds__(128) void k_acorr_pair(const double *__restrict__ s
 
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
-template <bool LEV>
+template <bool LEV, bool FMA = false>
 static acorr_stage_fn pick_acorr_stage(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9, LEV>;
-    case 11: return k_acorr_stage<11, LEV>;
-    case 13: return k_acorr_stage<13, LEV>;
-    case 17: return k_acorr_stage<17, LEV>;
-    case 21: return k_acorr_stage<21, LEV>;
-    case 25: return k_acorr_stage<25, LEV>;
-    case 33: return k_acorr_stage<33, LEV>;
+    case 9: return k_acorr_stage<9, LEV, FMA>;
+    case 11: return k_acorr_stage<11, LEV, FMA>;
+    case 13: return k_acorr_stage<13, LEV, FMA>;
+    case 17: return k_acorr_stage<17, LEV, FMA>;
+    case 21: return k_acorr_stage<21, LEV, FMA>;
+    case 25: return k_acorr_stage<25, LEV, FMA>;
+    case 33: return k_acorr_stage<33, LEV, FMA>;
     default: return nullptr;
   }
 }
@@ -659,9 +663,9 @@ static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_
 
 extern "C" {
 
-int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_t hop,
-                         int order, double *coefs_dev, double *err_dev, int *status_dev, int device,
-                         void *stream) {
+int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_len, int64_t hop,
+                            int order, double *coefs_dev, double *err_dev, int *status_dev, int flags, int device,
+                            void *stream) {
   if (!sig_dev || !coefs_dev || !err_dev || !status_dev) return alz::fail(ALZ_E_ARG, "NULL argument");
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
@@ -670,8 +674,9 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
   bool done = false;
   if (n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
     // one launch: autocorrelation and Levinson-Durbin in the same lane
-    if (alz::acorr_stage_fn fn = alz::pick_acorr_stage<true>(order + 1)) {
-      alz::acorr_stage_fn pair_fn = alz::pick_acorr_pair<true>(order + 1, n_frames);
+    const bool fused = (flags & ALZ_LPC_FUSED) != 0;
+    if (alz::acorr_stage_fn fn = fused ? alz::pick_acorr_stage<true, true>(order + 1) : alz::pick_acorr_stage<true>(order + 1)) {
+      alz::acorr_stage_fn pair_fn = fused ? nullptr : alz::pick_acorr_pair<true>(order + 1, n_frames);
       hipLaunchKernelGGL(pair_fn ? pair_fn : fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(pair_fn ? 128 : 64), 3 * 8192,
                          (hipStream_t)stream,
                          sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
@@ -703,6 +708,13 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                          nullptr, 0, (hipStream_t)stream);
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
+}
+
+int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_t hop,
+                         int order, double *coefs_dev, double *err_dev, int *status_dev, int device,
+                         void *stream) {
+  return alz_lpc_kautocor_dev_ex(sig_dev, n_frames, frame_len, hop, order, coefs_dev, err_dev, status_dev, 0, device,
+                                 stream);
 }
 
 int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int order,

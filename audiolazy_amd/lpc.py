@@ -20,8 +20,12 @@ def _frame_count(n_samples, frame_len, hop):
   return 0 if n_samples < frame_len else (n_samples - frame_len) // hop + 1
 
 
-def kautocor_frames(sig, frame_len, order, hop=None, device=0):
+def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False):
   """lpc.kautocor on every full frame of ``sig``.
+
+  fused=True opts into fused multiply-adds in the autocorrelation sums (faster: the kernel is bound
+  by FP64 issue; lags differ from the reference's by ~1e-16 relative, so the result is no longer
+  pinned to the last bit -- the contract is 1e-6).
 
   sig : 1-D float64 signal (NumPy) or a [F, frame_len] array of frames, or a
         1-D float64 torch CUDA tensor (results are then CUDA tensors).
@@ -39,16 +43,16 @@ def kautocor_frames(sig, frame_len, order, hop=None, device=0):
     err = torch.empty((F,), dtype=torch.float64, device=sig.device)
     status = torch.empty((F,), dtype=torch.int32, device=sig.device)
     stream = torch.cuda.current_stream(sig.device).cuda_stream
-    _ffi.check(L.alz_lpc_kautocor_dev(flat.data_ptr(), F, frame_len, hop, order, coefs.data_ptr(),
-                                      err.data_ptr(), status.data_ptr(), sig.device.index or 0,
-                                      ctypes.c_void_p(stream)))
+    _ffi.check(L.alz_lpc_kautocor_dev_ex(flat.data_ptr(), F, frame_len, hop, order, coefs.data_ptr(),
+                                         err.data_ptr(), status.data_ptr(), _ffi.LPC_FUSED if fused else 0,
+                                         sig.device.index or 0, ctypes.c_void_p(stream)))
     return coefs, err, status
   flat = np.ascontiguousarray(sig, dtype=np.float64).reshape(-1)
   F = _frame_count(flat.size, frame_len, hop)
   d_sig = _DevBuf(flat.nbytes, device).upload(flat)
   d_c, d_e, d_s = _DevBuf(F * (order + 1) * 8, device), _DevBuf(F * 8, device), _DevBuf(F * 4, device)
-  _ffi.check(L.alz_lpc_kautocor_dev(d_sig.ptr, F, frame_len, hop, order, d_c.ptr, d_e.ptr, d_s.ptr,
-                                    device, None))
+  _ffi.check(L.alz_lpc_kautocor_dev_ex(d_sig.ptr, F, frame_len, hop, order, d_c.ptr, d_e.ptr, d_s.ptr,
+                                       _ffi.LPC_FUSED if fused else 0, device, None))
   _ffi.check(L.alz_device_sync(device))
   return (d_c.download((F, order + 1), np.float64), d_e.download((F,), np.float64),
           d_s.download((F,), np.int32))

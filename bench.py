@@ -406,16 +406,17 @@ def wl_gammatone(ctx, args, alz, steps, warmup):
           "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N}
 
 
-def wl_lpc(ctx, args, alz, steps, warmup):
+def wl_lpc(ctx, args, alz, steps, warmup, fused=False):
   from audiolazy_amd.lpc import kautocor_frames
   F, L, order = 65536, 480, 16
   sig = ctx.noise((F * L,), 3)
-  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order), steps, warmup)
+  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused), steps, warmup)
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
     from oracle import oracle
     nf = 4096
-    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order)
+    nf = 65536 if fused else nf          # (the fused kernel needs >= 16384 frames)
+    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order, fused=fused)
     rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
     worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
     ok = worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs)
@@ -424,7 +425,7 @@ def wl_lpc(ctx, args, alz, steps, warmup):
   del sig
   ctx.torch.cuda.empty_cache()
   return {"units": float(F), "elapsed": elapsed, "parity": parity,
-          "kernel": "k_acorr_stage<17,lev> (autocorrelation + Levinson-Durbin in one launch)",
+          "kernel": "k_acorr_stage<17,lev%s> (autocorrelation + Levinson-Durbin in one launch)" % (",fma" if fused else ""),
           "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
 
 
@@ -588,6 +589,9 @@ def main():
         r = wl_lpc(ctx, args, alz, 20, 3)
         secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
                                  "480-sample frames")
+        r = wl_lpc(ctx, args, alz, 20, 3, fused=True)
+        secondary["lpc_fma"] = entry(r, 1, 20, "Gframes/s", "configs[4] with fused multiply-adds in the autocorrelation "
+                                     "sums (opt-in ALZ_LPC_FUSED; not pinned to the last bit)")
         r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
         secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
                                           "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel")
@@ -630,7 +634,7 @@ def main():
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   else:
-    res = wl_lpc(ctx, args, alz, args.steps, args.warmup)
+    res = wl_lpc(ctx, args, alz, args.steps, args.warmup, fused=args.fused)
     total_units = float(world) * res["units"]
     metric, unit = "Gframes/s through lpc.kautocor (autocorrelation + Levinson-Durbin, order 16, 10 ms frames)", "Gframes/s"
     config = {"workload": "configs[4]: lazy_lpc order-16 on %d concurrent 480-sample frames, float64" % res["F"],

@@ -141,6 +141,16 @@ const char *alz_bank_last_kernel(const alz_bank_t *h);
 int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                          int64_t hop, int order, double *coefs_dev,
                          double *err_dev, int *status_dev, int device, void *stream);
+/* The same with options.  ALZ_LPC_FUSED: the autocorrelation sums use one fused multiply-add per term
+ * instead of a separately rounded multiply and add (the kernel is bound by FP64 issue: half the
+ * instructions).  Same ascending order per lag; the lags are then NOT bit-identical to
+ * lazy_analysis.py:311-312 (relative differences ~1e-16; contract 1e-6).  Needs frames of >= 32
+ * samples, an even hop, >= 16384 frames and a curated order (8, 10, 12, 16, 20, 24, 32); other shapes
+ * run the exact kernels whatever the flag says.  No reference counterpart (CPython never fuses). */
+#define ALZ_LPC_FUSED 1
+int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_len,
+                            int64_t hop, int order, double *coefs_dev,
+                            double *err_dev, int *status_dev, int flags, int device, void *stream);
 /* levinson_durbin alone (lazy_lpc.py:52-136) on ready-made lag lists r [n_frames, n_lags];
  * n_lags <= order is zero-extended like the reference does (:117-118). */
 int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int order,

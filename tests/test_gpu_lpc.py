@@ -138,3 +138,25 @@ def test_large_batch_lane_kernels_bit_exact_acorr(lpc):
   assert np.array_equal(r2[16999].view(np.uint64), oracle.acorr(sig2[16999 * 40:], 16).view(np.uint64))
   r3 = lpc.acorr_frames(sig2, 40, 7)
   assert np.array_equal(r3[3].view(np.uint64), oracle.acorr(sig2[120:160], 7).view(np.uint64))
+
+
+def test_fused_mode_within_contract(lpc):
+  """ALZ_LPC_FUSED (opt-in): fused multiply-adds in the autocorrelation sums; the coefficients stay
+  within 1e-9 of the oracle's (the contract is 1e-6), the status array is the reference's."""
+  import torch
+  from oracle import oracle
+  F, L, order = 16384 + 64, 480, 16
+  sig = np.random.default_rng(77).uniform(-1, 1, F * L)
+  sig[5 * L:6 * L] = 0.0
+  d = torch.from_numpy(sig).cuda()
+  c, e, st = lpc.kautocor_frames(d, L, order, fused=True)
+  c0, e0, st0 = lpc.kautocor_frames(d, L, order)
+  rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
+  st = st.cpu().numpy()
+  assert np.array_equal(st, rs) and np.array_equal(st0.cpu().numpy(), rs)
+  ok = st == 0
+  c, e = c.cpu().numpy(), e.cpu().numpy()
+  scale = np.abs(rc[ok]).max(axis=1, keepdims=True)
+  assert (np.abs(c[ok] - rc[ok]) / scale).max() <= TOL
+  assert (np.abs(e[ok] - re[ok]) / np.abs(re[ok])).max() <= TOL
+  assert not np.array_equal(c[ok], c0.cpu().numpy()[ok])       # it really is the other arithmetic
