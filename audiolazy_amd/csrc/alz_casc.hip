@@ -76,7 +76,9 @@ __device__ __forceinline__ void c_wait_vm(int n) {   // n: a multiple of 4 (half
 // One section over a chunk of W samples held in registers: v[] in, v[] out (in place).
 // NB taps (pattern PB, bit k <=> b_k present), PA bit k-1 <=> a_k present; dx[] = the NB-1
 // previous inputs (dx[0] most recent), m1/m2 the previous outputs.
-template <int W, int NB, unsigned PB, unsigned PA>
+// FMA (opt-in, alz_bank_set_fused): every term after the first is one v_fma_f64 -- 4 instead of 7
+// instructions per step of a gammatone.slaney section, same term order, NOT the reference's doubles.
+template <int W, int NB, unsigned PB, unsigned PA, bool FMA = false>
 __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)[8], double na1,
                                               double na2, double (&dx)[7], double &m1, double &m2) {
   double p[W];
@@ -89,8 +91,12 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
     for (int k = 0; k < NB; ++k) {
       if ((PB >> k) & 1u) {
         const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dx[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
-        const double t = bc[k] * xv;
-        acc = first ? t : acc + t;
+        if (FMA && !first) {
+          acc = __builtin_fma(bc[k], xv, acc);
+        } else {
+          const double t = bc[k] * xv;
+          acc = first ? t : acc + t;
+        }
         first = false;
       }
     }
@@ -106,8 +112,8 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
   for (int u = 0; u < W; ++u) {
     double acc = p[u];
     if constexpr (PB != 0u) {
-      if constexpr (PA & 1u) acc = acc + na1 * m1;
-      if constexpr (PA & 2u) acc = acc + na2 * m2;
+      if constexpr (PA & 1u) acc = FMA ? __builtin_fma(na1, m1, acc) : acc + na1 * m1;
+      if constexpr (PA & 2u) acc = FMA ? __builtin_fma(na2, m2, acc) : acc + na2 * m2;
     } else {
       bool first = true;
       if constexpr (PA & 1u) { acc = na1 * m1; first = false; }
@@ -355,7 +361,7 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // only 256 workgroups wide at G = 64 (cfg4: 256 bands x 64 streams) then has two workgroups per CU
 // whose barrier intervals drift apart: one's section arithmetic runs while the other hands tiles over.
 template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
-          unsigned PA2, unsigned PB3, unsigned PA3>
+          unsigned PA2, unsigned PB3, unsigned PA3, bool FMA = false>
 __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 16, NW = 4 / SPW;
@@ -529,10 +535,10 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 #pragma unroll
           for (int j = 0; j < SPW; ++j) {
             const int s = wave * SPW + j;
-            if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
-            else section_chunk<16, nb_of(PB3), PB3, PA3>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            if (s == 0) section_chunk<16, nb_of(PB0), PB0, PA0, FMA>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 1) section_chunk<16, nb_of(PB1), PB1, PA1, FMA>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else if (s == 2) section_chunk<16, nb_of(PB2), PB2, PA2, FMA>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
+            else section_chunk<16, nb_of(PB3), PB3, PA3, FMA>(v, bc[j], na1[j], na2[j], dx[j], m1[j], m2[j]);
           }
         }
       }
@@ -975,12 +981,12 @@ static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
   return nullptr;
 }
 
-template <bool CM, int SPW, int G = 64>
+template <bool CM, int SPW, int G = 64, bool FMA = false>
 static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
 #define ALZ_PIPE(B0, A0, B1, A1, B2, A2, B3, A3)                                                 \
   if (pb[0] == B0 && pa[0] == A0 && pb[1] == B1 && pa[1] == A1 && pb[2] == B2 && pa[2] == A2 &&  \
       pb[3] == B3 && pa[3] == A3)                                                                \
-    return (casc_fn)k_pipe<CM, SPW, G, B0, A0, B1, A1, B2, A2, B3, A3>;
+    return (casc_fn)k_pipe<CM, SPW, G, B0, A0, B1, A1, B2, A2, B3, A3, FMA>;
   ALZ_PIPE(3, 3, 3, 3, 3, 3, 3, 3)        // gammatone.slaney
   ALZ_PIPE(5, 3, 1, 3, 5, 3, 1, 3)        // gammatone.klapuri
   ALZ_PIPE(0xFE, 3, 1, 3, 1, 3, 1, 3)     // gammatone.sampled
@@ -1051,6 +1057,9 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   casc_fn tandem = nullptr;
   if (nsec == 4 && pipe_env == 3) tandem = cm ? pick_tandem<true>(pb, pa) : pick_tandem<false>(pb, pa);
   if (tandem) { pipe = tandem; g = 64; groups = io.channels / 64; if (groups == 0) return ALZ_OK; }
+  const bool fma = io.fused != 0;
+  if (!pipe && nsec == 4 && fma && pipe_env != 0)
+    pipe = cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa);
   if (!pipe && nsec == 4 && (pipe_env == 1 || pipe_env == 3)) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
   if (!pipe && nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
   const int pipe_waves = tandem ? 10 : pipe_env == 2 ? 4 : 6;   // stage waves + loader + storer
@@ -1077,7 +1086,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * 16;
   *done_channels = groups * g;
-  *kernel_name = tandem ? "k_tandem" : pipe ? (g == 32 ? "k_pipe<32>" : "k_pipe") : "k_casc";
+  *kernel_name = tandem ? "k_tandem" : pipe ? (g == 32 ? "k_pipe<32>" : (fma && nsec == 4 && pipe_env != 0) ? "k_pipe<fma>" : "k_pipe") : "k_casc";
   return ALZ_OK;
 }
 

@@ -374,12 +374,14 @@ def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
           "C": C, "N": N}
 
 
-def wl_gammatone(ctx, args, alz, steps, warmup):
+def wl_gammatone(ctx, args, alz, steps, warmup, fused=False):
   torch = ctx.torch
   B, S, N = 256, 64, 1 << 16            # 512 streams over 8 GPUs -> 64 streams per GPU, all bands local
   s_, Hz = alz.sHz(48000)
   fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
   bank = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz, device=ctx.local)
+  if fused:
+    bank.set_fused(True)
   bank.reset()
   x = ctx.noise((S, N), 2)
   y = torch.empty((B * S, N), dtype=torch.float64, device=ctx.dev)
@@ -398,8 +400,15 @@ def wl_gammatone(ctx, args, alz, steps, warmup):
     bcat = np.repeat(np.array([sum((f.numlist for f in band), []) for band in bands]), S, axis=0)
     acat = np.repeat(np.array([sum((f.denlist for f in band), []) for band in bands]), S, axis=0)
     ref = oracle.bank(nbs, nas, bcat, acat, np.tile(xs.cpu().numpy(), (B, 1)), layout="chan")
-    parity = ("bit-exact vs oracle, %d bands x %d streams x %d samples" % (B, S, nchk)
-              if bits_equal(got, ref) else "MISMATCH")
+    if bits_equal(got, ref):
+      parity = "bit-exact vs oracle, %d bands x %d streams x %d samples" % (B, S, nchk)
+    elif fused:
+      err = norm_err(got, ref, 1)
+      parity = "FMA mode, not bit-exact by design: max normalised error %.3g vs oracle (contract 1e-6)" % err
+      if not err <= 1e-6:
+        parity = "MISMATCH: " + parity
+    else:
+      parity = "MISMATCH"
   del x, y, bank
   torch.cuda.empty_cache()
   return {"units": float(B) * S * N, "elapsed": elapsed, "kernel": kernel, "parity": parity,
@@ -586,6 +595,8 @@ def main():
         r = wl_gammatone(ctx, args, alz, 10, 2)
         secondary["gammatone"] = entry(r, 1, 10, "Gsamples/s", "configs[3]: ERB gammatone filterbank (gammatone.slaney), "
                                        "256 bands x 64 input streams per GPU (512 over 8), 2^16-sample blocks")
+        r = wl_gammatone(ctx, args, alz, 10, 2, fused=True)
+        secondary["gammatone_fma"] = entry(r, 1, 10, "Gsamples/s", "configs[3] in the opt-in FMA mode (alz_bank_set_fused)")
         r = wl_lpc(ctx, args, alz, 20, 3)
         secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
                                  "480-sample frames")
@@ -625,7 +636,7 @@ def main():
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   elif args.workload == "gammatone":
-    res = wl_gammatone(ctx, args, alz, args.steps, args.warmup)
+    res = wl_gammatone(ctx, args, alz, args.steps, args.warmup, fused=args.fused)
     total_units = float(world) * res["units"]
     metric, unit = "Gsamples/s (band x stream x sample outputs) through the ERB gammatone bank", "Gsamples/s"
     config = {"workload": "configs[3]: ERB gammatone filterbank (gammatone.slaney, 4-section cascades), %d bands x %d "

@@ -164,3 +164,20 @@ def test_acorr_default_lag_list_long_block(alz, oracle):
   assert len(got) == 200 and same_bits(got, oracle.acorr(blk, 199))
   big = np.random.default_rng(4).uniform(-1, 1, 5000).tolist()    # too long to stage in LDS
   assert same_bits(alz.acorr(big, 100), oracle.acorr(big, 100))
+
+
+def test_cfg4_fused_mode_within_contract(alz, oracle):
+  """alz_bank_set_fused on the gammatone bank: FMA contraction in the wave pipeline's sections."""
+  import torch
+  B, S, N = 64, 64, 2048
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
+  x = np.random.default_rng(6).uniform(-1, 1, (S, N))
+  exact = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz)
+  exact.reset()
+  y = exact.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
+  fused = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz).set_fused(True)
+  fused.reset()
+  yf = fused.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
+  assert "fma" in fused.last_kernel, fused.last_kernel
+  assert norm_err(yf, y, 1) <= 1e-9 and not same_bits(yf, y)
