@@ -118,7 +118,7 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   int power_section = -1;
 };
 // alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, two-wave streaming kernel
-int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int64_t channels, int nb, int na,
+int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
                  const int *kind, const double *value, const double *const *series, const int *negated,
                  double *xh, double *yh, hipStream_t stream, int64_t *done_samples);
 // alz_map.hip: one elementwise op over n contiguous doubles (see alz_map_dev)

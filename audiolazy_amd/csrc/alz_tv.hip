@@ -492,7 +492,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   // a bank steered by control streams (every series shared by the channels): the two-wave kernel
   // takes the full tiles, the lane-per-channel kernels below continue with the ragged rest
   static const bool duo_off = getenv("ALZ_TV_DUO") && atoi(getenv("ALZ_TV_DUO")) == 0;
-  if (!duo_off && channels > 1 && layout == ALZ_TIME_MAJOR && nb <= 3 && na <= 3 && p.gain_mode == 0) {
+  if (!duo_off && channels > 1 && nb <= 3 && na <= 3 && p.gain_mode == 0) {
     int kind[5], negated[5];
     double value[5];
     const double *series[5];
@@ -505,8 +505,8 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     }
     int64_t done = 0;
     if (ok) {
-      const int rc = alz::launch_tvduo(p.x, p.y, n, ldx, ldy, channels, nb, na, kind, value, series, negated, xh_dev,
-                                       yh_dev, (hipStream_t)stream, &done);
+      const int rc = alz::launch_tvduo(p.x, p.y, n, ldx, ldy, layout == ALZ_CHAN_MAJOR, channels, nb, na, kind, value,
+                                       series, negated, xh_dev, yh_dev, (hipStream_t)stream, &done);
       if (rc) { if (prev != device) (void)hipSetDevice(prev); return rc; }
     }
     if (done > 0) {

@@ -20,8 +20,8 @@
 //             coefficient pair on top of k_duo's recurrence (ghost lanes, skewed lane groups, one
 //             ds_write_b64 per four rows).
 //
-// Constant taps are allowed next to series taps (they are written into the same rings).  Time-major
-// blocks, a0 == 1, 16-channel groups, full 64-row tiles; everything else stays on k_tvp (the ragged
+// Constant taps are allowed next to series taps (they are written into the same rings).  Both
+// layouts, a0 == 1, 16-channel groups, full 64-sample tiles; everything else stays on k_tvp (the ragged
 // tail of a block continues there from the same state arrays).
 #include "alz_common.h"
 
@@ -91,10 +91,14 @@ __device__ __forceinline__ void wait_vm_literal() {
 
 // ND: 1 KiB coefficient transfers per tile (compile-time so that the steady-state s_waitcnt is a literal
 // and the queueing loop is straight-line code: a run-time count cost ~100 scalar instructions per tile)
-template <unsigned PB, unsigned PA, int ND>
+// CM: channel-major blocks ([C, N], one Stream per row), k_duo's layout: a 1 KiB DMA chunk is two channels
+// of 512 B with a 16-byte pad, the p / y rings keep 16 bytes after every channel.
+template <unsigned PB, unsigned PA, int ND, bool CM>
 __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
+  constexpr int kChanPitch = 64 * 8 + 16;                  // bytes per channel row of the p / y rings (CM)
+  constexpr int kPYSlot = CM ? 16 * kChanPitch : kSlot;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -103,21 +107,31 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
   const int64_t nt = p.n_tiles;
   char *xring = smem;
   char *pring = smem + kXRing * kSlot;
-  char *yring = pring + kPRing * kSlot;
-  char *rawring = yring + kYRing * kSlot;          // kXRing slots: lands with the x tile of the same index
+  char *yring = pring + kPRing * kPYSlot;
+  char *rawring = yring + kYRing * kPYSlot;        // kXRing slots: lands with the x tile of the same index
   char *pairring = rawring + kXRing * kRawSlot;    // kPRing slots: written with the p tile of the same index
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const int lane_off = cl * 8;
-#define ALZ_EOFF(u) ((u) * G * 8 + (((u) * G) >> 7) * 16)
-  constexpr int kStep = G * 8;
+  const int lane_off = CM ? cl * T * 8 + ((cl * T) >> 7) * 16 : cl * 8;    // x ring (DMA layout)
+  const int lane_off_p = CM ? cl * kChanPitch : cl * 8;                     // p / y rings
+#define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
+  constexpr int kStep = CM ? 8 : G * 8;
 
   if (wave == 1) {
     // ------------------------------ AUX ------------------------------
-    const int row = lane / 8, cp = lane % 8;
-    const int64_t x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
-    const int64_t y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
-    const int64_t x_chunk = 8 * p.ldx, y_chunk = 8 * p.ldy;
-    const int64_t x_tile = (int64_t)T * p.ldx, y_tile = (int64_t)T * p.ldy;
+    int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+    if (!CM) {
+      const int row = lane / 8, cp = lane % 8;
+      x_off = (int64_t)row * p.ldx + c0 + 2 * cp;
+      y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+      x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
+      x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
+    } else {
+      const int ch = lane / 32, sp = lane % 32;
+      x_off = (c0 + ch) * p.ldx + 2 * sp;
+      y_off = (c0 + ch) * p.ldy + 2 * sp;
+      x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
+      x_tile = T; y_tile = T;
+    }
     double d1 = (p.nb > 1) ? p.xh[0 * p.channels + c] : 0.0;   // x[-1], x[-2] of the stream
     double d2 = (p.nb > 2) ? p.xh[1 * p.channels + c] : 0.0;
     asm volatile("" : "+v"(d1), "+v"(d2));
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
       const char *xs = xring + (int)(t % kXRing) * kSlot + lane_off;
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kSlot + lane_off;  // tile t-1
       const unsigned raw = raw0 + (unsigned)(t % kXRing) * kRawSlot;
-      char *ps = pring + (int)(t % kPRing) * kSlot + lane_off;
+      char *ps = pring + (int)(t % kPRing) * kPYSlot + lane_off_p;
       // (-a1[n], -a2[n]) of row n = lane, for the recurrence wave
       {
         dbl2 pr;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
         *reinterpret_cast<dbl2 *>(pairring + (int)(t % kPRing) * kPairSlot + lane * 16) = pr;
       }
       // feed-forward: lane (q, cl) owns rows 4j + q (j = 0..15) of channel cl
-      const int adj1 = (q == 0) ? 16 : 0, adj2 = (q < 2) ? 16 : 0;
+      const int adj1 = (!CM && q == 0) ? 16 : 0, adj2 = (!CM && q < 2) ? 16 : 0;
       const char *x_d0 = xs + q * kStep;
       const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
       const char *x_d2[2] = {xs + (q - 2) * kStep - adj2, xs + (q - 2) * kStep};
@@ -220,11 +234,13 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
       }
     };
     auto store_tile = [&](int64_t t) {
-      const char *ys = yring + (int)(t % kYRing) * kSlot;
+      const char *ys = yring + (int)(t % kYRing) * kPYSlot;
       double *yt = yg + t * y_tile;
       dbl2 v[kChunks];
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+      for (int j = 0; j < kChunks; ++j)
+        v[j] = *reinterpret_cast<const dbl2 *>(ys + (CM ? (2 * j + lane / 32) * kChanPitch + (lane % 32) * 16
+                                                          : j * 1024 + lane * 16));
 #pragma unroll
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
@@ -272,11 +288,11 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
     int ps_cur = 0, ps_prv = kPRing - 1, ys_cur = 0;
     for (int64_t i = 0; i < nt; ++i) {
       // this lane works on row (u - q) of the tile; u - q < 0 lives in the previous tile's slots
-      const char *cur = pring + ps_cur * kSlot + lane_off - q * kStep;
-      const char *prv = pring + ps_prv * kSlot + lane_off + (T - q) * kStep;
+      const char *cur = pring + ps_cur * kPYSlot + lane_off_p - q * kStep;
+      const char *prv = pring + ps_prv * kPYSlot + lane_off_p + (T - q) * kStep;
       const char *ccur = pairring + ps_cur * kPairSlot - q * 16;
       const char *cprv = pairring + ps_prv * kPairSlot + (T - q) * 16;
-      char *wr = yring + ys_cur * kSlot + lane_off - q * kStep;
+      char *wr = yring + ys_cur * kPYSlot + lane_off_p - q * kStep;
       ps_prv = ps_cur;
       ps_cur = (ps_cur + 1 == kPRing) ? 0 : ps_cur + 1;
       ys_cur = (ys_cur + 1 == kYRing) ? 0 : ys_cur + 1;
@@ -335,19 +351,19 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
 
 typedef void (*tvduo_fn)(TDArgs);
 
-template <int ND>
+template <int ND, bool CM>
 static tvduo_fn pick_tvduo_nd(unsigned pb, unsigned pa) {
-#define ALZ_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) return (tvduo_fn)k_tvduo<PB_, PA_, ND>;
+#define ALZ_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) return (tvduo_fn)k_tvduo<PB_, PA_, ND, CM>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
 }
 
-static tvduo_fn pick_tvduo(unsigned pb, unsigned pa, int n_dma) {
+static tvduo_fn pick_tvduo(unsigned pb, unsigned pa, int n_dma, bool cm) {
   switch (n_dma) {
-    case 1: return pick_tvduo_nd<1>(pb, pa);
-    case 2: return pick_tvduo_nd<2>(pb, pa);
-    case 3: return pick_tvduo_nd<3>(pb, pa);
+    case 1: return cm ? pick_tvduo_nd<1, true>(pb, pa) : pick_tvduo_nd<1, false>(pb, pa);
+    case 2: return cm ? pick_tvduo_nd<2, true>(pb, pa) : pick_tvduo_nd<2, false>(pb, pa);
+    case 3: return cm ? pick_tvduo_nd<3, true>(pb, pa) : pick_tvduo_nd<3, false>(pb, pa);
     default: return nullptr;          // no series tap at all: a plain LTI bank, not this entry point's case
   }
 }
@@ -355,7 +371,7 @@ static tvduo_fn pick_tvduo(unsigned pb, unsigned pa, int n_dma) {
 // The part of a time-varying block the two-wave kernel can take: *done_samples full 64-row tiles of
 // all channels (0: not this kernel's shape).  taps: b0 b1 b2 a1 a2 as (kind, value, series, negated);
 // series must be shared by the channels and contiguous in time.
-int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int64_t channels, int nb, int na,
+int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
                  const int *kind, const double *value, const double *const *series, const int *negated,
                  double *xh, double *yh, hipStream_t stream, int64_t *done_samples) {
   *done_samples = 0;
@@ -366,7 +382,7 @@ int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy
   for (int k = 3; k < 5; ++k) pa |= (unsigned)(kind[k] != 0) << (k - 3);
   int n_series = 0;
   for (int k = 0; k < 5; ++k) n_series += kind[k] == 2;
-  tvduo_fn fn = pick_tvduo(pb, pa, (n_series + 1) / 2);
+  tvduo_fn fn = pick_tvduo(pb, pa, (n_series + 1) / 2, cm != 0);
   if (!fn) return ALZ_OK;
   TDArgs p;
   p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = n / 64; p.channels = channels;
@@ -387,7 +403,9 @@ int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy
     p.dma_src[d][0] = list[2 * d < ns ? 2 * d : 0];
     p.dma_src[d][1] = list[2 * d + 1 < ns ? 2 * d + 1 : (2 * d < ns ? 2 * d : 0)];
   }
-  const size_t lds = (size_t)(kXRing + kPRing + kYRing) * kSlot + (size_t)kXRing * kRawSlot + (size_t)kPRing * kPairSlot;
+  const size_t py_slot = cm ? (size_t)16 * (64 * 8 + 16) : (size_t)kSlot;
+  const size_t lds = (size_t)kXRing * kSlot + (size_t)(kPRing + kYRing) * py_slot + (size_t)kXRing * kRawSlot +
+                     (size_t)kPRing * kPairSlot;
   const int rc = ensure_dynamic_lds((const void *)fn, 96 * 1024);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)(channels / 16)), dim3(128), channels / 16 <= 256 ? (size_t)96 * 1024 : lds, stream, p);

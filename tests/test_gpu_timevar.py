@@ -176,7 +176,8 @@ def test_raw_abi_fuzz(al, case):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("pattern", [(1, 1), (3, 1), (1, 3), (3, 3), (5, 3), (7, 3), (1, 2)])
 @pytest.mark.parametrize("C", [16, 256])
-def test_bank_steered_by_shared_series(al, pattern, C):
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_bank_steered_by_shared_series(al, pattern, C, layout):
   import torch
   from audiolazy_amd import timevar
   pb, pa = pattern
@@ -206,9 +207,14 @@ def test_bank_steered_by_shared_series(al, pattern, C):
     def tap(v):
       if not isinstance(v, np.ndarray):
         return v
-      return dev(np.repeat(v[lo:hi, None], C, axis=1)) if per_channel else dev(v[lo:hi])
-    return timevar.process_block([tap(v) for v in b_ref], [tap(v) for v in a_ref], dev(x[lo:hi]),
-                                 xh=xh_, yh=yh_, zero=.25).cpu().numpy()
+      if not per_channel:
+        return dev(v[lo:hi])
+      full = np.repeat(v[lo:hi, None], C, axis=1)
+      return dev(full if layout == "time" else full.T)
+    xb = x[lo:hi] if layout == "time" else x[lo:hi].T
+    out = timevar.process_block([tap(v) for v in b_ref], [tap(v) for v in a_ref], dev(xb),
+                                xh=xh_, yh=yh_, zero=.25, layout=layout).cpu().numpy()
+    return out if layout == "time" else out.T
   y = np.concatenate([run(0, N1, False, xh, yh), run(N1, N, False, xh, yh)])
   # the same values as per-channel series: the lane-per-channel kernel, which must give the same doubles
   y_lane = np.concatenate([run(0, N1, True, xh2, yh2), run(N1, N, True, xh2, yh2)])
