@@ -58,6 +58,12 @@ def run_blocks(numlist, denlist, seq, memory=None, zero=0., block=None, device=0
   channels) or rows (one coefficient per channel, e.g. ``repeat(ndarray)``).
 
   numlist / denlist : coefficients by delay (constants or iterables), denlist[0] = a0.
+
+  Consumption: a block of ``block`` input items is pulled first, then one value per input item
+  from every coefficient iterator.  When a coefficient iterator ends before the input does, the
+  output ends there like the reference's, but up to one block of input has been consumed beyond
+  that point (the reference's generator pulls exactly one extra input item, lazy_filters.py:251-253);
+  use a small ``block_size`` when the leftover input matters.
   """
   from .bank import memory_to_hist, block_size
   L = _ffi.load()
