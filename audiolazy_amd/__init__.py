@@ -30,4 +30,4 @@ def sHz(rate):
   import math
   return float(rate), 2 * math.pi / rate
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 100 /* 0.1.0 */
+#define ALZ_VERSION 200 /* 0.2.0: + alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
