@@ -129,7 +129,7 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
 // section A, so step u+1 of A and step u of B are independent chains and the in-order wave can
 // fill one recurrence's result latency with the other's ops (twice the ILP of running the two
 // sections back to back).  Same operations in the same order per section: identical doubles.
-template <int W, int NBA, unsigned PBA, unsigned PAA, int NBB, unsigned PBB, unsigned PAB>
+template <int W, int NBA, unsigned PBA, unsigned PAA, int NBB, unsigned PBB, unsigned PAB, bool FMA = false>
 __device__ __forceinline__ void section_pair_chunk(double (&v)[W], const double (&bA)[8], double na1A,
                                                    double na2A, double (&dxA)[7], double &m1A, double &m2A,
                                                    const double (&bB)[8], double na1B, double na2B,
@@ -143,8 +143,12 @@ __device__ __forceinline__ void section_pair_chunk(double (&v)[W], const double 
     for (int k = 0; k < NBA; ++k) {
       if ((PBA >> k) & 1u) {
         const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dxA[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
-        const double t = bA[k] * xv;
-        acc = first ? t : acc + t;
+        if (FMA && !first) {
+          acc = __builtin_fma(bA[k], xv, acc);
+        } else {
+          const double t = bA[k] * xv;
+          acc = first ? t : acc + t;
+        }
         first = false;
       }
     }
@@ -161,8 +165,8 @@ __device__ __forceinline__ void section_pair_chunk(double (&v)[W], const double 
     // section A, step u
     double a = pA[u];
     if constexpr (PBA != 0u) {
-      if constexpr (PAA & 1u) a = a + na1A * m1A;
-      if constexpr (PAA & 2u) a = a + na2A * m2A;
+      if constexpr (PAA & 1u) a = FMA ? __builtin_fma(na1A, m1A, a) : a + na1A * m1A;
+      if constexpr (PAA & 2u) a = FMA ? __builtin_fma(na2A, m2A, a) : a + na2A * m2A;
     } else {
       bool first = true;
       if constexpr (PAA & 1u) { a = na1A * m1A; first = false; }
@@ -178,14 +182,18 @@ __device__ __forceinline__ void section_pair_chunk(double (&v)[W], const double 
     for (int k = 0; k < NBB; ++k) {
       if ((PBB >> k) & 1u) {
         const double xv = (u - k >= 0) ? av[u - k < 0 ? 0 : u - k] : dxB[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
-        const double t = bB[k] * xv;
-        b = firstb ? t : b + t;
+        if (FMA && !firstb) {
+          b = __builtin_fma(bB[k], xv, b);
+        } else {
+          const double t = bB[k] * xv;
+          b = firstb ? t : b + t;
+        }
         firstb = false;
       }
     }
     if constexpr (PBB != 0u) {
-      if constexpr (PAB & 1u) b = b + na1B * m1B;
-      if constexpr (PAB & 2u) b = b + na2B * m2B;
+      if constexpr (PAB & 1u) b = FMA ? __builtin_fma(na1B, m1B, b) : b + na1B * m1B;
+      if constexpr (PAB & 2u) b = FMA ? __builtin_fma(na2B, m2B, b) : b + na2B * m2B;
     } else {
       bool first = true;
       if constexpr (PAB & 1u) { b = na1B * m1B; first = false; }
@@ -526,10 +534,10 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       if (!ALZ_DBG(p, 2)) {
         if constexpr (SPW == 2) {
           if (wave == 0)
-            section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1>(
+            section_pair_chunk<16, nb_of(PB0), PB0, PA0, nb_of(PB1), PB1, PA1, FMA>(
                 v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
           else
-            section_pair_chunk<16, nb_of(PB2), PB2, PA2, nb_of(PB3), PB3, PA3>(
+            section_pair_chunk<16, nb_of(PB2), PB2, PA2, nb_of(PB3), PB3, PA3, FMA>(
                 v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
         } else {
 #pragma unroll
@@ -1058,6 +1066,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   if (nsec == 4 && pipe_env == 3) tandem = cm ? pick_tandem<true>(pb, pa) : pick_tandem<false>(pb, pa);
   if (tandem) { pipe = tandem; g = 64; groups = io.channels / 64; if (groups == 0) return ALZ_OK; }
   const bool fma = io.fused != 0;
+  if (!pipe && nsec == 4 && fma && pipe_env == 2)      // A/B: two sections per stage wave with fused arithmetic
+    pipe = cm ? pick_pipe<true, 2, 64, true>(pb, pa) : pick_pipe<false, 2, 64, true>(pb, pa);
   if (!pipe && nsec == 4 && fma && pipe_env != 0)
     pipe = cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa);
   if (!pipe && nsec == 4 && (pipe_env == 1 || pipe_env == 3)) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
