@@ -55,6 +55,8 @@ struct alz_bank {
   int input_map = 0;                    // ALZ_MAP_ABS / NEG / SQUARE applied to every input sample, or 0
   double *map_in = nullptr;             // the mapped input block when the stage is not fused into a kernel
   uint64_t map_in_bytes = 0;
+  double *expand_in = nullptr;          // OUTER bank with few inputs: the input with one column / row per channel
+  uint64_t expand_in_bytes = 0;
   int64_t time_parallel = 0;            // 0 off (default), -1 automatic chunk length, > 0 chunk length
   std::vector<alz::ScanScratch> scan;   // per section: chunk states and the cached transition matrices
   // staging for process_host and for out-of-place generic sections
@@ -293,6 +295,7 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->stage_y) (void)hipFree(h->stage_y);
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->map_in) (void)hipFree(h->map_in);
+  if (h->expand_in) (void)hipFree(h->expand_in);
   for (hipStream_t st : h->host_streams)
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->host_events) (void)hipEventDestroy(ev);
@@ -422,8 +425,26 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   io.mode = h->mode;
   io.zero = h->zero;
   io.fused = h->fused;
-  const int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
+  int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
+  // An OUTER bank whose inputs are fewer than a workgroup's channels (a gammatone bank on one stream:
+  // every band reads the same samples) cannot feed the streaming / pipeline kernels by input index.
+  // Give it one input column (row) per channel first: one streaming pass the size of the output, after
+  // which every kernel reads it like a diagonal bank's input.
+  int outer_by_input = h->mode == ALZ_BANK_OUTER;
+  if (outer_by_input && (h->n_inputs % 64) != 0 && h->channels >= 64 && x_dev != y_dev) {
+    const int64_t lde = layout == ALZ_TIME_MAJOR ? ((h->channels + 1) & ~(int64_t)1) : ((n + 1) & ~(int64_t)1);
+    const uint64_t extent = layout == ALZ_TIME_MAJOR ? (uint64_t)n * lde : (uint64_t)h->channels * lde;
+    int rc = grow(&h->expand_in, &h->expand_in_bytes, extent * 8);
+    if (rc) return rc;
+    const int64_t sen = layout == ALZ_TIME_MAJOR ? lde : 1, sec = layout == ALZ_TIME_MAJOR ? 1 : lde;
+    rc = alz::launch_expand(x_dev, h->expand_in, n, h->channels, h->n_inputs, sxn, sxc, sen, sec, st);
+    if (rc) return rc;
+    x_dev = h->expand_in;
+    sxn = sen;
+    sxc = sec;
+    outer_by_input = 0;
+  }
   // extent of y in elements, for the out-of-place copy some sections need
   const uint64_t y_extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
                                                       : (uint64_t)((h->channels - 1) * ldy + n);
@@ -450,7 +471,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
         io.x = x_dev + t_first * sxn;
         io.sxn = sxn;
         io.sxc = sxc;
-        io.map_input = h->mode == ALZ_BANK_OUTER;
+        io.map_input = outer_by_input;
         io.pre_op = pre_fused;
       } else {
         io.x = io.y;
@@ -510,7 +531,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     io.n = n;
     io.x = x_dev; io.y = y_dev;
     io.sxn = sxn; io.sxc = sxc; io.syn = syn; io.syc = syc;
-    io.map_input = h->mode == ALZ_BANK_OUTER;
+    io.map_input = outer_by_input;
     io.c_first = 0; io.c_count = h->channels;
     const char *name = "";
     int rc = alz::launch_cascade(h->sec.data(), h->n_sections, io, st, &fused_n, &fused_c, &name);

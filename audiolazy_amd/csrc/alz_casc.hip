@@ -32,6 +32,7 @@ struct CArgs {
   int64_t channels, n_inputs, n_sets;
   int64_t c_first;
   int mode;
+  int map_input;   // OUTER bank: x is indexed by input (channel % n_inputs); 0: x already has one row / column per channel
   int nsec;
   int nb[4], na[4];
   const double *b[4], *a[4];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   // OUTER: channel = set * n_inputs + input; the 64 channels of a wave share one set
   const bool outer = p.mode == ALZ_BANK_OUTER;
-  const int64_t in0 = outer ? c0 % p.n_inputs : c0;
+  const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
 
   int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
   const int64_t c = c0 + cl;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const bool outer = p.mode == ALZ_BANK_OUTER;
-  const int64_t in0 = outer ? c0 % p.n_inputs : c0;
+  const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   // stage w reads tile t - LAG w (and, overlapped, computes tile t - LAG w - 1) in interval t;
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(640) void k_tandem(CArgs p) {
   const int64_t c = c0 + lane;
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const bool outer = p.mode == ALZ_BANK_OUTER;
-  const int64_t in0 = outer ? c0 % p.n_inputs : c0;
+  const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
   const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
   constexpr int store_lag = 12;
@@ -1047,16 +1048,18 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   // skeleton does not shrink with the tile; kept for A/B runs only, ALZ_PIPE_G=32)
   int g = 64;
   if (pipe_g_env == 32 && nsec == 4 && pipe_env == 1 && io.channels % 32 == 0 &&
-      (io.mode != ALZ_BANK_OUTER || io.n_inputs % 32 == 0))
+      (io.mode != ALZ_BANK_OUTER || !io.map_input || io.n_inputs % 32 == 0))
     g = 32;
-  if (io.mode == ALZ_BANK_OUTER && (io.n_inputs % g) != 0) return ALZ_OK;  // a workgroup = channels of one band
+  // OUTER banks that read their input by input index: a workgroup's channels must be adjacent inputs of one band
+  const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
+  if (by_input && (io.n_inputs % g) != 0) return ALZ_OK;
   const int64_t tiles = io.n / 16;
   int64_t groups = io.channels / g;
   if (groups == 0 || tiles == 0) return ALZ_OK;
   casc_fn pipe = nullptr;
   if (nsec == 4 && pipe_env == 1 && g == 32) pipe = cm ? pick_pipe<true, 1, 32>(pb, pa) : pick_pipe<false, 1, 32>(pb, pa);
   if (!pipe) {
-    if (g == 32 && (io.mode == ALZ_BANK_OUTER && (io.n_inputs % 64) != 0)) return ALZ_OK;
+    if (g == 32 && by_input && (io.n_inputs % 64) != 0) return ALZ_OK;
     g = 64;
     groups = io.channels / 64;
     if (groups == 0) return ALZ_OK;
@@ -1078,7 +1081,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   CArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = tiles;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
-  p.c_first = 0; p.mode = io.mode; p.nsec = nsec;
+  p.c_first = 0; p.mode = io.mode; p.map_input = io.map_input; p.nsec = nsec;
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   for (int s = 0; s < 4; ++s) {

@@ -139,6 +139,27 @@ int launch_map(int op, const double *x, const double *y, double p0, double p1, i
   return ALZ_OK;
 }
 
+// OUTER bank with few inputs: x [n, n_inputs] -> xe with one column (time-major) / row (channel-major)
+// per channel, channel c holding input c % n_inputs, so that the streaming kernels can read it like a
+// diagonal bank's input (a gammatone bank on ONE stream is 256 channels that all read the same samples)
+__global__ __launch_bounds__(256) void k_expand(const double *x, double *xe, int64_t n, int64_t channels, int64_t n_inputs,
+                                                int64_t sxn, int64_t sxc, int64_t sen, int64_t sec, int time_major) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * channels) return;
+  const int64_t t = time_major ? i / channels : i % n, c = time_major ? i % channels : i / n;   // the fast index is contiguous in xe
+  xe[t * sen + c * sec] = x[t * sxn + (c % n_inputs) * sxc];
+}
+
+int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int64_t n_inputs, int64_t sxn, int64_t sxc,
+                  int64_t sen, int64_t sec, hipStream_t stream) {
+  const int64_t total = n * channels;
+  if (total == 0) return ALZ_OK;
+  hipLaunchKernelGGL(k_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, xe, n, channels, n_inputs,
+                     sxn, sxc, sen, sec, sec == 1 ? 1 : 0);
+  ALZ_HIP_CHECK(hipGetLastError());
+  return ALZ_OK;
+}
+
 }  // namespace alz
 
 extern "C" int alz_map_dev(int op, const double *x_dev, const double *y_dev, double p0, double p1, int64_t n,

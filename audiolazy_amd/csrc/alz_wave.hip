@@ -684,9 +684,10 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
   if (sec.any_div) g = 16;      // a0 != 1 somewhere: only the two-wave kernel has the dividing form
   const bool outer = io.mode == ALZ_BANK_OUTER;
-  if (outer) {
-    // a wave's channels must be adjacent inputs of ONE coefficient set; later cascade sections of
-    // an OUTER bank (map_input == 0) read y with the channel's own index, i.e. like a diagonal bank
+  if (outer && io.map_input) {
+    // the first section of an OUTER bank reads x by input index: a wave's channels must be adjacent inputs
+    // of ONE coefficient set.  Later cascade sections (and a bank whose input was expanded to one column
+    // per channel, alz_api.hip) read by the channel's own index, like a diagonal bank.
     while (g > 16 && io.n_inputs % g) g /= 2;
     if (io.n_inputs % g) return ALZ_OK;
   }

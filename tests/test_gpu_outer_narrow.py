@@ -1,0 +1,128 @@
+"""OUTER banks with few inputs: a filterbank on ONE stream (or three) -- the reference's own use of
+``gammatone`` / ``resonator`` banks (``[filt(sig) for filt in bank]``, audiolazy/lazy_auditory.py
+:83-230).  The engine gives such a bank one input column per channel first (csrc/alz_api.hip,
+``k_expand``) so that the streaming / pipeline kernels take it instead of the lane-per-channel
+fallback; the results must not change by a bit, and the opt-in time-parallel mode becomes available.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def alz():
+  import audiolazy_amd
+  audiolazy_amd.load_library()
+  assert audiolazy_amd.device_count() >= 1, "no HIP device: the engine has no CPU path"
+  return audiolazy_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+  from oracle import oracle as o
+  return o
+
+
+def same_bits(a, b):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  return a.shape == b.shape and bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)))
+
+
+def norm_err(got, ref, axis):
+  den = np.abs(ref).max(axis=axis)
+  den[den == 0] = 1.0
+  return float((np.abs(got - ref).max(axis=axis) / den).max())
+
+
+def gammatone_reference(alz, oracle, fcs, Hz, x_chan, strategy="slaney"):
+  """Every band's cascade on every stream through the CPU oracle; x_chan is [streams, n]."""
+  S = x_chan.shape[0]
+  k = alz.gammatone_erb_constants(4)[0]
+  bands = [getattr(alz.gammatone, strategy)(fc, k * alz.erb(fc, Hz)) for fc in fcs]
+  nbs = [max(len(band[s].numlist) for band in bands) for s in range(4)]
+  nas = [max(len(band[s].denlist) for band in bands) for s in range(4)]
+
+  def row(band, attr, sizes):
+    out = []
+    for s, n in enumerate(sizes):
+      lst = list(getattr(band[s], attr))
+      out += lst + [0.0] * (n - len(lst))
+    return out
+  bcat = np.repeat(np.array([row(band, "numlist", nbs) for band in bands]), S, axis=0)
+  acat = np.repeat(np.array([row(band, "denlist", nas) for band in bands]), S, axis=0)
+  return oracle.bank(nbs, nas, bcat, acat, np.tile(x_chan, (len(fcs), 1)), layout="chan")
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+@pytest.mark.parametrize("streams,bands", [(1, 256), (3, 64), (1, 70), (5, 13)])
+def test_gammatone_bank_on_few_streams(alz, oracle, layout, streams, bands):
+  import torch
+  N = 2048 + 22
+  s_, Hz = alz.sHz(44100)
+  fcs = [f * Hz for f in alz.erb_space(80., 16000., bands)]
+  bank = alz.gammatone_bank(fcs, streams, strategy="slaney", Hz=Hz)
+  bank.reset()
+  rng = np.random.default_rng(100 * streams + bands)
+  x = rng.uniform(-1, 1, (streams, N))
+  xin = x if layout == "chan" else np.ascontiguousarray(x.T)
+  y = bank.process(torch.from_numpy(xin).cuda(), layout=layout).cpu().numpy()
+  ref = gammatone_reference(alz, oracle, fcs, Hz, x)
+  assert same_bits(y if layout == "chan" else y.T, ref), bank.last_kernel
+  if (streams * bands) % 64 == 0:        # whole 64-channel groups: the wave pipeline takes them
+    assert "k_pipe" in bank.last_kernel or "k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel, bank.last_kernel
+  # a second block: the state carried on the device, the expanded input rebuilt for the new block
+  x2 = rng.uniform(-1, 1, (streams, 777))
+  xin2 = x2 if layout == "chan" else np.ascontiguousarray(x2.T)
+  y2 = bank.process(torch.from_numpy(xin2).cuda(), layout=layout).cpu().numpy()
+  ref2 = gammatone_reference(alz, oracle, fcs, Hz, np.concatenate([x, x2], axis=1))[:, N:]
+  assert same_bits(y2 if layout == "chan" else y2.T, ref2), bank.last_kernel
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_resonator_bank_on_one_stream_single_section(alz, oracle, layout):
+  """One biquad section per band, one stream: the streaming kernel instead of the lane-per-channel one."""
+  import torch
+  import bench
+  C, N = 512, 8192 + 6
+  b, a = bench.resonator_coefs(C)
+  x = np.random.default_rng(8).uniform(-1, 1, (1, N))
+  bank = alz.FilterBank([(b, a)], n_inputs=1, mode="outer")
+  bank.reset()
+  xin = x if layout == "chan" else np.ascontiguousarray(x.T)
+  y = bank.process(torch.from_numpy(xin).cuda(), layout=layout).cpu().numpy()
+  ref = oracle.bank([3], [3], b, a, np.tile(x, (C, 1)), layout="chan")
+  assert same_bits(y if layout == "chan" else y.T, ref), bank.last_kernel
+  assert "k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel, bank.last_kernel
+
+
+def test_one_stream_bank_time_parallel(alz, oracle):
+  """The opt-in time-parallel mode on a 256-band bank fed by ONE stream (not available while the
+  first section had to read its input by input index)."""
+  import torch
+  import bench
+  C, N = 256, 65536
+  b, a = bench.resonator_coefs(C)
+  x = np.random.default_rng(12).uniform(-1, 1, (N, 1))
+  bank = alz.FilterBank([(b, a)], n_inputs=1, mode="outer").set_time_parallel(True)
+  bank.reset()
+  y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
+  assert "scan" in bank.last_kernel, bank.last_kernel
+  ref = oracle.bank([3], [3], b, a, np.tile(x.T, (C, 1)), layout="chan").T
+  assert norm_err(y, ref, 0) <= 1e-8
+
+
+def test_abs_input_map_with_expanded_input(alz, oracle):
+  """envelope.abs on a bank of smoothers fed by one stream: |x| fused into the section's reads of the expanded input."""
+  import torch
+  C, N = 128, 4096
+  rng = np.random.default_rng(4)
+  pole = rng.uniform(0.9, 0.999, C)
+  b = (1 - pole)[:, None]
+  a = np.stack([np.ones(C), -pole], axis=1)
+  x = rng.uniform(-1, 1, (N, 1))
+  bank = alz.FilterBank([(b, a)], n_inputs=1, mode="outer").set_input_map("abs")
+  bank.reset()
+  y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
+  ref = oracle.bank([1], [2], b, a, np.tile(np.abs(x).T, (C, 1)), layout="chan").T
+  assert same_bits(y, ref), bank.last_kernel
