@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "alz_common.h"
+#include <type_traits>
 
 namespace alz {
 
@@ -124,6 +125,69 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
     m2 = m1;
     m1 = acc;
   }
+}
+
+// The same section over a 16-sample tile, handing every finished pair of outputs (2j, 2j + 1) to
+// `emit` as soon as it exists, and pinning that order for the instruction scheduler: group j =
+// {feed-forward sums of pair j + 1, recurrence of pair j, emit(j)}.  k_pipe's stage waves use it to
+// spread the LDS writes of the hand-over through the arithmetic of the interval instead of queueing
+// them all (four waves x 8 KiB at ~64 B/clk) behind the last recurrence step.  Same operations in the
+// same order as section_chunk: identical doubles.
+// `pre(j)` runs at the head of group j (k_pipe: the LDS read of piece j of the NEXT tile).
+template <int NB, unsigned PB, unsigned PA, bool FMA, typename Emit, typename Pre>
+__device__ __forceinline__ void section_tile_emit(const double (&v)[16], const double (&bc)[8], double na1, double na2,
+                                                  double (&dx)[7], double &m1, double &m2, Emit emit, Pre pre) {
+  double p[16], o[16];
+  auto ff = [&](int u) {
+    double acc = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if ((PB >> k) & 1u) {
+        const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dx[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
+        if (FMA && !first) {
+          acc = __builtin_fma(bc[k], xv, acc);
+        } else {
+          const double t = bc[k] * xv;
+          acc = first ? t : acc + t;
+        }
+        first = false;
+      }
+    }
+    p[u] = acc;
+  };
+  ff(0);
+  ff(1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pre(j);
+    if (j + 1 < 8) {
+      ff(2 * j + 2);
+      ff(2 * j + 3);
+    }
+#pragma unroll
+    for (int u = 2 * j; u < 2 * j + 2; ++u) {
+      double acc = p[u];
+      if constexpr (PB != 0u) {
+        if constexpr (PA & 1u) acc = FMA ? __builtin_fma(na1, m1, acc) : acc + na1 * m1;
+        if constexpr (PA & 2u) acc = FMA ? __builtin_fma(na2, m2, acc) : acc + na2 * m2;
+      } else {
+        bool first = true;
+        if constexpr (PA & 1u) { acc = na1 * m1; first = false; }
+        if constexpr (PA & 2u) { const double t = na2 * m2; acc = first ? t : acc + t; }
+      }
+      o[u] = acc;
+      m2 = m1;
+      m1 = acc;
+    }
+    emit(j, o[2 * j], o[2 * j + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double ndx[7];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) ndx[k] = (15 - k >= 0) ? v[15 - k < 0 ? 0 : 15 - k] : dx[k - 16 < 0 ? 0 : k - 16];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) dx[k] = ndx[k];
 }
 
 // Two consecutive sections over a chunk in ONE loop: step u of section B only needs step u of
@@ -362,6 +426,35 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // 394 Gsamples/s on cfg4: all the LDS traffic of the six waves then lands at the start of the
 // interval), kept for A/B only.
 
+// ALZ_PIPE_DIRECT (time-major blocks, G = 64, OVL = 1 only; bit 1: input, bit 2: output): the first
+// stage wave reads its tile straight from global memory into registers (a row of 64 channels is 512
+// contiguous bytes; three tiles in flight in four rotating register sets) and the last stage wave
+// stores its results straight from registers, instead of both going through LDS and the two helper
+// waves: 32 of the 80 KiB an interval moves through the CU's LDS pipe disappear.
+// Measured on cfg4 (profiles/r02_pipe_direct.log, Gsamples/s, bit-exact / FMA mode): LDS path 393 - 407 /
+// 437 - 453; direct input 424 - 442 / 499 - 522 in both layouts (channel-major: bit 4, a lane reads the 128
+// contiguous bytes of its own row with eight 16-byte loads); direct output 387 (slower: the last stage's 16
+// stores sit in its critical path), both 429.  Shipped: 5 = direct input in both layouts.
+#ifndef ALZ_PIPE_DIRECT
+#define ALZ_PIPE_DIRECT 5
+#endif
+// ALZ_PIPE_EARLYW (one section per stage wave, OVL = 1).  1: a stage writes each 16-byte piece of its
+// output tile as soon as the two samples exist (section_tile_emit) instead of all eight after the
+// last step.  2: in the steady state the eight LDS reads of the stage's NEXT input tile are spread over
+// the same eight groups as well (stage_pf), so the CU's LDS pipe sees an even stream of one read and
+// one write per wave and group instead of two bursts per interval.
+// Measured on cfg4, channel-major, on top of the direct input (profiles/r02_pipe_direct.log): 0: 424 - 438,
+// 1: 436 - 451, 2: 474 Gsamples/s; time-major 425 - 442 throughout.
+#ifndef ALZ_PIPE_EARLYW
+#define ALZ_PIPE_EARLYW 2
+#endif
+// ALZ_PIPE_TWO 1 (experiment; needs the direct input): no x ring in LDS (67 KiB per workgroup), at most 168
+// VGPRs per wave and three register sets in the first stage, so that TWO workgroups share a CU when
+// the bank has at least two per CU -- one's arithmetic runs while the other waits at its barrier.
+#ifndef ALZ_PIPE_TWO
+#define ALZ_PIPE_TWO 0
+#endif
+
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
 // G = channels per workgroup.  64: every lane of a stage wave is a channel, one workgroup fills a CU's
 // LDS.  32: half-width workgroups with 4 KiB tiles, so that TWO of them share a CU -- lanes 32..63 of
@@ -369,9 +462,21 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // so EXEC stays full; ghosts read the same LDS words by broadcast and do not write).  A bank that is
 // only 256 workgroups wide at G = 64 (cfg4: 256 bands x 64 streams) then has two workgroups per CU
 // whose barrier intervals drift apart: one's section arithmetic runs while the other hands tiles over.
+// timing ablations (-DALZ_ABLATE builds only; wrong results): bit 8 = no barriers, bit 16 = no LDS drain before them
+#define PIPE_BARRIER() do { if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier(); } while (0)
+// (the builtin, not inline asm: the compiler's own wait-count pass then knows that the LDS reads of this
+// interval have landed and does not guard next interval's arithmetic with waits of its own)
+#ifndef ALZ_PIPE_DRAINB
+#define ALZ_PIPE_DRAINB 1
+#endif
+#if ALZ_PIPE_DRAINB
+#define PIPE_DRAIN() do { if (!ALZ_DBG(p, 16)) { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } } while (0)
+#else
+#define PIPE_DRAIN() do { if (!ALZ_DBG(p, 16)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#endif
 template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
           unsigned PA2, unsigned PB3, unsigned PA3, bool FMA = false>
-__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
+__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3 : 1)) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 16, NW = 4 / SPW;
   constexpr int NCHK = G / 8;                    // 1 KiB DMA / store chunks per tile
@@ -391,6 +496,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
   // t - kDeLag[w]; the storer writes out tile t - 5 in the second half.
   constexpr bool DEPHASE = OVL == 3 && SPW == 1;
   constexpr int kDeLag[4] = {0, 1, 3, 4};
+  constexpr bool DIRECT_IN = (ALZ_PIPE_DIRECT & (CM ? 4 : 1)) && G == 64 && OVL == 1;
+  constexpr bool DIRECT_OUT = (ALZ_PIPE_DIRECT & 2) && !CM && G == 64 && OVL == 1;
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -407,9 +514,10 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
   // stage w reads tile t - LAG w (and, overlapped, computes tile t - LAG w - 1) in interval t;
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
   constexpr int store_lag = DEPHASE ? 5 : LAG * NW;
-  const int64_t n_iv = (nt + store_lag + 1 + 5) / 6 * 6;    // a multiple of the 2- and 3-interval unrolls
+  const int64_t n_iv = (nt + store_lag + 1 + 11) / 12 * 12;  // a multiple of the 2-, 3- and 4-interval unrolls
+  constexpr bool NO_XRING = ALZ_PIPE_TWO && DIRECT_IN;
   char *xring = smem;
-  char *qring = smem + kPXRing * kSlot;                  // NW-1 hand-off rings, 2 slots each
+  char *qring = smem + (NO_XRING ? 0 : kPXRing) * kSlot;  // NW-1 hand-off rings, 2 slots each
   char *yring = qring + (NW - 1) * 2 * kSlot;
   const int lane_off = CM ? (cl / 8) * 1040 + (cl % 8) * 128 : cl * 8;
   int swz[8];
@@ -444,28 +552,28 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 #pragma unroll
         for (int j = 0; j < NCHK; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlot + j * 1040);
       };
-      const bool on = !ALZ_DBG(p, 1);
+      const bool on = !ALZ_DBG(p, 1) && !DIRECT_IN;
       for (int t = 0; t < D && t < nt && on; ++t) queue_tile(t);
       {
         const int64_t after = ((nt < D ? nt : D) - 1);
         c_wait_vm(on ? (int)(after > 5 ? 5 : after) * NCHK : 0);   // tile 0 has landed
       }
-      __builtin_amdgcn_s_barrier();
+      PIPE_BARRIER();
       for (int64_t t = 0; t < n_iv; ++t) {
         if (t + D < nt && on) queue_tile(t + D);
         if (t + 1 < nt) {
           const int64_t last = (t + D < nt - 1) ? t + D : nt - 1;
           c_wait_vm(on ? (int)(last - (t + 1)) * NCHK : 0);  // tile t+1 has landed
         }
-        __builtin_amdgcn_s_barrier();
-        if constexpr (DEPHASE) __builtin_amdgcn_s_barrier();
+        PIPE_BARRIER();
+        if constexpr (DEPHASE) PIPE_BARRIER();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-      __builtin_amdgcn_s_barrier();
+      PIPE_BARRIER();
       for (int64_t t = 0; t < n_iv; ++t) {
-        if constexpr (DEPHASE) __builtin_amdgcn_s_barrier();   // (first half: stage 3 writes the tile read below)
-        if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4)) {
+        if constexpr (DEPHASE) PIPE_BARRIER();   // (first half: stage 3 writes the tile read below)
+        if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4) && !DIRECT_OUT) {
           const int64_t tt = t - store_lag;
           const char *ys = yring + (int)(tt % 2) * kSlot;
           double *yt = yg + tt * y_tile;
@@ -475,8 +583,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 #pragma unroll
           for (int j = 0; j < NCHK; ++j) c_store16(yt + j * y_chunk, w[j]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -554,7 +662,11 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
     };
     auto write_tile = [&](int64_t tile, const double (&v)[16]) {
       if (G < 64 && !real) return;                          // ghost lanes hold the same doubles: one copy is written
-      if (wave == NW - 1) {
+      if (DIRECT_OUT && wave == NW - 1) {
+        double *dst = p.y + (tile * T) * p.ldy + c0 + lane;   // 16 rows of 512 contiguous bytes
+#pragma unroll
+        for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], dst + u * p.ldy);
+      } else if (wave == NW - 1) {
         char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
 #pragma unroll
         for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
@@ -570,10 +682,89 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       }
     };
     auto work_tile = [&](int64_t tile, double (&v)[16]) {
-      do_sections(v);
-      write_tile(tile, v);
+      if constexpr (ALZ_PIPE_EARLYW && SPW == 1 && G == 64 && OVL == 1) {
+        if (ALZ_DBG(p, 2)) return;
+        if (wave == NW - 1) {
+          if (DIRECT_OUT) {
+            double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
+            section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+                [&](int j, double a, double b) {
+                  __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
+                  __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
+                }, [](int) {});
+          } else {
+            char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
+            section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+                [&](int j, double a, double b) {
+                  if constexpr (CM) {
+                    cdbl2 w;
+                    w.x = a;
+                    w.y = b;
+                    *reinterpret_cast<cdbl2 *>(dst + swz[j]) = w;
+                  } else {
+                    *reinterpret_cast<double *>(dst + ALZ_COFF(2 * j)) = a;
+                    *reinterpret_cast<double *>(dst + ALZ_COFF(2 * j + 1)) = b;
+                  }
+                }, [](int) {});
+          }
+        } else {
+          char *dst = qring + (wave * 2 + (int)(tile % 2)) * kSlot + cl * 16;
+          auto emit = [&](int j, double a, double b) {
+            cdbl2 w;
+            w.x = a;
+            w.y = b;
+            *reinterpret_cast<cdbl2 *>(dst + j * kPiece) = w;
+          };
+          if (wave == 0) section_tile_emit<nb_of(PB0), PB0, PA0, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+          else if (wave == 1) section_tile_emit<nb_of(PB1), PB1, PA1, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+          else section_tile_emit<nb_of(PB2), PB2, PA2, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+        }
+      } else {
+        do_sections(v);
+        write_tile(tile, v);
+      }
     };
-    __builtin_amdgcn_s_barrier();
+    // ALZ_PIPE_EARLYW == 2, stages 1..3 in their steady state: work on `tile` (in v) while the eight LDS
+    // reads of the stage's next input tile ride in the same groups as the eight writes of this one, so
+    // that the CU's LDS pipe sees an even stream instead of bursts.  The stage index is a compile-time
+    // constant here: straight-line code per stage, no flow merges (which made the compiler guard the
+    // arithmetic with LDS waits of its own).
+    auto stage_pf = [&](auto SI, int64_t tile, double (&v)[16], int64_t pf_tile, double (&nxt)[16]) {
+      constexpr int S = decltype(SI)::value;
+      constexpr unsigned pbS = S == 1 ? PB1 : S == 2 ? PB2 : PB3;
+      constexpr unsigned paS = S == 1 ? PA1 : S == 2 ? PA2 : PA3;
+      const char *src = qring + ((S - 1) * 2 + (int)(pf_tile & 1)) * kSlot + cl * 16;
+      auto pre = [&](int j) {
+        const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * kPiece);
+        nxt[2 * j] = w.x;
+        nxt[2 * j + 1] = w.y;
+      };
+      if constexpr (S == NW - 1) {
+        char *dst = yring + (int)(tile & 1) * kSlot + lane_off;
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+            [&](int j, double a, double b) {
+              if constexpr (CM) {
+                cdbl2 w;
+                w.x = a;
+                w.y = b;
+                *reinterpret_cast<cdbl2 *>(dst + swz[j]) = w;
+              } else {
+                *reinterpret_cast<double *>(dst + ALZ_COFF(2 * j)) = a;
+                *reinterpret_cast<double *>(dst + ALZ_COFF(2 * j + 1)) = b;
+              }
+            }, pre);
+      } else {
+        char *dst = qring + (S * 2 + (int)(tile & 1)) * kSlot + cl * 16;
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+            [&](int j, double a, double b) {
+              cdbl2 w;
+              w.x = a;
+              w.y = b;
+              *reinterpret_cast<cdbl2 *>(dst + j * kPiece) = w;
+            }, pre);
+      }
+    };
+    PIPE_BARRIER();
     if constexpr (DEPHASE) {
       double v[16];
 #pragma unroll
@@ -582,7 +773,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       const int lag = kDeLag[wave & 3];
       if (wave == 0 && nt > 0) {                              // tile 0 is in the x ring (the loader saw to it)
         read_tile(0, v);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIPE_DRAIN();
       }
       for (int64_t t = 0; t < n_iv; ++t) {
         const int64_t a = t - lag;                            // the tile this stage computes in interval t
@@ -593,8 +784,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
           if (a - 1 >= 0 && a - 1 < nt) write_tile(a - 1, v);  // finished in the second half of t - 1
           if (a >= 0 && a < nt) read_tile(a, v);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
         // ---- second half ----
         if (even) {
           if (a >= 0 && a < nt) write_tile(a, v);
@@ -602,8 +793,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
         } else {
           if (a >= 0 && a < nt) do_sections(v);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
       }
     } else if constexpr (OVL == 2) {
       double va[16], vb[16], vc[16];
@@ -616,13 +807,60 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
         if (a >= 0 && a < nt) read_tile(a, nxt);
         asm volatile("" ::: "memory");                        // LDS traffic is issued before the arithmetic
         if (a >= 1 && a - 1 < nt) do_sections(cur);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
       };
       for (int64_t t = 0; t < n_iv; t += 3) {
         interval(t, va, vb, vc);
         interval(t + 1, vb, vc, va);
         interval(t + 2, vc, va, vb);
+      }
+    } else if (DIRECT_IN && wave == 0) {
+      // tile k lives in register set k % 4; interval t fetches tile t + 2 and works on tile t - 1
+      // (the same schedule as the LDS path below), so three tiles of loads are in flight
+      const double *xl = CM ? p.x + (in0 + lane) * p.ldx : p.x + in0 + lane;
+      double s0[16], s1[16], s2[16], s3[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s2[u] = s3[u] = 0.0;
+      auto fetch = [&](int64_t tile, double (&v)[16]) {
+        const int64_t tt = tile < nt ? tile : nt - 1;       // past the end: a valid tile again, never used
+        if constexpr (CM) {                                   // the lane's own row: 128 contiguous bytes per tile
+          const cdbl2 *src = reinterpret_cast<const cdbl2 *>(xl + tt * T);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const cdbl2 w = src[j];
+            v[2 * j] = w.x;
+            v[2 * j + 1] = w.y;
+          }
+        } else {
+          const double *src = xl + tt * T * p.ldx;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = src[u * p.ldx];
+        }
+      };
+      fetch(0, s0);
+      if constexpr (!ALZ_PIPE_TWO) fetch(1, s1);
+      auto interval = [&](int64_t t, double (&cur)[16], double (&far)[16]) {
+        fetch(t + (ALZ_PIPE_TWO ? 1 : 2), far);
+        asm volatile("" ::: "memory");                        // the loads are issued before the arithmetic
+        if (t >= 1 && t - 1 < nt) work_tile(t - 1, cur);
+        PIPE_DRAIN();
+        PIPE_BARRIER();
+      };
+      if constexpr (ALZ_PIPE_TWO) {
+        // three sets: tile k in set k % 3; interval t fetches tile t + 1 and works on tile t - 1
+        for (int64_t t = 0; t < n_iv; t += 3) {
+          interval(t, s2, s1);
+          interval(t + 1, s0, s2);
+          interval(t + 2, s1, s0);
+        }
+      } else {
+        for (int64_t t = 0; t < n_iv; t += 4) {
+          interval(t, s3, s2);
+          interval(t + 1, s0, s3);
+          interval(t + 2, s1, s0);
+          interval(t + 3, s2, s1);
+        }
       }
     } else if constexpr (OVL == 1) {
       double va[16], vb[16];
@@ -633,10 +871,37 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
         if (ahead >= 0 && ahead < nt) read_tile(ahead, nxt);
         asm volatile("" ::: "memory");                        // the reads are issued before the arithmetic
         if (ahead >= 1 && ahead - 1 < nt) work_tile(ahead - 1, cur);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
       };
-      for (int64_t t = 0; t < n_iv; t += 2) {
+      int64_t t = 0;
+      if (ALZ_PIPE_EARLYW == 2 && SPW == 1 && G == 64 && wave > 0 && !ALZ_DBG(p, 2)) {
+        // steady intervals of stage `wave` (fetch tile t - lagw, work on the one before): t - lagw in [1, nt - 1];
+        // whole (even, odd) pairs of them run through stage_pf, the rest through the general form
+        const int64_t lagw = LAG * wave;
+        const int64_t t0 = lagw + 2, t1 = lagw + nt - 1;
+        const int64_t npairs = t1 >= t0 + 1 ? (t1 - t0 + 1) / 2 : 0;
+        for (; t < t0; t += 2) {
+          interval(t, va, vb);
+          interval(t + 1, vb, va);
+        }
+        const int64_t tend = t0 + 2 * npairs;
+        auto steady = [&](auto SI) {
+          for (int64_t tt = t0; tt < tend; tt += 2) {
+            stage_pf(SI, tt - lagw - 1, va, tt - lagw, vb);
+            PIPE_DRAIN();
+            PIPE_BARRIER();
+            stage_pf(SI, tt - lagw, vb, tt + 1 - lagw, va);
+            PIPE_DRAIN();
+            PIPE_BARRIER();
+          }
+        };
+        if (wave == 1) steady(std::integral_constant<int, 1>{});
+        else if (wave == 2) steady(std::integral_constant<int, 2>{});
+        else steady(std::integral_constant<int, 3>{});
+        t = tend;
+      }
+      for (; t < n_iv; t += 2) {
         interval(t, va, vb);
         interval(t + 1, vb, va);
       }
@@ -648,8 +913,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
           read_tile(tile, v);
           work_tile(tile, v);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        PIPE_DRAIN();
+        PIPE_BARRIER();
       }
     }
     if (real) {
@@ -666,6 +931,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 #undef ALZ_COFF
 }
 
+#undef PIPE_BARRIER
+#undef PIPE_DRAIN
 // ---------------------------------------------------------------------------
 // k_tandem: the four-section pipeline with TWO waves per section that take alternate tiles.
 //
@@ -1090,7 +1357,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   }
   const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
   const size_t lds = tandem ? (size_t)(kTXRing + 3 * kTQSlots + 2) * kCSlot + 4 * 128 * sizeof(double)
-                   : pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
+                   : pipe ? (size_t)((ALZ_PIPE_TWO && (ALZ_PIPE_DIRECT & (cm ? 4 : 1)) && g == 64 && pipe_env == 1 ? 0 : kPXRing) +
+                                     (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
   if (pipe) {
     const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
     if (rc) return rc;

@@ -374,7 +374,7 @@ def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
           "C": C, "N": N}
 
 
-def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=16, time_parallel=False):
+def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=16, time_parallel=False, layout="chan"):
   torch = ctx.torch
   B, S, N = 256, streams, 1 << log2n    # 512 streams over 8 GPUs -> 64 streams per GPU, all bands local
   s_, Hz = alz.sHz(48000)
@@ -385,17 +385,20 @@ def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=1
   if time_parallel:
     bank.set_time_parallel(True)
   bank.reset()
-  x = ctx.noise((S, N), 2)
-  y = torch.empty((B * S, N), dtype=torch.float64, device=ctx.dev)
-  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="chan", out=y), steps, warmup)
+  tm = layout == "time"
+  x = ctx.noise((N, S) if tm else (S, N), 2)
+  y = torch.empty((N, B * S) if tm else (B * S, N), dtype=torch.float64, device=ctx.dev)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout=layout, out=y), steps, warmup)
   kernel = bank.last_kernel
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
     from oracle import oracle
     nchk = min(N, 512 if S > 1 else 16384)
     bank.reset()
-    xs = x[:, :nchk].contiguous()
-    got = bank.process(xs, layout="chan").cpu().numpy()
+    xs = x[:nchk].t().contiguous() if tm else x[:, :nchk].contiguous()          # [S, nchk]
+    got = bank.process(xs.t().contiguous() if tm else xs, layout=layout).cpu().numpy()
+    if tm:
+      got = np.ascontiguousarray(got.T)
     k = alz.gammatone_erb_constants(4)[0]
     bands = [alz.gammatone.slaney(fc, k * alz.erb(fc, Hz)) for fc in fcs]
     nbs, nas = [len(f.numlist) for f in bands[0]], [len(f.denlist) for f in bands[0]]
@@ -415,7 +418,7 @@ def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=1
   del x, y, bank
   torch.cuda.empty_cache()
   return {"units": float(B) * S * N, "elapsed": elapsed, "kernel": kernel, "parity": parity,
-          "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N}
+          "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N, "layout": layout}
 
 
 def wl_lpc(ctx, args, alz, steps, warmup, fused=False):
@@ -527,6 +530,8 @@ def main():
   ap.add_argument("--layout", choices=["time", "chan"], default="time")
   ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
   ap.add_argument("--streams", type=int, default=64, help="--workload gammatone: input streams per GPU")
+  ap.add_argument("--bank-layout", choices=["time", "chan"], default="chan",
+                  help="--workload gammatone: x [S, N] -> y [B * S, N] (chan) or x [N, S] -> y [N, B * S] (time)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-secondary", action="store_true", help="skip configs[2..4] and the narrow-bank run")
   ap.add_argument("--no-parity-check", action="store_true",
@@ -646,12 +651,14 @@ def main():
     roof = res["roofline"]
   elif args.workload == "gammatone":
     res = wl_gammatone(ctx, args, alz, args.steps, args.warmup, fused=args.fused, streams=args.streams,
-                       log2n=args.log2_samples if args.streams < 64 else 16, time_parallel=bool(args.time_parallel))
+                       log2n=args.log2_samples if args.streams < 64 else 16, time_parallel=bool(args.time_parallel),
+                       layout=args.bank_layout)
     total_units = float(world) * res["units"]
     metric, unit = "Gsamples/s (band x stream x sample outputs) through the ERB gammatone bank", "Gsamples/s"
     config = {"workload": "configs[3]: ERB gammatone filterbank (gammatone.slaney, 4-section cascades), %d bands x %d "
                           "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
-                          "x [S, N] -> y [B, S, N]" % (res["B"], res["S"], res["N"]),
+                          "%s" % (res["B"], res["S"], res["N"],
+                                  "x [N, S] -> y [N, B, S]" if res["layout"] == "time" else "x [S, N] -> y [B, S, N]"),
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   else:
