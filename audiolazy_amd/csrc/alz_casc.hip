@@ -448,6 +448,12 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 #ifndef ALZ_PIPE_EARLYW
 #define ALZ_PIPE_EARLYW 2
 #endif
+// ALZ_PIPE_SKEW n (experiment): stage S idles n x S x 16 cycles after every barrier, so that the four stage
+// waves -- which run the same instruction sequence at the same rate -- do not all reach their LDS
+// operations in the same cycles.
+#ifndef ALZ_PIPE_SKEW
+#define ALZ_PIPE_SKEW 0
+#endif
 // ALZ_PIPE_TWO 1 (experiment; needs the direct input): no x ring in LDS (67 KiB per workgroup), at most 168
 // VGPRs per wave and three register sets in the first stage, so that TWO workgroups share a CU when
 // the bank has at least two per CU -- one's arithmetic runs while the other waits at its barrier.
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
   constexpr bool DEPHASE = OVL == 3 && SPW == 1;
   constexpr int kDeLag[4] = {0, 1, 3, 4};
   constexpr bool DIRECT_IN = (ALZ_PIPE_DIRECT & (CM ? 4 : 1)) && G == 64 && OVL == 1;
-  constexpr bool DIRECT_OUT = (ALZ_PIPE_DIRECT & 2) && !CM && G == 64 && OVL == 1;
+  constexpr bool DIRECT_OUT = (ALZ_PIPE_DIRECT & (CM ? 8 : 2)) && G == 64 && OVL == 1;
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -663,9 +669,20 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
     auto write_tile = [&](int64_t tile, const double (&v)[16]) {
       if (G < 64 && !real) return;                          // ghost lanes hold the same doubles: one copy is written
       if (DIRECT_OUT && wave == NW - 1) {
-        double *dst = p.y + (tile * T) * p.ldy + c0 + lane;   // 16 rows of 512 contiguous bytes
+        if constexpr (CM) {
+          cdbl2 *dst = reinterpret_cast<cdbl2 *>(p.y + (c0 + lane) * p.ldy + tile * T);   // 128 bytes of the lane's own row
 #pragma unroll
-        for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], dst + u * p.ldy);
+          for (int j = 0; j < 8; ++j) {
+            cdbl2 w;
+            w.x = v[2 * j];
+            w.y = v[2 * j + 1];
+            dst[j] = w;
+          }
+        } else {
+          double *dst = p.y + (tile * T) * p.ldy + c0 + lane;   // 16 rows of 512 contiguous bytes
+#pragma unroll
+          for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], dst + u * p.ldy);
+        }
       } else if (wave == NW - 1) {
         char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
 #pragma unroll
@@ -686,11 +703,18 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         if (ALZ_DBG(p, 2)) return;
         if (wave == NW - 1) {
           if (DIRECT_OUT) {
-            double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
+            double *dst = CM ? p.y + (c0 + lane) * p.ldy + tile * T : p.y + (tile * T) * p.ldy + c0 + lane;
             section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
                 [&](int j, double a, double b) {
-                  __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
-                  __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
+                  if constexpr (CM) {                       // the lane's own row: 16 bytes of a 128-byte line per group
+                    cdbl2 w;
+                    w.x = a;
+                    w.y = b;
+                    reinterpret_cast<cdbl2 *>(dst)[j] = w;
+                  } else {
+                    __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
+                    __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
+                  }
                 }, [](int) {});
           } else {
             char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
@@ -739,7 +763,21 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         nxt[2 * j] = w.x;
         nxt[2 * j + 1] = w.y;
       };
-      if constexpr (S == NW - 1) {
+      if constexpr (S == NW - 1 && DIRECT_OUT) {
+        double *dst = CM ? p.y + (c0 + lane) * p.ldy + tile * T : p.y + (tile * T) * p.ldy + c0 + lane;
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+            [&](int j, double a, double b) {
+              if constexpr (CM) {
+                cdbl2 w;
+                w.x = a;
+                w.y = b;
+                reinterpret_cast<cdbl2 *>(dst)[j] = w;
+              } else {
+                __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
+                __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
+              }
+            }, pre);
+      } else if constexpr (S == NW - 1) {
         char *dst = yring + (int)(tile & 1) * kSlot + lane_off;
         section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
             [&](int j, double a, double b) {
@@ -887,10 +925,16 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         }
         const int64_t tend = t0 + 2 * npairs;
         auto steady = [&](auto SI) {
+          auto skew = [&]() {
+#pragma unroll
+            for (int k = 0; k < ALZ_PIPE_SKEW * decltype(SI)::value; ++k) asm volatile("s_nop 15");
+          };
           for (int64_t tt = t0; tt < tend; tt += 2) {
+            skew();
             stage_pf(SI, tt - lagw - 1, va, tt - lagw, vb);
             PIPE_DRAIN();
             PIPE_BARRIER();
+            skew();
             stage_pf(SI, tt - lagw, vb, tt + 1 - lagw, va);
             PIPE_DRAIN();
             PIPE_BARRIER();
