@@ -342,7 +342,13 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 // i+3 and prepares p for tile i+1.  LDS: a 4-slot x ring (DMA target) + a 3-slot p/y ring.
 // G = 16 channels per workgroup (the REC wave's other 48 lanes are ghosts as in k_wave).
 // ---------------------------------------------------------------------------
-static constexpr int kXRing = 4, kPRing = 3, kYRing = 2;
+#ifndef ALZ_DUO_XRING
+#define ALZ_DUO_XRING 4
+#endif
+static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
+#ifndef ALZ_DUO_CHUNKWAIT
+#define ALZ_DUO_CHUNKWAIT 1
+#endif
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
@@ -569,6 +575,25 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
             pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if ALZ_DUO_CHUNKWAIT
+        {
+          // ONE wait per chunk for the four paired reads of chunk k, through the builtin so that the
+          // compiler's wait-count pass sees it and does not emit a wait of its own before every second
+          // step (an s_waitcnt costs a lone wave an issue slot even when it does not stall).  Newer LDS
+          // operations that may stay outstanding: the reads of chunks k+1 and k+2 (four ds_read2 each)
+          // and the y write that closed chunk k-1.
+          const int newer = (k + 1 < NCH ? 4 : 0) + (k + 2 < NCH ? 4 : 0) + ((!NOSTORE && k > 0) ? 1 : 0);
+          switch (newer) {                                   // (k is an unrolled loop index: folded at compile time)
+            case 0: __builtin_amdgcn_s_waitcnt(0xC07F); break;
+            case 1: __builtin_amdgcn_s_waitcnt(0xC17F); break;
+            case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+            case 5: __builtin_amdgcn_s_waitcnt(0xC57F); break;
+            case 8: __builtin_amdgcn_s_waitcnt(0xC87F); break;
+            default: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+          }
+          __builtin_amdgcn_sched_barrier(0);                  // (the wait stays ahead of the chunk's arithmetic)
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           double acc = pr[k % 3][u];

@@ -544,7 +544,7 @@ def main():
                        "biquad bank; default: the engine's own choice (bit-exact kernels)")
   ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                   help="process-group backend for N > 1 (nccl = RCCL; gloo lets tests run several ranks on one GPU)")
-  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc"], default="biquad",
+  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
@@ -646,6 +646,14 @@ def main():
     metric, unit = "Gsamples/s through ZFilter FIR-256 bank", "Gsamples/s"
     config = {"workload": "configs[2]: 256-tap FIR lowpass (Hamming-windowed sinc, shared taps) x %d channels, "
                           "float64, %d-sample blocks, 1 MI355X per rank" % (C, N),
+              "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]",
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  elif args.workload == "envelope":
+    res = wl_envelope(ctx, args, alz, C, N, args.steps, args.warmup)
+    total_units = float(world) * C * N
+    metric, unit = "Gsamples/s through a bank of envelope.abs followers (lowpass.pole on |x|)", "Gsamples/s"
+    config = {"workload": "envelope.abs x %d channels, float64, %d-sample blocks, |x| fused into the filter kernel" % (C, N),
               "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]",
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]

@@ -1,11 +1,10 @@
 #!/bin/bash
-# k_duo A/B: the shipped build against a variant library (default tools/variants/duo_cw0.so), two rounds on one box
+# k_duo x-ring depth (tiles of DMA in flight): 4 (shipped) / 5 / 6 on the workloads whose REC wave is not the limit
 mkdir -p gpurun_out/r02z
-V=${VARIANT:-duo_cw0}
-B="python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 3"
-for v in base $V base $V; do
+B="python bench.py --no-cpu-baseline --no-secondary --steps 10 --warmup 3"
+for v in base duo_xr5 duo_xr6; do
   if [ $v = base ]; then unset ALZ_LIBRARY; else export ALZ_LIBRARY=$PWD/tools/variants/$v.so; fi
-  for args in "" "--layout chan" "--channels 2048" "--fused" "--channels 512 --time-parallel 1"; do
+  for args in "" "--fused" "--workload envelope" "--layout chan --fused"; do
     timeout 200 $B $args 2>/dev/null > gpurun_out/r02z/b.json
     python - "$v" "$args" <<'PY'
 import json,sys
@@ -15,4 +14,4 @@ try:
 except Exception as e: print(sys.argv[1], sys.argv[2], "failed", e)
 PY
   done
-done | tee gpurun_out/r02z/ab_$V.log
+done | tee gpurun_out/r02z/xring.log
