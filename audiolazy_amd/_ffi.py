@@ -21,6 +21,7 @@ MAP_OPS = {"abs": 1, "neg": 2, "sqrt": 3, "square": 4, "mul": 5, "add": 6, "sub"
            "clip": 11, "clip_high": 12, "clip_low": 13, "add2": 20, "sub2": 21, "mul2": 22, "div2": 23}
 MAP_ZERODIV, MAP_DOMAIN = 1, 2
 LPC_FUSED = 1
+LPC_DENSE = 2
 BANK_DIAGONAL, BANK_OUTER = 0, 1
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -57,6 +58,7 @@ SIGNATURES = {
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_lpc_kautocor_dev_ex": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _int, _vp]),
   "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),
+  "alz_levinson_dev_ex": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _int, _vp]),
   "alz_acorr_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
   "alz_mix_dev": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _int, _vp]),
   "alz_mix_tracks_dev": (_int, [_int, _vp, _vp, _vp, ctypes.c_double, _i64, _vp, _int, _vp]),

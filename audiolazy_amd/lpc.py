@@ -20,8 +20,16 @@ def _frame_count(n_samples, frame_len, hop):
   return 0 if n_samples < frame_len else (n_samples - frame_len) // hop + 1
 
 
-def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False):
+def _lpc_flags(fused, exact):
+  return (_ffi.LPC_FUSED if fused else 0) | (_ffi.LPC_DENSE if exact else 0)
+
+
+def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False, exact=False):
   """lpc.kautocor on every full frame of ``sig``.
+
+  exact=True runs Levinson-Durbin with the reference's own dense inner products in the reference's
+  order (ALZ_LPC_DENSE): coefficients and error are then bit-identical to ``lpc.kautocor`` on every
+  frame (the default O(order^2) recursion agrees to ~1e-16, inside the 1e-6 contract, and is faster).
 
   fused=True opts into fused multiply-adds in the autocorrelation sums (faster: the kernel is bound
   by FP64 issue; lags differ from the reference's by ~1e-16 relative, so the result is no longer
@@ -44,7 +52,7 @@ def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False):
     status = torch.empty((F,), dtype=torch.int32, device=sig.device)
     stream = torch.cuda.current_stream(sig.device).cuda_stream
     _ffi.check(L.alz_lpc_kautocor_dev_ex(flat.data_ptr(), F, frame_len, hop, order, coefs.data_ptr(),
-                                         err.data_ptr(), status.data_ptr(), _ffi.LPC_FUSED if fused else 0,
+                                         err.data_ptr(), status.data_ptr(), _lpc_flags(fused, exact),
                                          sig.device.index or 0, ctypes.c_void_p(stream)))
     return coefs, err, status
   flat = np.ascontiguousarray(sig, dtype=np.float64).reshape(-1)
@@ -52,7 +60,7 @@ def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False):
   d_sig = _DevBuf(flat.nbytes, device).upload(flat)
   d_c, d_e, d_s = _DevBuf(F * (order + 1) * 8, device), _DevBuf(F * 8, device), _DevBuf(F * 4, device)
   _ffi.check(L.alz_lpc_kautocor_dev_ex(d_sig.ptr, F, frame_len, hop, order, d_c.ptr, d_e.ptr, d_s.ptr,
-                                       _ffi.LPC_FUSED if fused else 0, device, None))
+                                       _lpc_flags(fused, exact), device, None))
   _ffi.check(L.alz_device_sync(device))
   return (d_c.download((F, order + 1), np.float64), d_e.download((F,), np.float64),
           d_s.download((F,), np.int32))
@@ -87,10 +95,11 @@ def acorr(blk, max_lag=None):
   return acorr_frames(blk, len(blk), max_lag)[0].tolist()
 
 
-def levinson_durbin(acdata, order=None, device=0):
+def levinson_durbin(acdata, order=None, device=0, exact=True):
   """Solve the Yule-Walker equations for the lag list ``acdata``; returns the FIR
   analysis filter as a ZFilter with the prediction error in ``.error``
-  (reference lazy_lpc.py:52-136).  Raises ParCorError like the reference."""
+  (reference lazy_lpc.py:52-136).  Raises ParCorError like the reference.
+  One lag list at a time, so the reference's dense form (bit-identical result) is the default."""
   from .filters import ZFilter
   L = _ffi.load()
   acdata = np.ascontiguousarray([float(v) for v in acdata], dtype=np.float64)
@@ -98,7 +107,8 @@ def levinson_durbin(acdata, order=None, device=0):
     order = len(acdata) - 1
   d_r = _DevBuf(acdata.nbytes, device).upload(acdata)
   d_c, d_e, d_s = _DevBuf((order + 1) * 8, device), _DevBuf(8, device), _DevBuf(4, device)
-  _ffi.check(L.alz_levinson_dev(d_r.ptr, 1, len(acdata), order, d_c.ptr, d_e.ptr, d_s.ptr, device, None))
+  _ffi.check(L.alz_levinson_dev_ex(d_r.ptr, 1, len(acdata), order, d_c.ptr, d_e.ptr, d_s.ptr,
+                                   _ffi.LPC_DENSE if exact else 0, device, None))
   _ffi.check(L.alz_device_sync(device))
   _ffi.check(int(d_s.download((1,), np.int32)[0]))
   filt = ZFilter(d_c.download((order + 1,), np.float64).tolist())
@@ -111,7 +121,7 @@ def _kautocor(blk, order, device=0):
   lazy_lpc.py:229-272).  Returns a ZFilter with ``.error``."""
   from .filters import ZFilter
   blk = [float(v) for v in blk]
-  coefs, err, status = kautocor_frames(blk, len(blk), order, device=device)
+  coefs, err, status = kautocor_frames(blk, len(blk), order, device=device, exact=True)   # one block: bit-identical form
   _ffi.check(int(status[0]))
   filt = ZFilter(coefs[0].tolist())
   filt.error = float(err[0])

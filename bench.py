@@ -421,26 +421,31 @@ def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=1
           "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N, "layout": layout}
 
 
-def wl_lpc(ctx, args, alz, steps, warmup, fused=False):
+def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False):
   from audiolazy_amd.lpc import kautocor_frames
   F, L, order = 65536, 480, 16
   sig = ctx.noise((F * L,), 3)
-  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused), steps, warmup)
+  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused, exact=exact), steps, warmup)
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
     from oracle import oracle
     nf = 4096
-    nf = 65536 if fused else nf          # (the fused kernel needs >= 16384 frames)
-    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order, fused=fused)
+    nf = 65536 if (fused or exact) else nf          # (the fused kernel needs >= 16384 frames)
+    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order, fused=fused, exact=exact)
     rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
     worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
     ok = worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs)
-    parity = ("%d frames: coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)"
-              % (nf, worst)) if ok else "MISMATCH (%.3g)" % worst
+    if exact:
+      ok = bits_equal(coefs.cpu().numpy(), rc) and bits_equal(err.cpu().numpy(), re) and np.array_equal(status.cpu().numpy(), rs)
+      parity = "bit-exact vs oracle: coefficients and error of all %d frames" % nf if ok else "MISMATCH (%.3g)" % worst
+    else:
+      parity = ("%d frames: coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)"
+                % (nf, worst)) if ok else "MISMATCH (%.3g)" % worst
   del sig
   ctx.torch.cuda.empty_cache()
   return {"units": float(F), "elapsed": elapsed, "parity": parity,
-          "kernel": "k_acorr_stage<17,lev%s> (autocorrelation + Levinson-Durbin in one launch)" % (",fma" if fused else ""),
+          "kernel": ("k_acorr_stage<17> + k_levinson_dense<17> (the reference's dense Levinson-Durbin)" if exact else
+                     "k_acorr_stage<17,lev%s> (autocorrelation + Levinson-Durbin in one launch)" % (",fma" if fused else "")),
           "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
 
 
@@ -614,6 +619,9 @@ def main():
         r = wl_lpc(ctx, args, alz, 20, 3)
         secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
                                  "480-sample frames")
+        r = wl_lpc(ctx, args, alz, 20, 3, exact=True)
+        secondary["lpc_bit_identical"] = entry(r, 1, 20, "Gframes/s", "configs[4] with the reference's dense Levinson-Durbin "
+                                               "(ALZ_LPC_DENSE): coefficients and error bit-identical on every frame")
         r = wl_lpc(ctx, args, alz, 20, 3, fused=True)
         secondary["lpc_fma"] = entry(r, 1, 20, "Gframes/s", "configs[4] with fused multiply-adds in the autocorrelation "
                                      "sums (opt-in ALZ_LPC_FUSED; not pinned to the last bit)")

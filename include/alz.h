@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 200 /* 0.2.0: + alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex */
+#define ALZ_VERSION 201 /* 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
@@ -136,8 +136,9 @@ const char *alz_bank_last_kernel(const alz_bank_t *h);
  *   err   [n_frames]          (the filter's .error attribute),
  *   status[n_frames]          ALZ_OK or ALZ_E_PARCOR (zero-energy frame; the
  *                             reference raises ParCorError, lazy_lpc.py:132-133).
- * Floating point: not bit-exact (standard O(order^2) recursion instead of the
- * reference's dense inner products); tests hold it to 1e-9 normalised error. */
+ * Floating point: the lags are bit-exact; Levinson-Durbin is the standard O(order^2) recursion
+ * instead of the reference's dense inner products (tests hold it to 1e-9 normalised error, measured
+ * ~1e-16).  alz_lpc_kautocor_dev_ex with ALZ_LPC_DENSE is the bit-identical form. */
 int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                          int64_t hop, int order, double *coefs_dev,
                          double *err_dev, int *status_dev, int device, void *stream);
@@ -148,6 +149,11 @@ int alz_lpc_kautocor_dev(const double *sig_dev, int64_t n_frames, int frame_len,
  * samples, an even hop, >= 16384 frames and a curated order (8, 10, 12, 16, 20, 24, 32); other shapes
  * run the exact kernels whatever the flag says.  No reference counterpart (CPython never fuses). */
 #define ALZ_LPC_FUSED 1
+/* ALZ_LPC_DENSE: Levinson-Durbin with the reference's own dense inner products in the reference's
+ * order (lazy_lpc.py:121-131: inner(a, b) = sum(acdata[|i-j|] * a_i * b_j ...), O(order^3) per frame)
+ * on lags from the exact autocorrelation kernels: coefficients AND error bit-identical to
+ * lpc.kautocor / levinson_durbin on every frame, at about 1.5 x the time of the default path. */
+#define ALZ_LPC_DENSE 2
 int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_len,
                             int64_t hop, int order, double *coefs_dev,
                             double *err_dev, int *status_dev, int flags, int device, void *stream);
@@ -156,6 +162,10 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
 int alz_levinson_dev(const double *r_dev, int64_t n_frames, int n_lags, int order,
                      double *coefs_dev, double *err_dev, int *status_dev, int device,
                      void *stream);
+/* The same with options: flags = ALZ_LPC_DENSE for the reference's dense, bit-identical form. */
+int alz_levinson_dev_ex(const double *r_dev, int64_t n_frames, int n_lags, int order,
+                        double *coefs_dev, double *err_dev, int *status_dev, int flags, int device,
+                        void *stream);
 /* acorr alone (lazy_analysis.py:277-312): r [n_frames, max_lag+1] */
 int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                   int64_t hop, int max_lag, double *r_dev, int device, void *stream);

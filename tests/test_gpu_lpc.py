@@ -1,9 +1,10 @@
 """GPU parity for batched lpc.kautocor (reference lazy_lpc.py:229-272).
 
-acorr is bit-exact (same left-to-right sum).  Levinson-Durbin on the GPU is the
+acorr is bit-exact (same left-to-right sum).  Levinson-Durbin on the GPU is by default the
 standard O(order^2) recursion, not the reference's dense inner products, so it
 is floating-point parity: normalised max error of the coefficient vector and
-relative error of .error must be <= 1e-9 (north star allows 1e-6).
+relative error of .error must be <= 1e-9 (north star allows 1e-6).  With exact=True
+(ALZ_LPC_DENSE) the reference's dense form runs and everything is bit-identical (tests at the end).
 """
 import numpy as np
 import pytest
@@ -160,3 +161,80 @@ def test_fused_mode_within_contract(lpc):
   assert (np.abs(c[ok] - rc[ok]) / scale).max() <= TOL
   assert (np.abs(e[ok] - re[ok]) / np.abs(re[ok])).max() <= TOL
   assert not np.array_equal(c[ok], c0.cpu().numpy()[ok])       # it really is the other arithmetic
+
+
+# ---- ALZ_LPC_DENSE: the reference's dense Levinson-Durbin, bit-identical ---------------------------
+def same_bits(a, b):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  return a.shape == b.shape and bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)))
+
+
+def test_golden_kautocor_exact_mode_is_bit_identical_to_the_reference(lpc):
+  """exact=True: coefficients and .error equal the reference's own outputs (tests/golden/lpc.json,
+  generated by running the reference) in every bit."""
+  for case in load_golden("lpc.json")["kautocor"]:
+    x = np.array(unhex(case["x"]))
+    ref = np.array(unhex(case["coefs"]))
+    c, e, st = lpc.kautocor_frames(x, len(x), case["order"], exact=True)
+    ref = np.concatenate([ref, np.zeros(c.shape[1] - len(ref))])
+    assert st[0] == 0
+    assert same_bits(c[0], ref), (case["order"], c[0], ref)
+    assert same_bits([e[0]], [unhex(case["error"])])
+
+
+def test_golden_levinson_exact(lpc):
+  for case in load_golden("lpc.json").get("levinson", []):
+    ac = unhex(case["ac"])
+    filt = lpc.levinson_durbin(ac, case.get("order"))
+    ref = unhex(case["coefs"])
+    got = filt.numlist
+    assert same_bits(got + [0.0] * (len(ref) - len(got)), ref + [0.0] * (len(got) - len(ref)))
+    assert same_bits([filt.error], [unhex(case["error"])])
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 6, 8, 10, 12, 16, 5, 20, 40])
+def test_exact_mode_vs_oracle_all_frames(lpc, order):
+  """Unrolled kernels (curated orders) and the run-time-loop kernel (5, 20, 40) against the C oracle on
+  every frame, ParCorError frames included (status only)."""
+  from oracle import oracle
+  from audiolazy_amd import _ffi
+  rng = np.random.default_rng(order)
+  F, L = 2048 + 3, 96
+  sig = rng.uniform(-1, 1, F * L)
+  sig[5 * L:6 * L] = 0.0                                   # a silent frame
+  sig[9 * L:10 * L] = np.tile([1.0, -1.0], L // 2)         # lag pattern with exact cancellations
+  c, e, st = lpc.kautocor_frames(sig, L, order, exact=True)
+  rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
+  assert np.array_equal(st, rs) and st[5] == _ffi.E_PARCOR
+  ok = st == 0
+  assert same_bits(c[ok], rc[ok])
+  assert same_bits(e[ok], re[ok])
+
+
+def test_exact_mode_full_width_cfg5(lpc):
+  """configs[4] at full width: 65 536 frames x 480 samples, order 16, bit-identical on every frame."""
+  import torch
+  from oracle import oracle
+  F, L, order = 65536, 480, 16
+  sig = np.random.default_rng(9).uniform(-1, 1, F * L)
+  sig[7 * L:8 * L] = 0.0
+  d = torch.from_numpy(sig).cuda()
+  c, e, st = lpc.kautocor_frames(d, L, order, exact=True)
+  rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
+  st = st.cpu().numpy()
+  assert np.array_equal(st, rs) and np.count_nonzero(st) == 1
+  ok = st == 0
+  assert same_bits(c.cpu().numpy()[ok], rc[ok])
+  assert same_bits(e.cpu().numpy()[ok], re[ok])
+
+
+def test_levinson_zero_extended_lags_exact(lpc):
+  """order >= len(acdata): the lag list is zero-extended (lazy_lpc.py:117-118); exact zeros at the top of
+  the coefficient list shrink the dense list like Poly does."""
+  from oracle import oracle
+  ac = [3.0, 1.0, 0.5]
+  filt = lpc.levinson_durbin(ac, 5)
+  rc, re = oracle.levinson_durbin(ac, 5)
+  got = filt.numlist + [0.0] * (6 - len(filt.numlist))
+  assert same_bits(got, rc)
+  assert same_bits([filt.error], [re])
