@@ -124,6 +124,8 @@ int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy
 // alz_map.hip: one elementwise op over n contiguous doubles (see alz_map_dev)
 int launch_map(int op, const double *x, const double *y, double p0, double p1, int64_t n, double *out,
                int *flags, hipStream_t stream);
+int launch_levinson_dense(const double *r, int64_t n_frames, int n_lags, int order, double *coefs, double *err,
+                          int *status, hipStream_t st);
 int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int64_t n_inputs, int64_t sxn, int64_t sxc,
                   int64_t sen, int64_t sec, hipStream_t stream);
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
