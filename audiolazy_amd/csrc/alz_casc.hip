@@ -434,7 +434,10 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // Measured on cfg4 (profiles/r02_pipe_direct.log, Gsamples/s, bit-exact / FMA mode): LDS path 393 - 407 /
 // 437 - 453; direct input 424 - 442 / 499 - 522 in both layouts (channel-major: bit 4, a lane reads the 128
 // contiguous bytes of its own row with eight 16-byte loads); direct output 387 (slower: the last stage's 16
-// stores sit in its critical path), both 429.  Shipped: 5 = direct input in both layouts.
+// stores sit in its critical path), both 429.  Direct output in channel-major blocks (16-byte pieces of a lane's
+// own row) ran at 82 - 85: partial-line writes; two workgroups per CU without the x ring and a per-stage skew
+// after the barrier gained nothing either (profiles/NOTES_r02.md 12; none of the three is kept in the source).
+// Shipped: 5 = direct input in both layouts.
 #ifndef ALZ_PIPE_DIRECT
 #define ALZ_PIPE_DIRECT 5
 #endif
@@ -447,18 +450,6 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // 1: 436 - 451, 2: 474 Gsamples/s; time-major 425 - 442 throughout.
 #ifndef ALZ_PIPE_EARLYW
 #define ALZ_PIPE_EARLYW 2
-#endif
-// ALZ_PIPE_SKEW n (experiment): stage S idles n x S x 16 cycles after every barrier, so that the four stage
-// waves -- which run the same instruction sequence at the same rate -- do not all reach their LDS
-// operations in the same cycles.
-#ifndef ALZ_PIPE_SKEW
-#define ALZ_PIPE_SKEW 0
-#endif
-// ALZ_PIPE_TWO 1 (experiment; needs the direct input): no x ring in LDS (67 KiB per workgroup), at most 168
-// VGPRs per wave and three register sets in the first stage, so that TWO workgroups share a CU when
-// the bank has at least two per CU -- one's arithmetic runs while the other waits at its barrier.
-#ifndef ALZ_PIPE_TWO
-#define ALZ_PIPE_TWO 0
 #endif
 
 // SPW = sections per stage wave (1: four stage waves, 2: two stage waves); NW = 4 / SPW.
@@ -482,7 +473,7 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 #endif
 template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2,
           unsigned PA2, unsigned PB3, unsigned PA3, bool FMA = false>
-__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3 : 1)) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
+__global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = 16, NW = 4 / SPW;
   constexpr int NCHK = G / 8;                    // 1 KiB DMA / store chunks per tile
@@ -503,7 +494,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
   constexpr bool DEPHASE = OVL == 3 && SPW == 1;
   constexpr int kDeLag[4] = {0, 1, 3, 4};
   constexpr bool DIRECT_IN = (ALZ_PIPE_DIRECT & (CM ? 4 : 1)) && G == 64 && OVL == 1;
-  constexpr bool DIRECT_OUT = (ALZ_PIPE_DIRECT & (CM ? 8 : 2)) && G == 64 && OVL == 1;
+  constexpr bool DIRECT_OUT = (ALZ_PIPE_DIRECT & 2) && !CM && G == 64 && OVL == 1;
   constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
   constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -521,9 +512,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
   constexpr int store_lag = DEPHASE ? 5 : LAG * NW;
   const int64_t n_iv = (nt + store_lag + 1 + 11) / 12 * 12;  // a multiple of the 2-, 3- and 4-interval unrolls
-  constexpr bool NO_XRING = ALZ_PIPE_TWO && DIRECT_IN;
   char *xring = smem;
-  char *qring = smem + (NO_XRING ? 0 : kPXRing) * kSlot;  // NW-1 hand-off rings, 2 slots each
+  char *qring = smem + kPXRing * kSlot;                  // NW-1 hand-off rings, 2 slots each
   char *yring = qring + (NW - 1) * 2 * kSlot;
   const int lane_off = CM ? (cl / 8) * 1040 + (cl % 8) * 128 : cl * 8;
   int swz[8];
@@ -669,20 +659,9 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
     auto write_tile = [&](int64_t tile, const double (&v)[16]) {
       if (G < 64 && !real) return;                          // ghost lanes hold the same doubles: one copy is written
       if (DIRECT_OUT && wave == NW - 1) {
-        if constexpr (CM) {
-          cdbl2 *dst = reinterpret_cast<cdbl2 *>(p.y + (c0 + lane) * p.ldy + tile * T);   // 128 bytes of the lane's own row
+        double *dst = p.y + (tile * T) * p.ldy + c0 + lane;   // 16 rows of 512 contiguous bytes
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            cdbl2 w;
-            w.x = v[2 * j];
-            w.y = v[2 * j + 1];
-            dst[j] = w;
-          }
-        } else {
-          double *dst = p.y + (tile * T) * p.ldy + c0 + lane;   // 16 rows of 512 contiguous bytes
-#pragma unroll
-          for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], dst + u * p.ldy);
-        }
+        for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], dst + u * p.ldy);
       } else if (wave == NW - 1) {
         char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
 #pragma unroll
@@ -703,18 +682,11 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         if (ALZ_DBG(p, 2)) return;
         if (wave == NW - 1) {
           if (DIRECT_OUT) {
-            double *dst = CM ? p.y + (c0 + lane) * p.ldy + tile * T : p.y + (tile * T) * p.ldy + c0 + lane;
+            double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
             section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
                 [&](int j, double a, double b) {
-                  if constexpr (CM) {                       // the lane's own row: 16 bytes of a 128-byte line per group
-                    cdbl2 w;
-                    w.x = a;
-                    w.y = b;
-                    reinterpret_cast<cdbl2 *>(dst)[j] = w;
-                  } else {
-                    __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
-                    __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
-                  }
+                  __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
+                  __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
                 }, [](int) {});
           } else {
             char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
@@ -764,18 +736,11 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         nxt[2 * j + 1] = w.y;
       };
       if constexpr (S == NW - 1 && DIRECT_OUT) {
-        double *dst = CM ? p.y + (c0 + lane) * p.ldy + tile * T : p.y + (tile * T) * p.ldy + c0 + lane;
+        double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
         section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
             [&](int j, double a, double b) {
-              if constexpr (CM) {
-                cdbl2 w;
-                w.x = a;
-                w.y = b;
-                reinterpret_cast<cdbl2 *>(dst)[j] = w;
-              } else {
-                __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
-                __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
-              }
+              __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
+              __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
             }, pre);
       } else if constexpr (S == NW - 1) {
         char *dst = yring + (int)(tile & 1) * kSlot + lane_off;
@@ -877,28 +842,19 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         }
       };
       fetch(0, s0);
-      if constexpr (!ALZ_PIPE_TWO) fetch(1, s1);
+      fetch(1, s1);
       auto interval = [&](int64_t t, double (&cur)[16], double (&far)[16]) {
-        fetch(t + (ALZ_PIPE_TWO ? 1 : 2), far);
+        fetch(t + 2, far);
         asm volatile("" ::: "memory");                        // the loads are issued before the arithmetic
         if (t >= 1 && t - 1 < nt) work_tile(t - 1, cur);
         PIPE_DRAIN();
         PIPE_BARRIER();
       };
-      if constexpr (ALZ_PIPE_TWO) {
-        // three sets: tile k in set k % 3; interval t fetches tile t + 1 and works on tile t - 1
-        for (int64_t t = 0; t < n_iv; t += 3) {
-          interval(t, s2, s1);
-          interval(t + 1, s0, s2);
-          interval(t + 2, s1, s0);
-        }
-      } else {
-        for (int64_t t = 0; t < n_iv; t += 4) {
-          interval(t, s3, s2);
-          interval(t + 1, s0, s3);
-          interval(t + 2, s1, s0);
-          interval(t + 3, s2, s1);
-        }
+      for (int64_t t = 0; t < n_iv; t += 4) {
+        interval(t, s3, s2);
+        interval(t + 1, s0, s3);
+        interval(t + 2, s1, s0);
+        interval(t + 3, s2, s1);
       }
     } else if constexpr (OVL == 1) {
       double va[16], vb[16];
@@ -925,16 +881,10 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : (ALZ_PIPE_TWO ? 3
         }
         const int64_t tend = t0 + 2 * npairs;
         auto steady = [&](auto SI) {
-          auto skew = [&]() {
-#pragma unroll
-            for (int k = 0; k < ALZ_PIPE_SKEW * decltype(SI)::value; ++k) asm volatile("s_nop 15");
-          };
           for (int64_t tt = t0; tt < tend; tt += 2) {
-            skew();
             stage_pf(SI, tt - lagw - 1, va, tt - lagw, vb);
             PIPE_DRAIN();
             PIPE_BARRIER();
-            skew();
             stage_pf(SI, tt - lagw, vb, tt + 1 - lagw, va);
             PIPE_DRAIN();
             PIPE_BARRIER();
@@ -1401,8 +1351,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   }
   const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
   const size_t lds = tandem ? (size_t)(kTXRing + 3 * kTQSlots + 2) * kCSlot + 4 * 128 * sizeof(double)
-                   : pipe ? (size_t)((ALZ_PIPE_TWO && (ALZ_PIPE_DIRECT & (cm ? 4 : 1)) && g == 64 && pipe_env == 1 ? 0 : kPXRing) +
-                                     (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
+                   : pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
   if (pipe) {
     const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
     if (rc) return rc;
