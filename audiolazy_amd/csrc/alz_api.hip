@@ -435,15 +435,19 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   if (outer_by_input && (h->n_inputs % 64) != 0 && h->channels >= 64 && x_dev != y_dev) {
     const int64_t lde = layout == ALZ_TIME_MAJOR ? ((h->channels + 1) & ~(int64_t)1) : ((n + 1) & ~(int64_t)1);
     const uint64_t extent = layout == ALZ_TIME_MAJOR ? (uint64_t)n * lde : (uint64_t)h->channels * lde;
-    int rc = grow(&h->expand_in, &h->expand_in_bytes, extent * 8);
-    if (rc) return rc;
-    const int64_t sen = layout == ALZ_TIME_MAJOR ? lde : 1, sec = layout == ALZ_TIME_MAJOR ? 1 : lde;
-    rc = alz::launch_expand(x_dev, h->expand_in, n, h->channels, h->n_inputs, sxn, sxc, sen, sec, st);
-    if (rc) return rc;
-    x_dev = h->expand_in;
-    sxn = sen;
-    sxc = sec;
-    outer_by_input = 0;
+    // (a block as large as the output; when the device cannot spare it the bank simply keeps reading by
+    // input index through the lane-per-channel kernels: slower, same doubles)
+    if (grow(&h->expand_in, &h->expand_in_bytes, extent * 8) == ALZ_OK) {
+      const int64_t sen = layout == ALZ_TIME_MAJOR ? lde : 1, sec = layout == ALZ_TIME_MAJOR ? 1 : lde;
+      const int rc = alz::launch_expand(x_dev, h->expand_in, n, h->channels, h->n_inputs, sxn, sxc, sen, sec, st);
+      if (rc) return rc;
+      x_dev = h->expand_in;
+      sxn = sen;
+      sxc = sec;
+      outer_by_input = 0;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   // extent of y in elements, for the out-of-place copy some sections need
   const uint64_t y_extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
