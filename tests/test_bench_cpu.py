@@ -27,3 +27,29 @@ def test_fir_taps_are_the_windowed_sinc_of_the_survey():
   taps = bench.fir_taps()
   assert taps.shape == (256,) and np.allclose(taps, taps[::-1]) and abs(taps.sum() - 1.0) < 0.02
   assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+
+
+def test_bench_cli_names_every_workload_and_layout_knob():
+  """The command line the driver and the notes use: parsed without a GPU (``--help`` exits before any device call)."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+  assert out.returncode == 0
+  for flag in ("--gpus", "--steps", "--warmup", "--scaling", "--workload", "--streams", "--bank-layout", "--time-parallel",
+               "--fused", "--no-cpu-baseline", "--no-secondary", "--no-parity-check"):
+    assert flag in out.stdout, flag
+  for workload in ("biquad", "fir", "gammatone", "lpc", "envelope"):
+    assert workload in out.stdout
+
+
+def test_lpc_flag_word_matches_the_header():
+  """kautocor_frames(fused=, exact=) -> the flags of alz_lpc_kautocor_dev_ex as include/alz.h defines them."""
+  import importlib, re
+  lpc = importlib.import_module("audiolazy_amd.lpc")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  header = open(os.path.join(root, "include", "alz.h")).read()
+  fused = int(re.search(r"#define ALZ_LPC_FUSED (\d+)", header).group(1))
+  dense = int(re.search(r"#define ALZ_LPC_DENSE (\d+)", header).group(1))
+  assert lpc._lpc_flags(False, False) == 0
+  assert lpc._lpc_flags(True, False) == fused and lpc._lpc_flags(False, True) == dense
+  assert lpc._lpc_flags(True, True) == fused | dense and fused & dense == 0
