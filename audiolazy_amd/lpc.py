@@ -24,7 +24,7 @@ def _lpc_flags(fused, exact):
   return (_ffi.LPC_FUSED if fused else 0) | (_ffi.LPC_DENSE if exact else 0)
 
 
-def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False, exact=False):
+def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False, exact=False, out=None):
   """lpc.kautocor on every full frame of ``sig``.
 
   exact=True runs Levinson-Durbin with the reference's own dense inner products in the reference's
@@ -34,6 +34,9 @@ def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False, exac
   fused=True opts into fused multiply-adds in the autocorrelation sums (faster: the kernel is bound
   by FP64 issue; lags differ from the reference's by ~1e-16 relative, so the result is no longer
   pinned to the last bit -- the contract is 1e-6).
+
+  out=(coefs, err, status): preallocated CUDA result tensors for the torch path (a caller that analyses block
+  after block reuses them instead of allocating three tensors per call).
 
   sig : 1-D float64 signal (NumPy) or a [F, frame_len] array of frames, or a
         1-D float64 torch CUDA tensor (results are then CUDA tensors).
@@ -47,9 +50,17 @@ def kautocor_frames(sig, frame_len, order, hop=None, device=0, fused=False, exac
     import torch
     flat = sig.reshape(-1)
     F = _frame_count(flat.numel(), frame_len, hop)
-    coefs = torch.empty((F, order + 1), dtype=torch.float64, device=sig.device)
-    err = torch.empty((F,), dtype=torch.float64, device=sig.device)
-    status = torch.empty((F,), dtype=torch.int32, device=sig.device)
+    if out is not None:
+      coefs, err, status = out
+      if (tuple(coefs.shape) != (F, order + 1) or tuple(err.shape) != (F,) or tuple(status.shape) != (F,)
+          or coefs.dtype != torch.float64 or err.dtype != torch.float64 or status.dtype != torch.int32
+          or not (coefs.is_contiguous() and err.is_contiguous() and status.is_contiguous())
+          or coefs.device != sig.device or err.device != sig.device or status.device != sig.device):
+        raise ValueError("out must be contiguous (coefs [F, order+1] float64, err [F] float64, status [F] int32) on the signal's device")
+    else:
+      coefs = torch.empty((F, order + 1), dtype=torch.float64, device=sig.device)
+      err = torch.empty((F,), dtype=torch.float64, device=sig.device)
+      status = torch.empty((F,), dtype=torch.int32, device=sig.device)
     stream = torch.cuda.current_stream(sig.device).cuda_stream
     _ffi.check(L.alz_lpc_kautocor_dev_ex(flat.data_ptr(), F, frame_len, hop, order, coefs.data_ptr(),
                                          err.data_ptr(), status.data_ptr(), _lpc_flags(fused, exact),

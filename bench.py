@@ -425,7 +425,10 @@ def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False):
   from audiolazy_amd.lpc import kautocor_frames
   F, L, order = 65536, 480, 16
   sig = ctx.noise((F * L,), 3)
-  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused, exact=exact), steps, warmup)
+  torch = ctx.torch
+  out = (torch.empty((F, order + 1), dtype=torch.float64, device=ctx.dev), torch.empty((F,), dtype=torch.float64, device=ctx.dev),
+         torch.empty((F,), dtype=torch.int32, device=ctx.dev))          # results land in the same tensors every step
+  elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused, exact=exact, out=out), steps, warmup)
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
     from oracle import oracle

@@ -238,3 +238,17 @@ def test_levinson_zero_extended_lags_exact(lpc):
   got = filt.numlist + [0.0] * (6 - len(filt.numlist))
   assert same_bits(got, rc)
   assert same_bits([filt.error], [re])
+
+
+def test_preallocated_results(lpc):
+  import torch
+  F, L, order = 300, 64, 8
+  sig = torch.rand(F * L, dtype=torch.float64, device="cuda") * 2 - 1
+  c0, e0, s0 = lpc.kautocor_frames(sig, L, order)
+  out = (torch.empty((F, order + 1), dtype=torch.float64, device="cuda"), torch.empty((F,), dtype=torch.float64, device="cuda"),
+         torch.empty((F,), dtype=torch.int32, device="cuda"))
+  c1, e1, s1 = lpc.kautocor_frames(sig, L, order, out=out)
+  assert c1 is out[0] and e1 is out[1] and s1 is out[2]
+  assert torch.equal(c0, c1) and torch.equal(e0, e1) and torch.equal(s0, s1)
+  with pytest.raises(ValueError):
+    lpc.kautocor_frames(sig, L, order, out=(out[0][:10], out[1], out[2]))
