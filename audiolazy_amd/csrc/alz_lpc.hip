@@ -229,6 +229,13 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 // multiply and add -- half the instructions of a kernel that is bound by FP64 issue (moving the same
 // 252 MB without computing takes 34 us, tools/ubench_stride.hip), same ascending order per lag, NOT the
 // reference's doubles (differences ~1e-16 relative per lag; the contract is 1e-6).
+// ALZ_LPC_FULL 1: chunks that lie wholly inside the frame skip the per-step length check, so their 16 steps
+// are one basic block (61.2 against 65.5 us per call, profiles/r02_lpc_split.log).  Measured and not kept:
+// all 17 products of a step before the 17 additions (the compiler pairs each multiply with its add through
+// one temporary) -- 67.1 us: back-to-back dependent FP64 pairs cost nothing here.
+#ifndef ALZ_LPC_FULL
+#define ALZ_LPC_FULL 1
+#endif
 template <int P, bool LEV, bool FMA = false>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
@@ -286,10 +293,10 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
     const int valid = L - 16 * c;             // samples of this chunk inside the frame (>= 1)
     // x[m - i] is inside this chunk (u >= i) or in the history (hist[k] = x[16c - 1 - k]); only the
     // first H chunks have lags that reach before the start of the frame (checked form)
-    auto chunk = [&](auto checked) {
+    auto chunk = [&](auto checked, auto full) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        if (u < valid) {
+        if (decltype(full)::value || u < valid) {
           const double xm = cur[u];
 #pragma unroll
           for (int i = 0; i < P; ++i) {
@@ -303,8 +310,16 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
         }
       }
     };
-    if (c < H) chunk(std::true_type{});
-    else chunk(std::false_type{});
+#if ALZ_LPC_FULL
+    // a whole chunk inside the frame (every chunk but the last one of a ragged frame length): no per-step
+    // length check, so the 16 steps are one basic block
+    if (c < H) chunk(std::true_type{}, std::false_type{});
+    else if (valid >= 16) chunk(std::false_type{}, std::true_type{});
+    else chunk(std::false_type{}, std::false_type{});
+#else
+    if (c < H) chunk(std::true_type{}, std::false_type{});
+    else chunk(std::false_type{}, std::false_type{});
+#endif
     // history for the next chunk
 #pragma unroll
     for (int k = H * 16 - 1; k >= 16; --k) hist[k] = hist[k - 16];
