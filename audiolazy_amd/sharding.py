@@ -53,17 +53,19 @@ def local_bank(sections, n_channels, rank=None, world=None, device=None, **kwarg
   return FilterBank(secs, n_inputs=stop - start, device=device, **kwargs), (start, stop)
 
 
-def gather_channels(y_local, n_channels, channel_dim=-1, group=None, dst=None):
+def gather_channels(y_local, n_channels, channel_dim=-1, group=None, dst=None, force=False):
   """Assemble the full-width block from the per-rank shards along ``channel_dim``.
 
   y_local : torch tensor holding this rank's channels [.., stop - start, ..].
   dst None -> every rank gets the full block (all_gather); dst = r -> only rank r does
   (gather; others get None).  Shards may be ragged: they are padded to the largest shard
-  for the collective and trimmed afterwards.
+  for the collective and trimmed afterwards.  A one-rank group returns ``y_local`` itself
+  unless ``force`` asks for the collective call anyway (bench.py --init-dist: the RCCL path on
+  a one-GPU box).
   """
   import torch
   import torch.distributed as dist
-  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+  if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
     return y_local
   world, rank = dist.get_world_size(group), dist.get_rank(group)
   sizes = shard_sizes(n_channels, world)
@@ -86,12 +88,12 @@ def gather_channels(y_local, n_channels, channel_dim=-1, group=None, dst=None):
   return full.movedim(0, channel_dim)
 
 
-def mixdown(y_local, group=None, dst=None):
+def mixdown(y_local, group=None, dst=None, force=False):
   """Sum of every rank's block (ParallelFilter / Streamix-style mix over shards): all_reduce,
   or reduce to ``dst``.  Note the summation order across ranks is the collective's, so this is
   floating-point (not bit-exact) with respect to a single-process left-to-right sum."""
   import torch.distributed as dist
-  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+  if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
     return y_local
   out = y_local.clone()
   if dst is None:

@@ -191,6 +191,62 @@ def cpu_baseline(b, a, budget_s=3.5):
 
 
 # ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks
+# ---------------------------------------------------------------------------------------------
+def free_port():
+  import socket
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def relaunch(n_ranks):
+  """Re-run this very command line as ``n_ranks`` processes, one per GPU, under torch.distributed.run
+  (what the driver's own N > 1 command does); the ranks' stdout / stderr / exit status pass through."""
+  import subprocess
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on these hosts
+  env.setdefault("OMP_NUM_THREADS", "1")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+  """--launch-check: the rank start-up and the three collectives the timing protocol uses (barrier, MAX
+  all-reduce, all_gather of the per-rank figures) and nothing else -- no device, no kernels.  Lets the
+  N > 1 launcher be tested on a machine without GPUs (gloo)."""
+  import torch
+  import torch.distributed as dist
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  if "MASTER_PORT" not in os.environ:
+    os.environ["MASTER_PORT"] = str(free_port())
+  if args.backend == "nccl":
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+  else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+  dist.barrier()
+  t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  parts = [torch.empty_like(t) for _ in range(world)]
+  dist.all_gather(parts, torch.tensor([float(rank)], dtype=torch.float64, device=dev))
+  ok = float(t.item()) == float(world) and [float(p.item()) for p in parts] == [float(r) for r in range(world)]
+  dist.barrier()
+  dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps({"launch_check": "ok" if ok else "MISMATCH", "n_gpus": world, "requested_gpus": args.gpus,
+                      "backend": args.backend, "launcher": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID")
+                      else "none"}))
+  return 0 if ok else 3
+
+
+# ---------------------------------------------------------------------------------------------
 # GPU side
 # ---------------------------------------------------------------------------------------------
 class Ctx(object):
@@ -203,15 +259,19 @@ class Ctx(object):
     self.world = int(os.environ.get("WORLD_SIZE", "1"))
     self.local = int(os.environ.get("LOCAL_RANK", "0"))
     self.dist = None
+    self.local_elapsed = []                    # per ctx.timed() call; [0] is the headline workload
     if args.backend == "gloo":
       self.local %= max(torch.cuda.device_count(), 1)   # test mode: ranks may share a GPU
-    if self.world > 1:
+    if self.world > 1 or args.init_dist:
       import torch.distributed as dist
       os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-      if args.backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+      if "MASTER_PORT" not in os.environ:      # --init-dist without a launcher: a one-rank group of our own
+        os.environ["MASTER_PORT"] = str(free_port())
+      if args.backend == "nccl":               # "nccl" IS RCCL on ROCm
+        dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                device_id=torch.device("cuda", self.local))
       else:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
       self.dist = dist
     torch.cuda.set_device(self.local)
     self.dev = torch.device("cuda", self.local)
@@ -219,9 +279,18 @@ class Ctx(object):
 
   def sync_all(self):
     self.torch.cuda.synchronize(self.dev)
-    if self.world > 1:
+    if self.dist is not None:
       self.dist.barrier()
     self.torch.cuda.synchronize(self.dev)
+
+  def all_ranks(self, values):
+    """[values of rank 0, values of rank 1, ...] on every rank (one all_gather of a small float64 tensor)."""
+    if self.dist is None:
+      return [list(values)]
+    t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.red_dev)
+    parts = [self.torch.empty_like(t) for _ in range(self.world)]
+    self.dist.all_gather(parts, t)
+    return [[float(v) for v in p.tolist()] for p in parts]
 
   def timed(self, step, steps, warmup):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.
@@ -238,7 +307,8 @@ class Ctx(object):
       ev[s][1].record()
     self.sync_all()
     elapsed = time.perf_counter() - t0
-    if self.world > 1:
+    self.local_elapsed.append(elapsed)         # this rank's own clock (reported per rank next to the MAX)
+    if self.dist is not None:
       t = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
       self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
       elapsed = float(t.item())
@@ -518,6 +588,47 @@ def wl_timevar(ctx, args, alz, C, N, steps, warmup):
           "parity": parity, "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
+def wl_collective(ctx, args, C, n):
+  """The optional downstream step of SURVEY.md 8(e) / north_star: the filtering itself has no exchange, but
+  a consumer that mixes every channel needs them on one device.  Two forms, each ONE collective of
+  audiolazy_amd.sharding on the process group's backend (nccl = RCCL over xGMI): (a) reduce first -- every
+  rank sums its own channels, then one all_reduce of the [n] mix; (b) the raw gather of the [n, C] shards
+  to rank 0.  Timed outside the headline figure; the data stands for one block of this rank's output."""
+  torch = ctx.torch
+  from audiolazy_amd import sharding
+  y = ctx.noise((n, C), 9)
+  part = y.sum(dim=1)
+  reps, out = 3, {}
+  for key, fn, nbytes in (("mixdown_all_reduce", lambda: sharding.mixdown(part, force=True), n * 8),
+                          ("gather_to_rank0", lambda: sharding.gather_channels(y, ctx.world * C, channel_dim=1, dst=0, force=True),
+                           n * C * 8)):
+    got = fn()                                   # warm-up (communicator set-up) and the checked result
+    ctx.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    ctx.sync_all()
+    el = (time.perf_counter() - t0) / reps
+    el = max(r[0] for r in ctx.all_ranks([el]))
+    out[key] = {"ms": el * 1e3, "bytes_per_rank": nbytes, "GBps_per_rank": nbytes / el / 1e9}
+    if key == "mixdown_all_reduce":
+      tot = sum(r[0] for r in ctx.all_ranks([float(part.sum())]))
+      ok = abs(float(got.sum()) - tot) <= 1e-9 * max(1.0, abs(tot)) and (ctx.world > 1 or bool(torch.equal(got, part)))
+    elif ctx.rank == 0:
+      ok = tuple(got.shape) == (n, ctx.world * C) and bool(torch.equal(got[:, :C], y))
+    else:
+      ok = got is None
+    out[key]["check"] = "ok" if all(r[0] == 1.0 for r in ctx.all_ranks([1.0 if ok else 0.0])) else "MISMATCH"
+  del y
+  torch.cuda.empty_cache()
+  bad = [k for k, v in out.items() if v["check"] != "ok"]
+  return {"workload": "downstream step, outside the filter path: channel mix over ranks as one all_reduce of the per-rank "
+                      "sums, and the raw gather of every rank's [%d, %d] float64 shard to rank 0" % (n, C),
+          "backend": "%s (%s)" % (args.backend, "RCCL" if args.backend == "nccl" else "CPU tensors, test mode"),
+          "ranks": ctx.world, "parity": ("MISMATCH: " + ", ".join(bad)) if bad else "collective results checked on every rank",
+          "collectives": out}
+
+
 def entry(res, world, steps, unit, workload):
   """A secondary-workload record: same fields as the main line's core."""
   roof = dict(res["roofline"])
@@ -552,13 +663,25 @@ def main():
                        "biquad bank; default: the engine's own choice (bit-exact kernels)")
   ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                   help="process-group backend for N > 1 (nccl = RCCL; gloo lets tests run several ranks on one GPU)")
+  ap.add_argument("--init-dist", action="store_true",
+                  help="initialise the process group even for ONE rank, so that the barrier, the MAX all-reduce and the "
+                       "downstream gather / mixdown run on the chosen backend (RCCL on a one-GPU box)")
+  ap.add_argument("--launch-check", action="store_true",
+                  help="start the ranks, run the protocol's collectives, print one line and exit (no device work)")
   ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
 
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    sys.exit(relaunch(args.gpus))      # plain `python bench.py --gpus N`: start the N ranks ourselves
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world != args.gpus and rank == 0:
+    print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d"
+          % (args.gpus, world, world), file=sys.stderr)
+  if args.launch_check:
+    sys.exit(launch_check(args, rank, world))
   C, N = args.channels, 1 << args.log2_samples
 
   # the CPU legs fork a process pool: run them before torch / HIP exist in this process
@@ -688,6 +811,15 @@ def main():
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
 
+  # every rank's own figures next to the whole-job one (MAX over ranks prices the line's value)
+  per_rank = None
+  if ctx.dist is not None:
+    rows = ctx.all_ranks([ctx.local_elapsed[0], res["units"], roof["kernel_ms_avg"], roof["frac"]])
+    per_rank = [{"rank": r, "value": u * args.steps / el / 1e9, "unit": unit, "ms_per_step": el / args.steps * 1e3,
+                 "kernel_ms_avg": k, "roofline_frac": f} for r, (el, u, k, f) in enumerate(rows)]
+    if args.workload == "biquad":
+      secondary["downstream_collective"] = wl_collective(ctx, args, res["C"], min(N, 1 << 16))
+
   bad = False
   if rank == 0:
     out = {
@@ -697,6 +829,10 @@ def main():
       "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
       "dtype": "f64", "data": "synthetic", "config": config, "roofline": roof,
     }
+    if per_rank is not None:
+      out["per_rank"] = per_rank
+      out["process_group"] = {"backend": args.backend, "ranks": world,
+                              "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "none (--init-dist)"}
     if secondary:
       out["secondary"] = secondary
     if cpu is not None:
@@ -706,7 +842,7 @@ def main():
     bad = any(str(c).startswith("MISMATCH") for c in checks)
     if bad:
       print("bench.py: PARITY MISMATCH -- the number above is not a valid result", file=sys.stderr)
-  if world > 1:
+  if ctx.dist is not None:
     ctx.dist.barrier()
     ctx.dist.destroy_process_group()
   if bad:

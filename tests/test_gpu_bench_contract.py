@@ -84,6 +84,35 @@ def test_two_ranks_strong_scaling_path():
   assert line["scaling"] == "strong" and line["config"]["channels_per_gpu"] == 256
 
 
+def test_plain_gpus_2_launches_two_ranks_without_torchrun():
+  # no launcher around it: bench.py starts its own ranks (they share this box's one GPU, hence gloo)
+  env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+  out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--channels", "256",
+                        "--log2-samples", "13", "--backend", "gloo"], cwd=ROOT, env=env_clean, capture_output=True,
+                       text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+  check(line, 2, 2, 1)
+  assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["value"] > 0 for r in line["per_rank"])
+  assert abs(sum(r["value"] for r in line["per_rank"]) - line["value"]) / line["value"] < 0.5
+  col = line["secondary"]["downstream_collective"]
+  assert col["ranks"] == 2 and col["parity"].startswith("collective results checked")
+
+
+def test_one_rank_group_on_rccl():
+  # init_process_group("nccl"), the barrier, the MAX all-reduce, the per-rank all_gather and the downstream
+  # gather / mixdown of audiolazy_amd.sharding on CUDA tensors: all on RCCL, on the one GPU this box has
+  line = run([sys.executable, "bench.py", "--gpus", "1", "--backend", "nccl", "--init-dist", "--steps", "2", "--warmup", "1",
+              "--channels", "512", "--log2-samples", "14", "--no-cpu-baseline"])
+  check(line, 1, 2, 1)
+  assert line["process_group"] == {"backend": "nccl", "ranks": 1, "launcher": "none (--init-dist)"}
+  assert len(line["per_rank"]) == 1 and abs(line["per_rank"][0]["value"] - line["value"]) / line["value"] < 1e-6
+  col = line["secondary"]["downstream_collective"]
+  assert col["backend"].startswith("nccl") and col["parity"].startswith("collective results checked")
+  assert set(col["collectives"]) == {"mixdown_all_reduce", "gather_to_rank0"}
+  assert all(c["check"] == "ok" and c["ms"] > 0 for c in col["collectives"].values())
+
+
 def test_smoke_entry():
   out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
