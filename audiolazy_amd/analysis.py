@@ -75,6 +75,8 @@ def _running_mean(sig, size, zero):
   leaves the sum, the new one (``item * (1 / size)``) enters it -- in that order, which fixes the
   roundings (reference :553-565)."""
   scale = 1. / size
+  if size < 0:
+    raise ValueError("maxlen must be non-negative")   # the reference's deque(maxlen=size), at the first item
   ring, at = [zero * scale] * size, 0
   acc = zero
   for item in sig:
@@ -92,8 +94,7 @@ def maverage(size):
   ``(sig, zero=0.) -> Stream``.  Not a filter object (no algebra, no frequency response) and,
   being a running sum, not the same roundings as the filter strategies; it runs on the host like
   the reference's."""
-  if size < 1:
-    raise IndexError("pop from an empty deque")      # what the reference's empty window raises
+  1. / size      # size 0: ZeroDivisionError here, at construction, like the reference's ``size_inv = 1. / size``
   return lambda sig, zero=0.: Stream(_running_mean(sig, size, zero))
 
 

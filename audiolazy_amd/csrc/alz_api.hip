@@ -577,7 +577,7 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   // three-stage pipeline over chunks of the time axis (pinned, double-buffered staging).
   // The link then carries both directions at once and at the pinned rate; small blocks (the filter
   // call protocol's 4096-sample blocks) keep the plain synchronous path, whose latency is lower.
-  static const int pipe_env = getenv("ALZ_HOST_PIPE") ? atoi(getenv("ALZ_HOST_PIPE")) : 1;
+  static const int pipe_env = ALZ_TUNE("ALZ_HOST_PIPE", 1);
   const uint64_t total_bytes = ((uint64_t)in_rows * in_cols + (uint64_t)out_rows * out_cols) * 8;
   if (pipe_env && total_bytes >= ((uint64_t)64 << 20) && n >= 8192) {
     const uint64_t x_extent = ((uint64_t)(in_rows - 1) * ldx + in_cols) * 8;

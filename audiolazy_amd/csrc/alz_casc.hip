@@ -927,312 +927,6 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 
 #undef PIPE_BARRIER
 #undef PIPE_DRAIN
-// ---------------------------------------------------------------------------
-// k_tandem: the four-section pipeline with TWO waves per section that take alternate tiles.
-//
-// In k_pipe a stage wave does everything for its section one after the other -- fetch the tile,
-// feed-forward sums, recurrence, write the tile -- and the interval between two barriers is the sum
-// of those (profiles/r02_pipe_variants.log: neither half-width workgroups nor de-phased stages
-// shorten it, because a single wave's LDS hand-over is issue- and latency-bound, not bandwidth-bound).
-// Only the recurrence has to be serial from tile to tile.  So section s gets waves A (even tiles) and
-// B (odd tiles); in every interval one of them runs the recurrence of tile k -- 16 steps of
-// y = (p + (-a1) y[-1]) + (-a2) y[-2] on sums p it prepared one interval earlier -- while its partner
-// writes out tile k-1 (which it finished in the previous interval), fetches tile k+1 and forms that
-// tile's feed-forward sums p = b0 x + b1 x[-1] + ... .  The recurrence state (y[-1], y[-2]) crosses
-// from one wave to the other through a 1 KiB LDS slot per section at the barrier.  The interval is
-// then max(recurrence, hand-over + feed-forward) instead of their sum.  Same doubles as k_casc /
-// k_pipe: the sums are formed in the reference's term order (numerator terms first).
-//
-// Schedule (interval j, section s): feed-forward of tile j - 3s, recurrence of tile j - 3s - 1,
-// write-out of tile j - 3s - 2; the storer stores tile j - 12.  Hand-off rings have three slots (a
-// tile is read twice: as the input of its own feed-forward and, one interval later, as the input
-// history of the next tile's).  Ten waves: 8 stage waves (wave w: section w & 3, parity w >> 2, so
-// that partners land on the same SIMD), loader, storer.
-// ---------------------------------------------------------------------------
-static constexpr int kTXRing = 7, kTQSlots = 3;
-
-template <int NB, unsigned PB>
-__device__ __forceinline__ void tandem_ff(const double (&x)[16], const double (&hist)[7], const double (&bc)[8],
-                                          double (&pp)[16]) {
-  // hist[k] = the input k + 1 samples before this tile (hist[0] most recent)
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    double acc = 0.0;
-    bool first = true;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if ((PB >> k) & 1u) {
-        const double xv = (u - k >= 0) ? x[u - k < 0 ? 0 : u - k] : hist[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
-        const double t = bc[k] * xv;
-        acc = first ? t : acc + t;
-        first = false;
-      }
-    }
-    pp[u] = acc;
-  }
-}
-
-template <unsigned PB, unsigned PA>
-__device__ __forceinline__ void tandem_rec(const double (&pp)[16], double na1, double na2, double &m1, double &m2,
-                                           double (&y)[16]) {
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    double acc = pp[u];
-    if constexpr (PB != 0u) {
-      if constexpr (PA & 1u) acc = acc + na1 * m1;
-      if constexpr (PA & 2u) acc = acc + na2 * m2;
-    } else {
-      bool first = true;
-      if constexpr (PA & 1u) { acc = na1 * m1; first = false; }
-      if constexpr (PA & 2u) { const double t = na2 * m2; acc = first ? t : acc + t; }
-    }
-    y[u] = acc;
-    m2 = m1;
-    m1 = acc;
-  }
-}
-
-template <bool CM, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
-          unsigned PB3, unsigned PA3>
-__global__ __launch_bounds__(640) void k_tandem(CArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int G = 64, T = 16;
-  constexpr int kSlot = kCSlot;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const int64_t c0 = p.c_first + (int64_t)blockIdx.x * G;
-  const int64_t c = c0 + lane;
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const bool outer = p.mode == ALZ_BANK_OUTER;
-  const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
-  const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
-  const int64_t nt = p.n_tiles;
-  constexpr int store_lag = 12;
-  const int64_t n_iv = nt + store_lag + 1;
-  char *xring = smem;
-  char *qring = smem + kTXRing * kSlot;                  // 3 hand-off rings x 3 slots
-  char *yring = qring + 3 * kTQSlots * kSlot;            // 2 slots
-  char *sring = yring + 2 * kSlot;                       // recurrence state: [section][2][64 lanes] doubles
-  const int lane_off = CM ? (lane / 8) * 1040 + (lane % 8) * 128 : lane * 8;
-  int swz[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
-#define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
-
-  if (wave >= 8) {
-    int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
-    if (!CM) {
-      const int row = lane / 32, cp = lane % 32;
-      x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
-      y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
-      x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
-      x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
-    } else {
-      const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
-      x_off = (in0 + ch) * p.ldx + 2 * sp;
-      y_off = (c0 + ch) * p.ldy + 2 * sp;
-      x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
-      x_tile = T; y_tile = T;
-    }
-    const double *xg = p.x + x_off;
-    double *yg = p.y + y_off;
-    // tiles queued ahead: tile t + D lands in the slot of tile t - 2, whose last reader (the
-    // feed-forward of tile t - 1, for its input history) ran in interval t - 1
-    constexpr int D = kTXRing - 2;
-    if (wave == 8) {
-      auto queue_tile = [&](int64_t t) {
-        const int s = (int)(t % kTXRing);
-#pragma unroll
-        for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlot + j * 1040);
-      };
-      for (int t = 0; t < D && t < nt; ++t) queue_tile(t);
-      {
-        const int64_t after = ((nt < D ? nt : D) - 1);
-        c_wait_vm((int)after * 8);                            // tile 0 has landed
-      }
-      __builtin_amdgcn_s_barrier();
-      for (int64_t t = 0; t < n_iv; ++t) {
-        if (t + D < nt) queue_tile(t + D);
-        if (t + 1 < nt) {
-          const int64_t last = (t + D < nt - 1) ? t + D : nt - 1;
-          c_wait_vm((int)(last - (t + 1)) * 8);               // tile t+1 has landed (its feed-forward is next)
-        }
-        __builtin_amdgcn_s_barrier();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      __builtin_amdgcn_s_barrier();
-      for (int64_t t = 0; t < n_iv; ++t) {
-        if (t >= store_lag && t - store_lag < nt) {
-          const int64_t tt = t - store_lag;
-          const char *ys = yring + (int)(tt % 2) * kSlot;
-          double *yt = yg + tt * y_tile;
-          cdbl2 w[kCChunks];
-#pragma unroll
-          for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ys + j * 1040 + lane * 16);
-#pragma unroll
-          for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  } else {
-    const int sec = wave & 3, par = wave >> 2;
-    constexpr unsigned PBS[4] = {PB0, PB1, PB2, PB3};
-    constexpr unsigned PAS[4] = {PA0, PA1, PA2, PA3};
-    unsigned pbv = 0, pav = 0;
-    int nbv = 1, nav = 1;
-    const double *bsrc = p.b[0], *asrc = p.a[0];
-    double *xhs = p.xh[0], *yhs = p.yh[0];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (sec == s) {
-        pbv = PBS[s]; pav = PAS[s]; nbv = p.nb[s]; nav = p.na[s];
-        bsrc = p.b[s]; asrc = p.a[s]; xhs = p.xh[s]; yhs = p.yh[s];
-      }
-    double bc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bc[k] = ((pbv >> k) & 1u) ? bsrc[(int64_t)k * p.n_sets + set] : 0.0;
-    const double na1 = (pav & 1u) ? -asrc[1 * p.n_sets + set] : 0.0;
-    const double na2 = (pav & 2u) ? -asrc[2 * p.n_sets + set] : 0.0;
-    double m1 = (nav > 1) ? yhs[0 * p.channels + c] : 0.0;
-    double m2 = (nav > 2) ? yhs[1 * p.channels + c] : 0.0;
-    double *st = reinterpret_cast<double *>(sring) + sec * 128 + lane;       // [0]: y[-1], [64]: y[-2]
-    if (par == 0) {            // the state every recurrence starts from is read from LDS, tile 0 included
-      st[0] = m1;
-      st[64] = m2;
-    }
-
-    auto read_tile = [&](int64_t tile, double (&v)[16]) {
-      if (sec == 0) {
-        const char *src = xring + (int)(tile % kTXRing) * kSlot + lane_off;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const double *>(src + ALZ_COFF(u));
-      } else {
-        const char *src = qring + ((sec - 1) * kTQSlots + (int)(tile % kTQSlots)) * kSlot + lane * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * 1024);
-          v[2 * j] = w.x;
-          v[2 * j + 1] = w.y;
-        }
-      }
-    };
-    // the last nb - 1 inputs of `tile` (the history of the tile after it), most recent first
-    auto read_tail = [&](int64_t tile, double (&h)[7]) {
-      if (sec == 0) {
-        const char *src = xring + (int)(tile % kTXRing) * kSlot + lane_off;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-          if (k < nbv - 1) h[k] = *reinterpret_cast<const double *>(src + ALZ_COFF(15 - k));
-      } else {
-        const char *src = qring + ((sec - 1) * kTQSlots + (int)(tile % kTQSlots)) * kSlot + lane * 16;
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-          if (k < nbv - 1) h[k] = *reinterpret_cast<const double *>(src + ((15 - k) >> 1) * 1024 + ((15 - k) & 1) * 8);
-      }
-    };
-    auto write_tile = [&](int64_t tile, const double (&v)[16]) {
-      if (sec == 3) {
-        char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) *reinterpret_cast<double *>(dst + ALZ_COFF(u)) = v[u];
-      } else {
-        char *dst = qring + (sec * kTQSlots + (int)(tile % kTQSlots)) * kSlot + lane * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          cdbl2 w;
-          w.x = v[2 * j];
-          w.y = v[2 * j + 1];
-          *reinterpret_cast<cdbl2 *>(dst + j * 1024) = w;
-        }
-      }
-    };
-    // partner role in interval j: write out the tile this wave's recurrence finished in interval
-    // j - 1, fetch the tile whose recurrence it runs in interval j + 1, and form that tile's sums
-    auto hand_over = [&](int64_t j, const double (&yv)[16], double (&pp)[16]) {
-      const int64_t k_out = j - 3 * sec - 2, k_in = j - 3 * sec;
-      const bool have_in = k_in >= 0 && k_in < nt;
-      double xin[16], hist[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) hist[k] = 0.0;
-      if (have_in) {
-        read_tile(k_in, xin);
-        if (k_in > 0) {
-          read_tail(k_in - 1, hist);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 7; ++k)
-            if (k < nbv - 1) hist[k] = xhs[(int64_t)k * p.channels + c];
-        }
-      }
-      if (k_out >= 0 && k_out < nt) write_tile(k_out, yv);
-      if (have_in) {
-        if (sec == 0) tandem_ff<nb_of(PB0), PB0>(xin, hist, bc, pp);
-        else if (sec == 1) tandem_ff<nb_of(PB1), PB1>(xin, hist, bc, pp);
-        else if (sec == 2) tandem_ff<nb_of(PB2), PB2>(xin, hist, bc, pp);
-        else tandem_ff<nb_of(PB3), PB3>(xin, hist, bc, pp);
-      }
-    };
-    auto recurrence = [&](int64_t j, const double (&pp)[16], double (&yv)[16]) {
-      const int64_t k_rec = j - 3 * sec - 1;
-      if (k_rec < 0 || k_rec >= nt) return;
-      m1 = st[0];
-      m2 = st[64];
-      if (sec == 0) tandem_rec<PB0, PA0>(pp, na1, na2, m1, m2, yv);
-      else if (sec == 1) tandem_rec<PB1, PA1>(pp, na1, na2, m1, m2, yv);
-      else if (sec == 2) tandem_rec<PB2, PA2>(pp, na1, na2, m1, m2, yv);
-      else tandem_rec<PB3, PA3>(pp, na1, na2, m1, m2, yv);
-      st[0] = m1;
-      st[64] = m2;
-    };
-    auto end_interval = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    end_interval();                                          // (initial state is in LDS, tile 0 has landed)
-    // this wave's recurrences fall in the intervals j = k + 3 sec + 1 with k = par (mod 2); the
-    // intervals in between are its hand-over intervals
-    const int phase = (par + sec + 1) & 1;
-    int64_t j = 0;
-    if (phase == 0) {                                        // interval 0 would be a recurrence slot: no tile yet
-      end_interval();
-      j = 1;
-    }
-    double yv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) yv[u] = 0.0;
-    for (; j + 1 < n_iv; j += 2) {
-      double pp[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) pp[u] = 0.0;
-      hand_over(j, yv, pp);
-      end_interval();
-      recurrence(j + 1, pp, yv);
-      end_interval();
-    }
-    if (j < n_iv) {                                          // a last hand-over interval (write-out only)
-      double pp[16];
-      hand_over(j, yv, pp);
-      end_interval();
-    }
-    // final state: the wave that ran the last tile's recurrence holds y[-1], y[-2]; the input history
-    // is the tail of the last tile, still in its ring slot
-    if (nt > 0 && ((nt - 1) & 1) == par) {
-      double hist[7];
-      read_tail(nt - 1, hist);
-#pragma unroll
-      for (int k = 0; k < 7; ++k)
-        if (k < nbv - 1) xhs[(int64_t)k * p.channels + c] = hist[k];
-      if (nav > 1) yhs[0 * p.channels + c] = m1;
-      if (nav > 2) yhs[1 * p.channels + c] = m2;
-    }
-  }
-#undef ALZ_COFF
-}
-
 typedef void (*casc_fn)(CArgs);
 
 template <bool CM>
@@ -1264,19 +958,6 @@ static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
   return nullptr;
 }
 
-template <bool CM>
-static casc_fn pick_tandem(const unsigned *pb, const unsigned *pa) {
-#define ALZ_TANDEM(B0, A0, B1, A1, B2, A2, B3, A3)                                               \
-  if (pb[0] == B0 && pa[0] == A0 && pb[1] == B1 && pa[1] == A1 && pb[2] == B2 && pa[2] == A2 &&  \
-      pb[3] == B3 && pa[3] == A3)                                                                \
-    return (casc_fn)k_tandem<CM, B0, A0, B1, A1, B2, A2, B3, A3>;
-  ALZ_TANDEM(3, 3, 3, 3, 3, 3, 3, 3)        // gammatone.slaney
-  ALZ_TANDEM(5, 3, 1, 3, 5, 3, 1, 3)        // gammatone.klapuri
-  ALZ_TANDEM(0xFE, 3, 1, 3, 1, 3, 1, 3)     // gammatone.sampled
-#undef ALZ_TANDEM
-  return nullptr;
-}
-
 // Whole cascade in one pass when its section patterns are one of the fused combinations.
 // Handles the full 16-sample tiles of the full 64-channel groups; reports what it covered.
 int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
@@ -1300,43 +981,24 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   const int64_t ldx = cm ? io.sxc : io.sxn, ldy = cm ? io.syc : io.syn;
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
   if ((ldx | ldy) & 1) return ALZ_OK;
-  // ALZ_PIPE: 0 = single-wave k_casc, 1 = one section per stage wave, 2 = two sections per stage wave
-  static const int pipe_env = getenv("ALZ_PIPE") ? atoi(getenv("ALZ_PIPE")) : 1;
-  // half-width workgroups (two per CU) when full-width ones would leave CUs with a single workgroup
-  static const int pipe_g_env = getenv("ALZ_PIPE_G") ? atoi(getenv("ALZ_PIPE_G")) : 0;
-  // (measured on cfg4, 256 bands x 64 streams: two half-width workgroups per CU 258 Gsamples/s against
-  // 385 for one full-width one -- the ghost lanes double the arithmetic per sample and the per-interval
-  // skeleton does not shrink with the tile; kept for A/B runs only, ALZ_PIPE_G=32)
-  int g = 64;
-  if (pipe_g_env == 32 && nsec == 4 && pipe_env == 1 && io.channels % 32 == 0 &&
-      (io.mode != ALZ_BANK_OUTER || !io.map_input || io.n_inputs % 32 == 0))
-    g = 32;
   // OUTER banks that read their input by input index: a workgroup's channels must be adjacent inputs of one band
   const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
+  const int g = 64;
   if (by_input && (io.n_inputs % g) != 0) return ALZ_OK;
   const int64_t tiles = io.n / 16;
-  int64_t groups = io.channels / g;
+  const int64_t groups = io.channels / g;
   if (groups == 0 || tiles == 0) return ALZ_OK;
-  casc_fn pipe = nullptr;
-  if (nsec == 4 && pipe_env == 1 && g == 32) pipe = cm ? pick_pipe<true, 1, 32>(pb, pa) : pick_pipe<false, 1, 32>(pb, pa);
-  if (!pipe) {
-    if (g == 32 && by_input && (io.n_inputs % 64) != 0) return ALZ_OK;
-    g = 64;
-    groups = io.channels / 64;
-    if (groups == 0) return ALZ_OK;
-  }
-  // ALZ_PIPE=3: the tandem pipeline (two waves per section on alternate tiles)
-  casc_fn tandem = nullptr;
-  if (nsec == 4 && pipe_env == 3) tandem = cm ? pick_tandem<true>(pb, pa) : pick_tandem<false>(pb, pa);
-  if (tandem) { pipe = tandem; g = 64; groups = io.channels / 64; if (groups == 0) return ALZ_OK; }
+  // Four sections: the wave pipeline (one section per stage wave) while there are fewer 64-channel groups than
+  // SIMDs; from 1024 groups up every SIMD has a whole single-wave cascade of its own and the hand-over only
+  // costs (256 bands x 256 streams: k_casc 528 - 538 against k_pipe 436 - 472 Gsamples/s, profiles/NOTES_r02.md 14).
+  // ALZ_TUNE: a run-time override exists in -DALZ_TUNING builds only (tools/variants).
+  const int pipe_sel = ALZ_TUNE("ALZ_PIPE", groups >= 1024 ? 0 : 1);
   const bool fma = io.fused != 0;
-  if (!pipe && nsec == 4 && fma && pipe_env == 2)      // A/B: two sections per stage wave with fused arithmetic
-    pipe = cm ? pick_pipe<true, 2, 64, true>(pb, pa) : pick_pipe<false, 2, 64, true>(pb, pa);
-  if (!pipe && nsec == 4 && fma && pipe_env != 0)
-    pipe = cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa);
-  if (!pipe && nsec == 4 && (pipe_env == 1 || pipe_env == 3)) pipe = cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa);
-  if (!pipe && nsec == 4 && pipe_env == 2) pipe = cm ? pick_pipe<true, 2>(pb, pa) : pick_pipe<false, 2>(pb, pa);
-  const int pipe_waves = tandem ? 10 : pipe_env == 2 ? 4 : 6;   // stage waves + loader + storer
+  casc_fn pipe = nullptr;
+  if (nsec == 4 && pipe_sel != 0)
+    pipe = fma ? (cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa))
+               : (cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa));
+  const int pipe_waves = 6;   // four stage waves + loader + storer
   casc_fn fn = pipe ? pipe : (cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
   if (!fn) return ALZ_OK;
   CArgs p;
@@ -1350,8 +1012,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
   }
   const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
-  const size_t lds = tandem ? (size_t)(kTXRing + 3 * kTQSlots + 2) * kCSlot + 4 * 128 * sizeof(double)
-                   : pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
+  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
   if (pipe) {
     const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
     if (rc) return rc;
@@ -1360,7 +1021,7 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * 16;
   *done_channels = groups * g;
-  *kernel_name = tandem ? "k_tandem" : pipe ? (g == 32 ? "k_pipe<32>" : (fma && nsec == 4 && pipe_env != 0) ? "k_pipe<fma>" : "k_pipe") : "k_casc";
+  *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : "k_casc";
   return ALZ_OK;
 }
 

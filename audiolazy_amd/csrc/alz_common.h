@@ -19,6 +19,15 @@
 #define ALZ_DBG_ENV() 0
 #endif
 
+// Tuning overrides read from the environment exist only in -DALZ_TUNING builds (tools/variants, loaded through
+// ALZ_LIBRARY for A/B runs); the shipped library carries the measured defaults and no run-time knobs.
+#ifdef ALZ_TUNING
+#include <stdlib.h>
+#define ALZ_TUNE(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define ALZ_TUNE(name, dflt) (dflt)
+#endif
+
 namespace alz {
 
 // thread-local last-error message (alz_last_error)

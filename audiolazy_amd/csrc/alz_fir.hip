@@ -18,7 +18,6 @@
 //
 // Bound: FP64 issue, not HBM: 2*nb - 1 f64 ops per output sample (511 for 256 taps) at one op
 // per ~4.5 cycles per SIMD.
-#include <cstdlib>
 #include "alz_common.h"
 
 namespace alz {
@@ -50,6 +49,9 @@ struct FArgs {
   const double *xh;        // xh[k * channels + c] = x[-1-k]
   int div;                 // some a0 != 1
   double zero;             // what an all-zero tap set yields (lazy_filters.py:227-231)
+  // k_fir_ring: block (x, y) computes the runs of kRingR output rows  y * run_first_mul + s * run_stride,
+  // s = 0 .. run_count - 1 (those that start inside the block)
+  int64_t run_first_mul, run_stride, run_count;
 };
 
 template <bool SHARED>
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(64) void k_fir(FArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_fir_s: k_fir for taps shared by the whole bank, restructured around what bounded k_fir<true>
+// (k_fir_s, round 1, kept only as this note:) k_fir for taps shared by the whole bank, restructured around what bounded k_fir<true>
 // (62 % of the separately-rounded f64 rate): the K new rows of a tap block were loaded at the top
 // of the block and needed by its first tap, so each of the two waves of a SIMD sat out a whole
 // L2 / HBM latency per block.  Here the rows of block kb + K are requested before the sums of
@@ -166,89 +168,6 @@ __device__ __forceinline__ double wave_uniform(double v) {
   const int lo = __builtin_amdgcn_readfirstlane((int)bits);
   const int hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_fir_s(FArgs p) {
-  constexpr int R = kFirR, K = kFirSK;
-  const int lane = threadIdx.x;
-  int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + lane;
-  const bool live = c < p.c_end;
-  if (!live) c = p.c_end - 1;
-  const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? c % p.n_inputs : c;
-  const double a0 = p.a[0];
-  const int64_t tb0 = (int64_t)blockIdx.y * kFirTB;
-  extern __shared__ __attribute__((aligned(16))) double tap_lds[];
-  const int padded = ((p.nb + K - 1) / K) * K;
-  for (int k = lane; k < padded; k += 64) tap_lds[k] = (k < p.nb) ? p.b[k] : 0.0;
-  __syncthreads();
-  const unsigned lane_off = (unsigned)in * 8u;               // launch_fir keeps channels * 8 < 2^31
-  const int64_t row_bytes = p.sxn * 8;
-
-  auto load_row = [&](int64_t t) -> double {
-    if (t > p.n - 1) t = p.n - 1;
-    int64_t hk = -t - 1;
-    if (hk > p.nb - 2) hk = p.nb - 2;
-    const double *src = (t >= 0) ? p.x + t * p.sxn + in : p.xh + (hk < 0 ? 0 : hk) * p.channels + c;
-    return *src;
-  };
-  // rows tb .. tb + K - 1 (all <= n - 1 by construction) into dst
-  auto load_group = [&](int64_t tb, double (&dst)[K]) {
-    if (tb >= 0) {
-      const char *base = (const char *)p.x + tb * row_bytes;  // wave-uniform
-#pragma unroll
-      for (int j = 0; j < K; ++j) dst[j] = *(const double *)(base + j * row_bytes + lane_off);
-    } else {
-#pragma unroll
-      for (int j = 0; j < K; ++j) dst[j] = load_row(tb + j);
-    }
-  };
-
-  for (int sub = 0; sub < kFirTB; sub += R) {
-    const int64_t t0 = tb0 + sub;
-    if (t0 >= p.n) break;
-    double acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = -0.0;
-    double xw[R + K - 1], xn[K];
-#pragma unroll
-    for (int j = K; j < R + K - 1; ++j) xw[j] = load_row(t0 - (K - 1) + j);
-    load_group(t0 - (K - 1), xn);
-    for (int kb = 0; kb < p.nb; kb += K) {
-      if (kb > 0) {
-#pragma unroll
-        for (int j = R + K - 2; j >= K; --j) xw[j] = xw[j - K];
-      }
-#pragma unroll
-      for (int j = 0; j < K; ++j) xw[j] = xn[j];
-      if (kb + K < p.nb) load_group(t0 - (kb + K) - (K - 1), xn);   // next block's rows, in flight
-      double bk[K];
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) bk[kk] = wave_uniform(tap_lds[kb + kk]);
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk) {
-        if ((__double_as_longlong(bk[kk]) << 1) == 0) continue;    // +-0 tap: absent from the sum
-#pragma unroll
-        for (int r = 0; r < R; r += 4) {
-          const double m0 = bk[kk] * xw[r - kk + (K - 1)];
-          const double m1 = bk[kk] * xw[r + 1 - kk + (K - 1)];
-          const double m2 = bk[kk] * xw[r + 2 - kk + (K - 1)];
-          const double m3 = bk[kk] * xw[r + 3 - kk + (K - 1)];
-          acc[r] = acc[r] + m0;
-          acc[r + 1] = acc[r + 1] + m1;
-          acc[r + 2] = acc[r + 2] + m2;
-          acc[r + 3] = acc[r + 3] + m3;
-        }
-      }
-    }
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t t = t0 + r;
-        if (t < p.n) p.y[t * p.syn + c] = p.div ? acc[r] / a0 : acc[r];
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -268,6 +187,9 @@ typedef const double __attribute__((address_space(4))) *const_taps_t;
 #ifndef ALZ_FIR_RING_R
 #define ALZ_FIR_RING_R 48
 #endif
+#ifndef ALZ_FIR_MG
+#define ALZ_FIR_MG 4      // products formed per group in the bit-exact instantiation (4 or 2)
+#endif
 static constexpr int kRingR = ALZ_FIR_RING_R;
 static constexpr int kRingTB = 8 * kRingR;   // output rows per wave
 static constexpr int kRingK = kFirSK;
@@ -283,36 +205,51 @@ __device__ __forceinline__ bool tap_absent(double t) {
 struct RingCtx {
   const FArgs *p;
   int64_t in, c, row_bytes;
-  unsigned lane_off;
+  unsigned lane_off, chan_off;   // byte offsets of this lane's input column / output channel
   const_taps_t taps;
 };
-
-__device__ __forceinline__ double ring_edge_row(const RingCtx &q, int64_t t) {
-  const FArgs &p = *q.p;
-  if (t > p.n - 1) t = p.n - 1;                             // past the block: never used
-  int64_t hk = -t - 1;                                      // before the stream: history row
-  if (hk > p.nb - 2) hk = p.nb - 2;                         // beyond the delay line: never used
-  const double *src = (t >= 0) ? p.x + t * p.sxn + q.in : p.xh + (hk < 0 ? 0 : hk) * p.channels + q.c;
-  return *src;
-}
 
 // rows tb .. tb + K - 1 (all <= n - 1) of this wave's channels into one ring group.  The buffer
 // loads are issued whatever tb is (from row 0 when the group reaches before the block) and the rare
 // history case overwrites them afterwards: with the loads behind a branch the compiler's waitcnt
 // pass has to assume at the join that none were issued and waits for ALL outstanding loads before
 // the first use of the PREVIOUS group -- which is exactly the latency this prefetch is there to hide.
+template <bool EDGE>
 __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, double (&dst)[kRingK]) {
-  const int64_t tc = tb < 0 ? 0 : tb;
-  const char *base = (const char *)q.p->x + tc * q.row_bytes;            // wave-uniform
-  int64_t valid = (q.p->n - tc) * q.row_bytes;             // rows past the block read as 0.0 (range check)
-  if (valid > 0x7fffffff) valid = 0x7fffffff;
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)valid, 0x00020000);
+  if constexpr (!EDGE) {
+    const int64_t tc = tb < 0 ? 0 : tb;
+    const char *base = (const char *)q.p->x + tc * q.row_bytes;            // wave-uniform
+    int64_t valid = (q.p->n - tc) * q.row_bytes;
+    if (valid > 0x7fffffff) valid = 0x7fffffff;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)valid, 0x00020000);
+    // rows past the block are never used; they are clamped to its last row with scalar arithmetic (the
+    // descriptor's range check does not cover the scalar offset)
+    const int last = (int)((q.p->n - 1 - tc) < (kRingK - 1) ? (q.p->n - 1 - tc) : (kRingK - 1));
 #pragma unroll
-  for (int j = 0; j < kRingK; ++j)
-    dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, (int)(j * q.row_bytes), 0));
-  if (tb < 0) {
+    for (int j = 0; j < kRingK; ++j)
+      dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, (int)((j < last ? j : last) * q.row_bytes), 0));
+  } else {
+    // first row tiles of a block: a row is either inside the block (t >= 0) or a row of the delay line
+    // (p.xh[(-t - 1) * channels + c]).  Which one is wave-uniform, so it is a scalar choice of descriptor and
+    // row offset for the same buffer load -- no per-lane 64-bit pointers, no branch for the wait-count pass to
+    // lose track of (launch_fir keeps both byte ranges below 2^31).
+    const FArgs &p = *q.p;
+    int64_t xbytes = p.n * q.row_bytes;
+    if (xbytes > 0x7fffffff) xbytes = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.xh, 0, (int)((int64_t)(p.nb - 1) * p.channels * 8), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < kRingK; ++j) dst[j] = ring_edge_row(q, tb + j);
+    for (int j = 0; j < kRingK; ++j) {
+      int64_t t = tb + j;
+      if (t > p.n - 1) t = p.n - 1;                           // past the block: never used
+      int64_t hk = -t - 1;                                    // before the stream: history row
+      if (hk > p.nb - 2) hk = p.nb - 2;                       // beyond the delay line: never used
+      const bool in_block = t >= 0;
+      const int soff = in_block ? (int)(t * q.row_bytes) : (int)(hk * p.channels * 8);
+      const unsigned voff = in_block ? q.lane_off : q.chan_off;
+      dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(in_block ? rx : rh, voff, soff, 0));
+    }
   }
 }
 
@@ -327,12 +264,12 @@ __device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double 
   }
 }
 
-template <int PH, bool FMA>
+template <int PH, bool FMA, bool EDGE>
 __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, double (&xr)[kRingG][kRingK],
                                           double (&acc)[kRingR], const double (&tap)[kRingK],
                                           double (&tap_next)[kRingK]) {
   constexpr int R = kRingR, K = kRingK, NG = kRingG;
-  ring_load_group(q, t0 - (kb + K) - (K - 1), xr[NG - 1 - PH]);   // unused after the last block
+  ring_load_group<EDGE>(q, t0 - (kb + K) - (K - 1), xr[NG - 1 - PH]);   // unused after the last block
   ring_load_taps(q, kb + K, tap_next);                            // likewise (all 0.0 past the end)
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) {
@@ -348,6 +285,22 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
         acc[r + 2] = __builtin_fma(tap[kk], ALZ_RING_X(r + 2 - kk + (K - 1)), acc[r + 2]);
         acc[r + 3] = __builtin_fma(tap[kk], ALZ_RING_X(r + 3 - kk + (K - 1)), acc[r + 3]);
       } else {
+#if ALZ_FIR_MG == 2
+        // products formed two at a time: 48 accumulators + 64 window rows leave room for two product
+        // temporaries, four spilled 36 bytes per lane (rocprofv3 Scratch_Size, profiles/r02_kernel_dispatches.csv)
+        {
+          const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
+          const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
+          acc[r] = acc[r] + m0;
+          acc[r + 1] = acc[r + 1] + m1;
+        }
+        {
+          const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
+          const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
+          acc[r + 2] = acc[r + 2] + m2;
+          acc[r + 3] = acc[r + 3] + m3;
+        }
+#else
         const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
         const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
         const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
@@ -356,6 +309,7 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
         acc[r + 1] = acc[r + 1] + m1;
         acc[r + 2] = acc[r + 2] + m2;
         acc[r + 3] = acc[r + 3] + m3;
+#endif
       }
     }
 #undef ALZ_RING_X
@@ -363,28 +317,65 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
 }
 
 // NG is even: the two tap buffers swap roles with the parity of the phase
-template <int PH, bool FMA>
+template <int PH, bool FMA, bool EDGE>
 __device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb, double (&xr)[kRingG][kRingK],
                                            double (&acc)[kRingR], double (&tap_a)[kRingK], double (&tap_b)[kRingK],
                                            bool &done) {
   if constexpr (PH < kRingG) {
     if (!done) {
-      if constexpr (PH % 2 == 0) ring_step<PH, FMA>(q, t0, kb, xr, acc, tap_a, tap_b);
-      else ring_step<PH, FMA>(q, t0, kb, xr, acc, tap_b, tap_a);
+      if constexpr (PH % 2 == 0) ring_step<PH, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b);
+      else ring_step<PH, FMA, EDGE>(q, t0, kb, xr, acc, tap_b, tap_a);
       kb += kRingK;
       done = kb >= q.p->nb;
     }
-    ring_steps<PH + 1, FMA>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+    ring_steps<PH + 1, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b, done);
   }
 }
 
 #ifndef ALZ_FIR_WAVES
 #define ALZ_FIR_WAVES 2
 #endif
+// One run of R output rows per lane.  EDGE = false: every row the run touches (t0 - nb - K .. t0 + R - 1) lies
+// inside the block, so the window comes through buffer loads only -- no per-lane row pointers, no history
+// selects in the tap loop (that code kept ~16 more VGPRs live across the loop: the bit-exact instantiation
+// spilled 36 bytes per lane at R = 48).  EDGE = true: the first row tiles of a block, which reach into the
+// delay line (p.xh), and nothing else.
+template <bool FMA, bool EDGE>
+__device__ __forceinline__ void ring_run(const FArgs &p, const RingCtx &q, int64_t t0, bool live, double a0) {
+  constexpr int R = kRingR, K = kRingK, NG = kRingG;
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = -0.0;
+  double xr[NG][K];
+#pragma unroll
+  for (int g = NG - 2; g >= 0; --g)                          // groups 0 .. NG - 2: rows t0 - (K - 1) .. t0 + R - 1 (+ 1 unused)
+    ring_load_group<EDGE>(q, t0 - (K - 1) + g * K, xr[g]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) xr[NG - 1][j] = 0.0;
+  int kb = 0;
+  bool done = false;
+  double tap_a[K], tap_b[K];
+  ring_load_taps(q, 0, tap_a);
+  while (!done) {
+    ring_steps<0, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b, done);
+    if constexpr (NG % 2 != 0) {                             // odd ring: the roles end up swapped
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) { const double t = tap_a[kk]; tap_a[kk] = tap_b[kk]; tap_b[kk] = t; }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = t0 + r;
+      if (t < p.n) p.y[t * p.syn + q.c] = p.div ? acc[r] / a0 : acc[r];
+    }
+  }
+}
+
 template <bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_FIR_WAVES, ALZ_FIR_WAVES)))
 void k_fir_ring(FArgs p) {
-  constexpr int R = kRingR, K = kRingK, NG = kRingG;
+  constexpr int R = kRingR, K = kRingK;
   const int lane = threadIdx.x;
   RingCtx q;
   q.p = &p;
@@ -393,42 +384,19 @@ void k_fir_ring(FArgs p) {
   if (!live) q.c = p.c_end - 1;
   q.in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? q.c % p.n_inputs : q.c;
   q.lane_off = (unsigned)q.in * 8u;                         // launch_fir keeps channels * 8 < 2^31
+  q.chan_off = (unsigned)q.c * 8u;
   q.row_bytes = p.sxn * 8;
   q.taps = (const_taps_t)(uintptr_t)p.b;
   const double a0 = p.a[0];
-  const int64_t tb0 = (int64_t)blockIdx.y * kRingTB;
-
-  for (int sub = 0; sub < kRingTB; sub += R) {
-    const int64_t t0 = tb0 + sub;
+  // the lowest row a run starting at t0 reads is t0 - (nb_padded + K) - (K - 1) (the prefetch of the block
+  // after the last one): runs that start past that are interior
+  const int64_t reach = (int64_t)((p.nb + K - 1) / K) * K + 2 * K;
+  int64_t run = (int64_t)blockIdx.y * p.run_first_mul;
+  for (int64_t s = 0; s < p.run_count; ++s, run += p.run_stride) {
+    const int64_t t0 = run * R;
     if (t0 >= p.n) break;
-    double acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = -0.0;
-    double xr[NG][K];
-#pragma unroll
-    for (int j = K; j < R + K; ++j)                          // groups 1 .. NG - 2: rows of this output run
-      xr[j / K][j % K] = (j < R + K - 1) ? ring_edge_row(q, t0 - (K - 1) + j) : 0.0;
-    ring_load_group(q, t0 - (K - 1), xr[0]);
-#pragma unroll
-    for (int j = 0; j < K; ++j) xr[NG - 1][j] = 0.0;
-    int kb = 0;
-    bool done = false;
-    double tap_a[K], tap_b[K];
-    ring_load_taps(q, 0, tap_a);
-    while (!done) {
-      ring_steps<0, FMA>(q, t0, kb, xr, acc, tap_a, tap_b, done);
-      if constexpr (NG % 2 != 0) {                           // odd ring: the roles end up swapped
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) { const double t = tap_a[kk]; tap_a[kk] = tap_b[kk]; tap_b[kk] = t; }
-      }
-    }
-    if (live) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t t = t0 + r;
-        if (t < p.n) p.y[t * p.syn + q.c] = p.div ? acc[r] / a0 : acc[r];
-      }
-    }
+    if (t0 >= reach) ring_run<FMA, false>(p, q, t0, live, a0);
+    else ring_run<FMA, true>(p, q, t0, live, a0);
   }
 }
 
@@ -565,6 +533,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   p.mode = io.mode; p.map_input = io.map_input;
   p.nb = sec.nb; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.div = sec.any_div ? 1 : 0;
   p.zero = io.zero;
+  p.run_first_mul = 0; p.run_stride = 1; p.run_count = 0;
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const unsigned gy = (unsigned)((io.n + kFirTB - 1) / kFirTB);
   if (gy > 65535u) return ALZ_OK;  // block longer than the grid's y range: caller falls back
@@ -580,16 +549,31 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     if (gyc > 65535u || io.c_count > 0x7fffffff) return ALZ_OK;
     hipLaunchKernelGGL(k_fir_cm, dim3((unsigned)io.c_count, gyc), dim3(64), lds, stream, p);
   } else if (sec.shared_sets && io.n_inputs * 8 < ((int64_t)1 << 31) && io.channels * 8 < ((int64_t)1 << 31) &&
-             io.sxn * 8 * kRingK < ((int64_t)1 << 31) && !getenv("ALZ_FIR_OLD")) {
-    if (getenv("ALZ_FIR_S")) {
-      hipLaunchKernelGGL(k_fir_s, dim3(gx, gy), dim3(64), tap_bytes, stream, p);
-      shared_name = "k_fir_s";
+             io.sxn * 8 * kRingK < ((int64_t)1 << 31) &&
+             (int64_t)(sec.nb + 4 * kRingK + kRingTB) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge tiles: 32-bit row offsets
+             (int64_t)(sec.nb - 1) * io.channels * 8 < ((int64_t)1 << 31)) {
+    // Run-to-wave mapping.  A run (kRingR output rows of 64 channels) reads a window of kRingR + nb - 1 input rows,
+    // so neighbouring runs share most of their input.  Interleaved (default): the grid is just large enough to
+    // fill the chip (two waves per SIMD) and block y takes runs y, y + GY, y + 2 GY, ...: at any moment the GY
+    // waves of a channel group -- same XCD, since the XCD follows blockIdx.x -- work on ADJACENT runs, and a row
+    // fetched by the leading wave is found in that XCD's L2 by the others a few microseconds later (reuse distance
+    // ~1.5 MB per XCD against 4 MB of L2).  Blocked (round 1/2): block y takes 8 consecutive runs, so concurrent
+    // waves are 8 runs apart and every re-read of a row comes from HBM / Infinity Cache 40+ us later.
+    const int64_t runs_total = (io.n + kRingR - 1) / kRingR;
+    const int map_sel = ALZ_TUNE("ALZ_FIR_MAP", 1);
+    unsigned gyr;
+    if (map_sel == 1) {
+      int64_t gy_fill = (2 * 1024 + gx - 1) / gx;             // waves that fill 1024 SIMDs twice
+      if (gy_fill < 1) gy_fill = 1;
+      gyr = (unsigned)(runs_total < gy_fill ? runs_total : gy_fill);
+      p.run_first_mul = 1; p.run_stride = gyr; p.run_count = (runs_total + gyr - 1) / gyr;
     } else {
-      const unsigned gyr = (unsigned)((io.n + kRingTB - 1) / kRingTB);
-      if (io.fused) hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gyr), dim3(64), 0, stream, p);
-      else hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gyr), dim3(64), 0, stream, p);
-      shared_name = io.fused ? "k_fir_ring<fma>" : "k_fir_ring";
+      gyr = (unsigned)((io.n + kRingTB - 1) / kRingTB);
+      p.run_first_mul = kRingTB / kRingR; p.run_stride = 1; p.run_count = kRingTB / kRingR;
     }
+    if (io.fused) hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gyr), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gyr), dim3(64), 0, stream, p);
+    shared_name = io.fused ? "k_fir_ring<fma>" : "k_fir_ring";
   }
   else if (sec.shared_sets)
     hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), tap_bytes, stream, p);

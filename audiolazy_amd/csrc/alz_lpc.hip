@@ -18,7 +18,7 @@
 
 #include <type_traits>
 
-#include "alz_common.h"
+#include "alz_lev.h"
 
 namespace alz {
 
@@ -223,8 +223,10 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-// LEV = true: Levinson-Durbin runs right away on the lane's P lags (still in registers) and the
+// LEV = 1: Levinson-Durbin runs right away on the lane's P lags (still in registers) and the
 // kernel writes coefficients / error / status instead of the lags: lpc.kautocor in one launch.
+// LEV = 2 (ALZ_LPC_DENSE): the same with the reference's own dense Levinson-Durbin (alz_lev.h): coefficients
+// and error bit-identical to lpc.kautocor on every frame, still one launch.
 // FMA = true (opt-in, ALZ_LPC_FUSED): every term is one v_fma_f64 instead of a separately rounded
 // multiply and add -- half the instructions of a kernel that is bound by FP64 issue (moving the same
 // 252 MB without computing takes 34 us, tools/ubench_stride.hip), same ascending order per lag, NOT the
@@ -236,7 +238,7 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 #ifndef ALZ_LPC_FULL
 #define ALZ_LPC_FULL 1
 #endif
-template <int P, bool LEV, bool FMA = false>
+template <int P, int LEV, bool FMA = false>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
                                                      double *__restrict__ coefs, double *__restrict__ err,
@@ -326,10 +328,20 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
 #pragma unroll
     for (int k = 0; k < 16; ++k) hist[k] = cur[15 - k];
   }
-  if constexpr (!LEV) {
+  if constexpr (LEV == 0) {
     if (live) {
 #pragma unroll
       for (int i = 0; i < P; ++i) r_out[f * P + i] = acc[i];
+    }
+  } else if constexpr (LEV == 2) {
+    double A[P], e;
+    int st;
+    levinson_dense_regs<P>(acc, A, e, st);
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < P; ++i) coefs[f * P + i] = A[i];
+      err[f] = e;
+      status[f] = st;
     }
   } else {
     constexpr int order = P - 1;
@@ -364,163 +376,9 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
   }
 }
 
-// ---------------------------------------------------------------------------
-// k_acorr_pair<P, LEV>: k_acorr_stage with the LAGS of a frame split over the two waves of a
-// workgroup.  65 536 frames are 1024 lane-per-frame waves, one per SIMD, and a wave that has its SIMD
-// to itself issues one instruction per ~5.3 cycles whatever the mix (PMC: the wave issues for 111 k of
-// its 121 k cycles): the kernel sat on the lone-wave issue floor.  Here wave 0 sums lags 0 .. P0-1 and
-// wave 1 lags P0 .. P-1 of the same 64 frames from the same LDS chunk ring (wave 0 queues the DMA;
-// one s_barrier per chunk tells wave 1 that a chunk has landed and wave 0 that the slot it is about
-// to refill has been read), so every SIMD hosts two waves of half the length.  Each lag is still
-// summed by one lane in ascending sample order: bit-exact.  At the end wave 1 hands its lags over
-// through LDS and wave 0 runs Levinson-Durbin / writes the results.
-// ---------------------------------------------------------------------------
-template <int P, bool LEV>
-__global__ __launch_bounds__(128) void k_acorr_pair(const double *__restrict__ sig, int64_t n_frames,
-                                                    int frame_len, int64_t hop, double *__restrict__ r_out,
-                                                    double *__restrict__ coefs, double *__restrict__ err,
-                                                    int *__restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(P >= 2 && P <= 17, "one chunk of history");
-  constexpr int P0 = (P + 1) / 2;            // lags of wave 0; wave 1 takes the other P - P0
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const int64_t f0 = (int64_t)blockIdx.x * 64;
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const int L = frame_len;
-  const int nchunks = (L + 15) / 16;
-  auto src_of = [&](int j, int c) -> const double * {
-    int64_t fr = f0 + 8 * j + lane / 8;
-    if (fr > n_frames - 1) fr = n_frames - 1;
-    const int piece = (lane % 8) ^ (int)((8 * j + lane / 8) & 7);
-    int64_t s0 = (int64_t)16 * c + 2 * piece;
-    if (s0 > L - 2) s0 = (L >= 2) ? ((L - 2) & ~1) : 0;
-    return sig + fr * hop + s0;
-  };
-  auto queue = [&](int c) {
-    const unsigned slot = lds0 + (unsigned)(c % 3) * 8192u;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lpc_dma16(src_of(j, c), slot + j * 1024);
-  };
-  const int64_t f = f0 + lane;
-  const bool live = f < n_frames;
-  constexpr int NL = P0;                      // accumulators per lane (wave 1 uses P - P0 <= P0 of them)
-  double acc[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) acc[i] = 0.0;
-  double hist[16];                            // hist[k] = x[16*c - 1 - k]
-#pragma unroll
-  for (int k = 0; k < 16; ++k) hist[k] = 0.0;
-
-  if (wave == 0) {
-    queue(0);
-    if (nchunks > 1) queue(1);
-  }
-  for (int c = 0; c < nchunks; ++c) {
-    if (wave == 0) {
-      // transfers issued after chunk c's: chunk c+1 (chunk c+2 is queued after the barrier)
-      if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of chunk c-1 are done
-    __builtin_amdgcn_s_barrier();                            // chunk c has landed; slot (c+2)%3 is free
-    if (wave == 0 && c + 2 < nchunks) queue(c + 2);
-    const char *slot = smem + (c % 3) * 8192 + lane * 128;
-    double cur[16];
-#pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
-      typedef double d2 __attribute__((ext_vector_type(2)));
-      const d2 v = *reinterpret_cast<const d2 *>(slot + ((pc ^ (lane & 7)) * 16));
-      cur[2 * pc] = v.x;
-      cur[2 * pc + 1] = v.y;
-    }
-    const int valid = L - 16 * c;
-    auto chunk = [&](auto checked, auto first_half) {
-      constexpr int I0 = decltype(first_half)::value ? 0 : P0;
-      constexpr int I1 = decltype(first_half)::value ? P0 : P;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (u < valid) {
-          const double xm = cur[u];
-#pragma unroll
-          for (int i = I0; i < I1; ++i) {
-            const double xe = (u - i >= 0) ? cur[u - i >= 0 ? u - i : 0] : hist[(i - u - 1) < 16 ? (i - u - 1) : 0];
-            if constexpr (decltype(checked)::value) {
-              if (u - i >= 0 || 16 * c + u - i >= 0) acc[i - I0] = acc[i - I0] + xe * xm;
-            } else {
-              acc[i - I0] = acc[i - I0] + xe * xm;
-            }
-          }
-        }
-      }
-    };
-    if (wave == 0) {
-      if (c < 1) chunk(std::true_type{}, std::true_type{});
-      else chunk(std::false_type{}, std::true_type{});
-    } else {
-      if (c < 1) chunk(std::true_type{}, std::false_type{});
-      else chunk(std::false_type{}, std::false_type{});
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hist[k] = cur[15 - k];
-  }
-  // wave 1 hands its lags over: [lag - P0][lane] doubles in the (now idle) ring
-  double *hand = reinterpret_cast<double *>(smem);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                              // every read of the last chunk is done
-  if (wave == 1) {
-#pragma unroll
-    for (int i = 0; i < P - P0; ++i) hand[i * 64 + lane] = acc[i];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wave == 1) return;
-  double r[P];
-#pragma unroll
-  for (int i = 0; i < P0; ++i) r[i] = acc[i];
-#pragma unroll
-  for (int i = P0; i < P; ++i) r[i] = hand[(i - P0) * 64 + lane];
-  if constexpr (!LEV) {
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < P; ++i) r_out[f * P + i] = r[i];
-    }
-  } else {
-    constexpr int order = P - 1;
-    double a[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) a[i] = 0.0;
-    a[0] = 1.0;
-    double E = r[0];
-    int st = ALZ_OK;
-#pragma unroll
-    for (int m = 1; m <= order; ++m) {
-      double num = r[m];
-#pragma unroll
-      for (int i = 1; i < m; ++i) num = num + a[i] * r[m - i];
-      if (E == 0.0) st = ALZ_E_PARCOR;               // inner(B, B) == 0, lazy_lpc.py:132-133
-      const double k = (st == ALZ_OK) ? -(num / E) : 0.0;
-#pragma unroll
-      for (int i = 1; 2 * i <= m; ++i) {
-        const double ai = a[i], aj = a[m - i];
-        a[i] = ai + k * aj;
-        if (2 * i != m) a[m - i] = aj + k * ai;
-      }
-      a[m] = k;
-      E = E * (1.0 - k * k);
-    }
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < P; ++i) coefs[f * P + i] = a[i];
-      err[f] = E;
-      status[f] = st;
-    }
-  }
-}
-
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
-template <bool LEV, bool FMA = false>
+template <int LEV, bool FMA = false>
 static acorr_stage_fn pick_acorr_stage(int P) {
   switch (P) {
     case 9: return k_acorr_stage<9, LEV, FMA>;
@@ -534,26 +392,20 @@ static acorr_stage_fn pick_acorr_stage(int P) {
   }
 }
 
-// A/B only (ALZ_LPC_PAIR=1): measured 63.5 us against 64.2 us for 65 536 frames -- two half-length waves
-// per SIMD do not help, so the lone-wave issue rate is not what bounds the kernel; 252 MB in 62 us is
-// 4.1 TB/s of 128-byte pieces at a 3840-byte stride, and more in flight only lengthens the queue
-// (profiles/NOTES_r02.md).  Kept as the record of that experiment; the one-wave form is the default.
-template <bool LEV>
-static acorr_stage_fn pick_acorr_pair(int P, int64_t n_frames) {
-  static const int pair_env = getenv("ALZ_LPC_PAIR") ? atoi(getenv("ALZ_LPC_PAIR")) : 0;
-  if (!pair_env || (n_frames + 63) / 64 > 2048) return nullptr;
+// the bit-identical one-launch form for the orders the dense Levinson-Durbin is unrolled for (alz_lev.hip has
+// the same list); other orders run the two-launch form
+static acorr_stage_fn pick_acorr_stage_dense(int P) {
   switch (P) {
-    case 9: return k_acorr_pair<9, LEV>;
-    case 11: return k_acorr_pair<11, LEV>;
-    case 13: return k_acorr_pair<13, LEV>;
-    case 17: return k_acorr_pair<17, LEV>;
+    case 9: return k_acorr_stage<9, 2>;
+    case 11: return k_acorr_stage<11, 2>;
+    case 13: return k_acorr_stage<13, 2>;
+    case 17: return k_acorr_stage<17, 2>;
     default: return nullptr;
   }
 }
 
 static bool stage_ok(const double *sig, int64_t n_frames, int frame_len, int64_t hop) {
-  static const int stage_env = getenv("ALZ_LPC_STAGE") ? atoi(getenv("ALZ_LPC_STAGE")) : 1;
-  return stage_env && n_frames >= 16384 && frame_len >= 32 && (hop % 2) == 0 && ((uintptr_t)sig & 15) == 0;
+  return n_frames >= 16384 && frame_len >= 32 && (hop % 2) == 0 && ((uintptr_t)sig & 15) == 0;
 }
 
 static acorr_lane_fn pick_acorr_lane(int P) {
@@ -616,10 +468,8 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   *rc = ALZ_OK;
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
-  if (acorr_stage_fn st_fn = stage_ok(sig, n_frames, frame_len, hop) ? pick_acorr_stage<false>(P) : nullptr) {
-    acorr_stage_fn pair_fn = pick_acorr_pair<false>(P, n_frames);
-    hipLaunchKernelGGL(pair_fn ? pair_fn : st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(pair_fn ? 128 : 64),
-                       3 * 8192, st, sig, n_frames,
+  if (acorr_stage_fn st_fn = stage_ok(sig, n_frames, frame_len, hop) ? pick_acorr_stage<0>(P) : nullptr) {
+    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, st, sig, n_frames,
                        frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
     return true;
@@ -650,8 +500,8 @@ static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_
                       hipStream_t st) {
   if (n_frames < 0 || frame_len < 1 || hop < 0 || order < 0)
     return fail(ALZ_E_ARG, "lpc: bad frame geometry");
-  if (order > 63) return fail(ALZ_E_UNSUPPORTED, "lpc: order > 63 is outside the engine's gate");
   if (n_frames == 0) return ALZ_OK;
+  if (order > 63) return fail(ALZ_E_UNSUPPORTED, "lpc: order > 63 runs the dense Levinson-Durbin only");
   const int slot = order <= 31 ? 32 : 64;
   const int fpw = 64 / slot;
   const size_t lds = (size_t)fpw * frame_len * sizeof(double);
@@ -687,13 +537,26 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
   bool done = false;
-  if ((flags & ALZ_LPC_DENSE) != 0 && n_frames > 0) {
-    // bit-exact end to end: the lags from the exact acorr kernels, then the reference's dense Levinson-Durbin
-    if (order > 63) rc = alz::fail(ALZ_E_UNSUPPORTED, "lpc: order > 63 is outside the engine's gate");
+  const bool dense = (flags & ALZ_LPC_DENSE) != 0 || order > 63;     // (orders past the register kernels: dense form only)
+  if (n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
+    // one launch: autocorrelation and Levinson-Durbin in the same lane
+    const bool fused = (flags & ALZ_LPC_FUSED) != 0;
+    alz::acorr_stage_fn fn = dense ? (fused ? nullptr : alz::pick_acorr_stage_dense(order + 1))
+                                   : (fused ? alz::pick_acorr_stage<1, true>(order + 1) : alz::pick_acorr_stage<1>(order + 1));
+    if (fn) {
+      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, (hipStream_t)stream,
+                         sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
+      if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
+      done = true;
+    }
+  }
+  if (!done && dense && n_frames > 0) {
+    // bit-exact end to end in two launches: the lags from the exact acorr kernels, then the reference's dense
+    // Levinson-Durbin (small batches, odd frame geometry, orders without an unrolled kernel)
     double *r_tmp = nullptr;
     const size_t bytes = (size_t)n_frames * (order + 1) * sizeof(double);
-    if (rc == ALZ_OK && hipMallocAsync((void **)&r_tmp, bytes, (hipStream_t)stream) != hipSuccess)
-      rc = alz::fail(ALZ_E_HIP, "lpc: scratch allocation failed");
+    if (hipMallocAsync((void **)&r_tmp, bytes, (hipStream_t)stream) != hipSuccess)
+      rc = alz::fail(ALZ_E_NOMEM, "lpc: scratch allocation failed");
     if (rc == ALZ_OK) {
       (void)alz::launch_acorr_dense(sig_dev, n_frames, frame_len, hop, order, r_tmp, (hipStream_t)stream, &rc);
       if (rc == ALZ_OK)
@@ -702,18 +565,6 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
       (void)hipFreeAsync(r_tmp, (hipStream_t)stream);
     }
     done = true;
-  }
-  if (!done && n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
-    // one launch: autocorrelation and Levinson-Durbin in the same lane
-    const bool fused = (flags & ALZ_LPC_FUSED) != 0;
-    if (alz::acorr_stage_fn fn = fused ? alz::pick_acorr_stage<true, true>(order + 1) : alz::pick_acorr_stage<true>(order + 1)) {
-      alz::acorr_stage_fn pair_fn = fused ? nullptr : alz::pick_acorr_pair<true>(order + 1, n_frames);
-      hipLaunchKernelGGL(pair_fn ? pair_fn : fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(pair_fn ? 128 : 64), 3 * 8192,
-                         (hipStream_t)stream,
-                         sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
-      if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
-      done = true;
-    }
   }
   if (!done && order <= alz::kLevMax && n_frames > 0) {
     // two passes through a stream-ordered scratch array of lags
@@ -757,7 +608,7 @@ int alz_levinson_dev_ex(const double *r_dev, int64_t n_frames, int n_lags, int o
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
-  if ((flags & ALZ_LPC_DENSE) != 0) {
+  if ((flags & ALZ_LPC_DENSE) != 0 || order > 63) {
     rc = alz::launch_levinson_dense(r_dev, n_frames, n_lags, order, coefs_dev, err_dev, status_dev, (hipStream_t)stream);
   } else if (order <= alz::kLevMax) {
     if (n_frames > 0) {

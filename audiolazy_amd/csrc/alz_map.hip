@@ -30,8 +30,11 @@ __device__ __forceinline__ double map_one(double x, double y, double p0, double 
   if constexpr (OP == ALZ_MAP_ABS) return __builtin_fabs(x);
   if constexpr (OP == ALZ_MAP_NEG) return -x;
   if constexpr (OP == ALZ_MAP_SQRT) {
-    if (x < 0.0) flag |= ALZ_MAP_DOMAIN;          // a negative float ** .5 is complex in Python 3
-    return __builtin_sqrt(x);                     // correctly rounded (OCML), == pow(v, .5) of libm on [0, inf)
+    // CPython's ``v ** .5`` is libm pow(v, .5): (-0.0) ** .5 == +0.0 and (-inf) ** .5 == +inf (C99 pow), where
+    // sqrt would give -0.0 and NaN; a negative finite item is complex in Python 3 -> flagged
+    if (x == -__builtin_inf()) return __builtin_inf();
+    if (x < 0.0) flag |= ALZ_MAP_DOMAIN;
+    return __builtin_sqrt(x + 0.0);               // correctly rounded (OCML), == pow(v, .5) of libm on [0, inf]
   }
   if constexpr (OP == ALZ_MAP_SQUARE) return x * x;
   if constexpr (OP == ALZ_MAP_MUL) return x * p0;

@@ -491,7 +491,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   // a bank steered by control streams (every series shared by the channels): the two-wave kernel
   // takes the full tiles, the lane-per-channel kernels below continue with the ragged rest
-  static const bool duo_off = getenv("ALZ_TV_DUO") && atoi(getenv("ALZ_TV_DUO")) == 0;
+  static const bool duo_off = ALZ_TUNE("ALZ_TV_DUO", 1) == 0;
   if (!duo_off && channels > 1 && nb <= 3 && na <= 3 && p.gain_mode == 0) {
     int kind[5], negated[5];
     double value[5];
@@ -537,9 +537,8 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     for (int k = 0; k < 3; ++k) pb |= (p.b.kind[k] != 0) << k;
     for (int k = 1; k < 3; ++k) pa |= (p.a.kind[k] != 0) << (k - 1);
     void (*fn)(alz::TvArgs) = alz::k_tv<3, 3, 16>;
-    static const bool old_env = getenv("ALZ_TV_OLD") != nullptr;   // A/B: the first version of the pattern kernels
 #define ALZ_TV_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) fn = old_env ? alz::k_tv<3, 3, 16, PB_, PA_> : alz::k_tvp<PB_, PA_, ALZ_TVP_B>;
+  if (pb == PB_ && pa == PA_) fn = alz::k_tvp<PB_, PA_, ALZ_TVP_B>;
     ALZ_TV_PAT(1, 1) ALZ_TV_PAT(3, 1) ALZ_TV_PAT(1, 3) ALZ_TV_PAT(3, 3) ALZ_TV_PAT(5, 3) ALZ_TV_PAT(7, 3)
     ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
 #undef ALZ_TV_PAT

@@ -705,7 +705,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   int g = 64;
   if (lanes < 64 * 256) g = 32;
   if (lanes < 48 * 256) g = 16;
-  static const int g_env = getenv("ALZ_G") ? atoi(getenv("ALZ_G")) : 0;   // tuning override
+  static const int g_env = ALZ_TUNE("ALZ_G", 0);   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
   if (sec.any_div) g = 16;      // a0 != 1 somewhere: only the two-wave kernel has the dividing form
   const bool outer = io.mode == ALZ_BANK_OUTER;
@@ -728,7 +728,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   if (groups == 0 || tiles == 0) return ALZ_OK;
   if (ch && tiles * t != ch->chunk_len) return ALZ_OK;
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
-  static const int duo_env = getenv("ALZ_DUO") ? atoi(getenv("ALZ_DUO")) : 1;
+  static const int duo_env = ALZ_TUNE("ALZ_DUO", 1);
   const bool nostore = ch && ch->nostore;
   const bool pre_abs = io.pre_op == ALZ_MAP_ABS;
   if (io.pre_op && (!pre_abs || ch || io.fused || sec.any_div)) return ALZ_OK;   // the caller maps the input first

@@ -127,11 +127,20 @@ def levinson_durbin(acdata, order=None, device=0, exact=True):
   return filt
 
 
-def _kautocor(blk, order, device=0):
+def _default_order(blk, order):
+  """``order`` defaults to ``len(blk) - 1`` (the reference's documented default, lazy_lpc.py:154-155, which is
+  what its ``acorr(blk, None)`` delivers)."""
+  return len(blk) - 1 if order is None else order
+
+
+def _kautocor(blk, order=None, device=0):
   """lpc.kautocor: autocorrelation method via Levinson-Durbin (reference
-  lazy_lpc.py:229-272).  Returns a ZFilter with ``.error``."""
+  lazy_lpc.py:229-272).  Returns a ZFilter with ``.error``.  Any order: past 63 the engine runs the
+  reference's dense Levinson-Durbin from a workspace in device memory (slow, but ``lpc(blk, order >= 100)``
+  is this route in the reference, :176-180)."""
   from .filters import ZFilter
   blk = [float(v) for v in blk]
+  order = _default_order(blk, order)
   coefs, err, status = kautocor_frames(blk, len(blk), order, device=device, exact=True)   # one block: bit-identical form
   _ffi.check(int(status[0]))
   filt = ZFilter(coefs[0].tolist())
@@ -139,11 +148,13 @@ def _kautocor(blk, order, device=0):
   return filt
 
 
-def _nautocor(blk, order, device=0):
+def _nautocor(blk, order=None, device=0):
   """lpc.nautocor: the autocorrelation normal equations solved with numpy.linalg.pinv (reference
   lazy_lpc.py:188-225).  The lags come from the GPU (bit-exact ``acorr``); the small dense solve
   is the same NumPy call the reference makes, on the host."""
   from .filters import ZFilter
+  blk = [float(v) for v in blk]
+  order = _default_order(blk, order)
   lags = np.asarray(acorr(blk, order), dtype=np.float64)
   idx = np.abs(np.subtract.outer(np.arange(order), np.arange(order)))
   normal = lags[idx] if order > 0 else np.zeros((0, 0))
@@ -154,9 +165,11 @@ def _nautocor(blk, order, device=0):
   return filt
 
 
-def _autocor(blk, order, device=0):
+def _autocor(blk, order=None, device=0):
   """lpc.autocor, the reference's default strategy (lazy_lpc.py:140-185): the pseudo-inverse form
   below order 100, Levinson-Durbin above it with the pseudo-inverse as the ParCorError fallback."""
+  blk = [float(v) for v in blk]
+  order = _default_order(blk, order)
   if order < 100:
     return _nautocor(blk, order, device=device)
   try:

@@ -51,7 +51,13 @@ def map_block(op, x, other=None, p0=0., p1=0., out=None, device=0):
         raise ValueError("torch blocks must be contiguous float64 CUDA tensors")
     if binary and tuple(other.shape) != tuple(x.shape):
       raise ValueError("blocks differ in shape")
-    res = torch.empty_like(x) if out is None else out
+    if out is None:
+      res = torch.empty_like(x)
+    else:       # the kernel writes x.numel() doubles through out.data_ptr(): it must be exactly that buffer
+      if (not getattr(out, "is_cuda", False) or out.dtype != torch.float64 or not out.is_contiguous()
+          or tuple(out.shape) != tuple(x.shape) or out.device != x.device):
+        raise ValueError("out must be a contiguous float64 CUDA tensor of the input's shape on the input's device")
+      res = out
     flags = torch.zeros((1,), dtype=torch.int32, device=x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     _ffi.check(L.alz_map_dev(code, x.data_ptr(), other.data_ptr() if binary else None, float(p0), float(p1),
@@ -65,8 +71,10 @@ def map_block(op, x, other=None, p0=0., p1=0., out=None, device=0):
     other = np.ascontiguousarray(other, dtype=np.float64)
     if other.shape != x.shape:
       raise ValueError("blocks differ in shape")
+  if out is not None and (not isinstance(out, np.ndarray) or out.shape != x.shape or out.dtype != np.float64):
+    raise ValueError("out must be a float64 ndarray of the input's shape")
   if x.size == 0:
-    return np.empty(x.shape)
+    return np.empty(x.shape) if out is None else out
   d_x = _ffi.DevBuf(x.nbytes, device).upload(x)
   d_y = _ffi.DevBuf(other.nbytes, device).upload(other) if binary else None
   d_f = _ffi.DevBuf(4, device).upload(np.zeros(1, dtype=np.int32))

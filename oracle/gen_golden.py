@@ -262,6 +262,35 @@ def lpc_cases():
   return out
 
 
+def lpc_strategy_cases():
+  """The other autocorrelation-method strategies (lazy_lpc.py:140-225): ``lpc(blk, order)`` = ``lpc.autocor``
+  (pseudo-inverse form below order 100, Levinson-Durbin from 100 up with the pseudo-inverse as ParCorError
+  fallback), ``lpc.nautocor``; ``lpc.kautocor`` and ``acorr`` past 63 lags.  Blocks are stored once."""
+  fr = noise(480, 4242)
+  res = resonator.z_exp(700 * Hz, 40 * Hz)
+  ar = list(res(noise(480 + 200, 5)))[200:]
+  silent = [0.] * 150          # kautocor raises ParCorError -> lpc.autocor falls back to the pseudo-inverse form
+  blocks = dict(noise=fr, resonant=ar, silent=silent)
+  out = dict(blocks={k: hx(v) for k, v in blocks.items()}, acorr=[], nautocor=[], autocor=[], kautocor=[])
+  for lag in (64, 80, 130):
+    out["acorr"].append(dict(blk="noise", max_lag=lag, r=hx(acorr(fr, lag))))
+  for name in ("noise", "resonant"):
+    blk = blocks[name]
+    for order in (2, 8, 16):
+      f = lpc.nautocor(blk, order)
+      out["nautocor"].append(dict(blk=name, order=order, coefs=hx(f.numlist), error=hx(f.error)))
+    for order in (16, 70, 100, 120):
+      f = lpc(blk, order)
+      out["autocor"].append(dict(blk=name, order=order, coefs=hx(f.numlist), error=hx(f.error),
+                                 route="nautocor" if order < 100 else "kautocor"))
+    for order in (40, 70, 100):
+      f = lpc.kautocor(blk, order)
+      out["kautocor"].append(dict(blk=name, order=order, coefs=hx(f.numlist), error=hx(f.error)))
+  f = lpc(silent, 100)
+  out["autocor"].append(dict(blk="silent", order=100, coefs=hx(f.numlist), error=hx(f.error), route="fallback"))
+  return out
+
+
 # --------------------------------------------------------------------------
 # 7. Stream.blocks
 # --------------------------------------------------------------------------
@@ -516,6 +545,9 @@ if __name__ == "__main__":
   if len(sys.argv) > 1 and sys.argv[1] == "--only-maps":
     dump("maps.json", maps_cases())
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-lpc-strategies":
+    dump("lpc_strategies.json", lpc_strategy_cases())
+    sys.exit(0)
   dump("filters.json", filt_cases())
   dump("lfilter_grid.json", lfilter_grid())
   dump("containers.json", container_cases())
@@ -530,3 +562,4 @@ if __name__ == "__main__":
   dump("timevar.json", timevar_cases())
   dump("timevar_algebra.json", timevar_algebra_cases())
   dump("maps.json", maps_cases())
+  dump("lpc_strategies.json", lpc_strategy_cases())

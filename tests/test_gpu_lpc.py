@@ -252,3 +252,54 @@ def test_preallocated_results(lpc):
   assert torch.equal(c0, c1) and torch.equal(e0, e1) and torch.equal(s0, s1)
   with pytest.raises(ValueError):
     lpc.kautocor_frames(sig, L, order, out=(out[0][:10], out[1], out[2]))
+
+
+def test_lpc_strategies_match_the_reference(lpc):
+  """``lpc`` (= ``lpc.autocor``), ``lpc.nautocor``, ``lpc.kautocor`` past order 63 and ``acorr`` past 63 lags against
+  tests/golden/lpc_strategies.json, generated by the reference (round-2 advisor: none of this was covered, and
+  ``lpc(blk, 100)`` raised NotImplementedError)."""
+  import audiolazy_amd as alz
+  g = load_golden("lpc_strategies.json")
+  blocks = {k: unhex(v) for k, v in g["blocks"].items()}
+  pad = lambda got, n: list(got) + [0.] * (n - len(got))
+  bits = lambda a: np.asarray(a, dtype=np.float64).view(np.uint64)
+  for case in g["acorr"]:
+    assert np.array_equal(bits(alz.acorr(blocks[case["blk"]], case["max_lag"])), bits(unhex(case["r"])))
+  for case in g["kautocor"]:
+    f = alz.lpc.kautocor(blocks[case["blk"]], case["order"])
+    ref = unhex(case["coefs"])
+    assert np.array_equal(bits(pad(f.numlist, len(ref))), bits(ref)) and f.error == unhex(case["error"])
+  for case in g["nautocor"]:
+    f = alz.lpc.nautocor(blocks[case["blk"]], case["order"])
+    ref = unhex(case["coefs"])
+    np.testing.assert_allclose(pad(f.numlist, len(ref)), ref, rtol=1e-9, atol=1e-9)
+    assert f.error == pytest.approx(unhex(case["error"]), rel=1e-9, abs=1e-9)
+  for case in g["autocor"]:
+    f = alz.lpc(blocks[case["blk"]], case["order"])
+    ref = unhex(case["coefs"])
+    if case["route"] == "kautocor":        # order >= 100: Levinson-Durbin, bit-identical
+      assert np.array_equal(bits(pad(f.numlist, len(ref))), bits(ref)) and f.error == unhex(case["error"])
+    else:                                  # pseudo-inverse form (also the ParCorError fallback of the silent block)
+      np.testing.assert_allclose(pad(f.numlist, len(ref)), ref, rtol=1e-9, atol=1e-9)
+      assert f.error == pytest.approx(unhex(case["error"]), rel=1e-9, abs=1e-9)
+  # order defaults to len(blk) - 1 (lazy_lpc.py:154-155)
+  short = blocks["noise"][:12]
+  assert alz.lpc(short).numlist == alz.lpc(short, 11).numlist
+  assert alz.lpc.kautocor(short).numlist == alz.lpc.kautocor(short, 11).numlist
+  with pytest.raises(alz.ParCorError):
+    alz.lpc.kautocor(blocks["silent"], 100)
+
+
+def test_bit_identical_batch_is_one_launch(lpc):
+  """exact=True on a large batch: the dense Levinson-Durbin runs inside k_acorr_stage (one launch) and is still
+  bit-identical to the oracle on every frame, the silent one included; batches too small for the staged kernel
+  and orders without an unrolled kernel take the two-launch form with the same doubles."""
+  from oracle import oracle
+  rng = np.random.default_rng(77)
+  for F, L, order in ((16384 + 37, 480, 16), (16384, 200, 12), (300, 480, 16), (16400, 480, 14)):
+    sig = rng.uniform(-1, 1, F * L)
+    sig[3 * L: 4 * L] = 0.0
+    c, e, st = lpc.kautocor_frames(sig, L, order, exact=True)
+    rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
+    assert np.array_equal(st, rs) and st[3] == -4
+    assert np.array_equal(c.view(np.uint64), rc.view(np.uint64)) and np.array_equal(e.view(np.uint64), re.view(np.uint64))

@@ -183,3 +183,25 @@ def test_envelope_block(alz, oracle):
   # and against the reference's own per-sample form (x ** 2 is libm pow): within a few ulp
   one = np.array(list(alz.envelope.rms(x[:, 0].tolist(), cutoff)))
   assert np.max(np.abs(rms[:, 0] - one)) / np.max(np.abs(one)) <= 1e-15
+
+
+def test_root_edges_and_out_validation():
+  """(-0.0) ** .5 == +0.0 and (-inf) ** .5 == +inf as in CPython (round-2 advisor); ``out`` is validated like the
+  inputs on the torch path and honoured on the empty NumPy path."""
+  import torch
+  from audiolazy_amd import maps as m
+  items = [0.0, -0.0, 4.0, 2.0, float("inf"), float("-inf"), 5e-324]
+  want = np.array([v ** .5 for v in items])
+  got = m.sqrt_block(np.array(items))
+  assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+  xd = torch.from_numpy(np.array(items * 40)).cuda()
+  got = m.sqrt_block(xd).cpu().numpy()
+  assert np.array_equal(got.view(np.uint64), np.tile(want, 40).view(np.uint64))
+  for bad in (torch.empty(xd.shape, dtype=torch.float32, device="cuda"), torch.empty((3,), dtype=torch.float64, device="cuda"),
+              torch.empty((2 * xd.numel(),), dtype=torch.float64, device="cuda")[::2], torch.empty(xd.shape, dtype=torch.float64)):
+    with pytest.raises(ValueError):
+      m.abs_block(xd, out=bad)
+  out = torch.empty_like(xd)
+  assert m.abs_block(xd, out=out) is out
+  empty_out = np.empty((0,))
+  assert m.abs_block(np.empty((0,)), out=empty_out) is empty_out

@@ -70,3 +70,15 @@ def test_host_running_mean_mirrors_the_reference():
     if case["fn"] == "maverage.deque":
       got = list(alz.maverage.deque(case["size"])(XS, zero=unhex(case["zero"])))
       assert same_bits(got, unhex(case["r"])), case
+
+
+def test_root_edge_items_follow_python_pow():
+  """``v ** .5`` in CPython is libm pow(v, .5): (-0.0) ** .5 is +0.0 and (-inf) ** .5 is +inf, where a
+  plain square root gives -0.0 and NaN.  The restatement follows the per-sample expression."""
+  from oracle import oracle
+  items = [0.0, -0.0, 4.0, 2.0, float("inf"), float("-inf"), float("nan"), 5e-324, 1.7976931348623157e308]
+  got = oracle.map_block("sqrt", np.array(items))
+  want = np.array([v ** .5 for v in items])
+  assert np.array_equal(got.view(np.uint64)[:6], want.view(np.uint64)[:6])
+  assert np.isnan(got[6]) and np.isnan(want[6])
+  assert np.array_equal(got.view(np.uint64)[7:], want.view(np.uint64)[7:])

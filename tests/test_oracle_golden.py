@@ -240,3 +240,44 @@ def test_pyref_source_is_the_documented_statement():
   src, names = pyref.df1_source([[.1, .2]], [1, [.3, .4]])
   assert names == ["b0", "a1"] and "m0 = next(b0) * d0 + -next(a1) * m1" in src
   assert pyref.consume_blocks(pyref.noise(10000, 1), 4096) == 10000
+
+
+def test_lpc_strategies_against_the_reference():
+  """tests/golden/lpc_strategies.json (generated by the reference): lags past 63 and Levinson-Durbin at orders
+  40 .. 120 are bit-identical in the C restatement; the pseudo-inverse strategies go through numpy.linalg.pinv
+  like the reference (LAPACK results may differ in the last bits from one CPU to another: 1e-9)."""
+  g = load_golden("lpc_strategies.json")
+  blocks = {k: unhex(v) for k, v in g["blocks"].items()}
+  for case in g["acorr"]:
+    assert same_bits(oracle.acorr(blocks[case["blk"]], case["max_lag"]), unhex(case["r"]))
+  for case in g["kautocor"] + [c for c in g["autocor"] if c["route"] == "kautocor"]:
+    x = blocks[case["blk"]]
+    coefs, err, status = oracle.kautocor_frames(x, 1, len(x), len(x), case["order"])
+    ref = np.array(unhex(case["coefs"]))
+    ref = np.concatenate([ref, np.zeros(coefs.shape[1] - len(ref))])
+    assert status[0] == 0 and same_bits(coefs[0], ref) and err[0] == unhex(case["error"])
+  for case in g["nautocor"] + [c for c in g["autocor"] if c["route"] != "kautocor"]:
+    x = blocks[case["blk"]]
+    coefs, err = oracle.nautocor(x, case["order"])
+    ref = unhex(case["coefs"])
+    ref = ref + [0.] * (len(coefs) - len(ref))             # Poly drops exact-zero top coefficients
+    np.testing.assert_allclose(coefs, ref, rtol=1e-9, atol=1e-9)
+    assert err == pytest.approx(unhex(case["error"]), rel=1e-9, abs=1e-9)
+  # the silent block: kautocor is a ParCorError (status), the fallback's coefficients are all zero
+  assert oracle.kautocor_frames(blocks["silent"], 1, 150, 150, 100)[2][0] == -4
+
+
+def test_levinson_and_kautocor_restatements_are_bit_identical():
+  """Tighter than the 1e-12 of the round-1 tests: the C restatement of the dense Levinson-Durbin reproduces the
+  reference's coefficients and error to the last bit on every golden case."""
+  for case in load_golden("lpc.json")["levinson"]:
+    coefs, err = oracle.levinson_durbin(unhex(case["ac"]), case["order"])
+    ref = np.array(unhex(case["coefs"]))
+    ref = np.concatenate([ref, np.zeros(len(coefs) - len(ref))])
+    assert same_bits(np.asarray(coefs, dtype=np.float64), ref) and err == unhex(case["error"])
+  for case in load_golden("lpc.json")["kautocor"]:
+    x = unhex(case["x"])
+    coefs, err, status = oracle.kautocor_frames(x, 1, len(x), len(x), case["order"])
+    ref = np.array(unhex(case["coefs"]))
+    ref = np.concatenate([ref, np.zeros(coefs.shape[1] - len(ref))])
+    assert status[0] == 0 and same_bits(coefs[0], ref) and err[0] == unhex(case["error"])
