@@ -279,7 +279,7 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
     boff += nb[s];
     aoff += na[s];
   }
-  h->scan.resize((size_t)n_sections);
+  h->scan.resize((size_t)n_sections + 1);   // [n_sections]: the fused time-parallel cascade's own scratch
   *out = h;
   return ALZ_OK;
 }
@@ -427,6 +427,31 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   io.fused = h->fused;
   int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
+  auto note = [&](const char *k) {
+    h->last_kernel = k;
+    if (!h->last_kernels.empty()) h->last_kernels += "+";
+    h->last_kernels += k;
+  };
+
+  // opt-in time-parallel mode, whole fused cascade at once (channel-major blocks): the chunks of the time axis
+  // become the cascade kernel's channels, read straight from the un-expanded input (alz_scan.hip)
+  if (h->time_parallel != 0 && h->n_sections >= 2 && layout == ALZ_CHAN_MAJOR && x_dev != y_dev) {
+    io.n = n;
+    io.x = x_dev; io.y = y_dev;
+    io.sxn = 1; io.sxc = ldx; io.syn = 1; io.syc = ldy;
+    io.map_input = h->mode == ALZ_BANK_OUTER;
+    io.c_first = 0; io.c_count = h->channels;
+    bool taken = false;
+    const char *name = "";
+    const int rc = alz::launch_scan_cascade(h->sec.data(), h->n_sections, io, st, h->time_parallel < 0 ? 0 : h->time_parallel,
+                                            &h->scan[(size_t)h->n_sections], &taken, &name);
+    if (rc) return rc;
+    if (taken) {
+      note(name);
+      return ALZ_OK;
+    }
+  }
+
   // An OUTER bank whose inputs are fewer than a workgroup's channels (a gammatone bank on one stream:
   // every band reads the same samples) cannot feed the streaming / pipeline kernels by input index.
   // Give it one input column (row) per channel first: one streaming pass the size of the output, after
@@ -452,12 +477,6 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   // extent of y in elements, for the out-of-place copy some sections need
   const uint64_t y_extent = layout == ALZ_TIME_MAJOR ? (uint64_t)((n - 1) * ldy + h->channels)
                                                       : (uint64_t)((h->channels - 1) * ldy + n);
-
-  auto note = [&](const char *k) {
-    h->last_kernel = k;
-    if (!h->last_kernels.empty()) h->last_kernels += "+";
-    h->last_kernels += k;
-  };
 
   // Section by section over channels [c_first, c_first + c_count) and samples
   // [t_first, t_first + t_count): the streaming kernel takes what it can (only when the range

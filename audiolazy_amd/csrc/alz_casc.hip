@@ -39,7 +39,42 @@ struct CArgs {
   const double *b[4], *a[4];
   double *xh[4], *yh[4];
   int dbg;  // ALZ_WAVE_DEBUG ablation bits (wrong output!): 1 no DMA, 2 no section arithmetic, 4 no stores
+  // time-parallel mode (alz_scan.hip, channel-major blocks only): kchunks > 0 cuts every channel's block into
+  // kchunks chunks of ldx == ldy == chunk-length samples and runs them as "virtual channels"
+  // vc = real_channel * kchunks + chunk.  A 64-channel group is then 64 consecutive chunks of ONE real channel
+  // (kchunks % 64 == 0): its rows start at real * ld?_outer + chunk * ld? and are ld? apart; coefficient set
+  // and input index follow the real channel; state lives in per-virtual-channel arrays (channels = all vc).
+  int64_t kchunks, ldx_outer, ldy_outer;
+  int nostore;   // the zero-state pass: run for the end state only
 };
+
+// where a group of 64 (virtual) channels starting at c0 finds its rows, set and input
+struct CGroup {
+  int64_t xbase, ybase;   // element offsets of the group's first row in x / y
+  int64_t creal0;         // real channel of the group's first lane
+};
+__device__ __forceinline__ CGroup c_group(const CArgs &p, int64_t c0) {
+  CGroup g;
+  const bool outer = p.mode == ALZ_BANK_OUTER;
+  if (p.kchunks > 0) {
+    const int64_t real = c0 / p.kchunks, j0 = c0 - real * p.kchunks;
+    const int64_t in = (outer && p.map_input) ? real % p.n_inputs : real;
+    g.xbase = in * p.ldx_outer + j0 * p.ldx;
+    g.ybase = real * p.ldy_outer + j0 * p.ldy;
+    g.creal0 = real;
+  } else {
+    const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
+    g.xbase = in0 * p.ldx;      // (channel-major; the time-major callers use in0 itself)
+    g.ybase = c0 * p.ldy;
+    g.creal0 = c0;
+  }
+  return g;
+}
+// coefficient set of (virtual) channel c
+__device__ __forceinline__ int64_t c_set(const CArgs &p, int64_t c) {
+  const int64_t real = p.kchunks > 0 ? c / p.kchunks : c;
+  return p.mode == ALZ_BANK_OUTER ? real / p.n_inputs : ((p.n_sets == 1) ? 0 : real);
+}
 
 __device__ __forceinline__ void c_dma16(const void *gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -298,7 +333,8 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   // OUTER: channel = set * n_inputs + input; the 64 channels of a wave share one set
   const bool outer = p.mode == ALZ_BANK_OUTER;
   const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
-  const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
+  const int64_t set = c_set(p, c);
+  const CGroup grp = c_group(p, c0);
 
   int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
   if (!CM) {
@@ -312,8 +348,8 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     // with the channel index on the GLOBAL side (the DMA lands linearly in LDS): lane (ch, k)
     // moves piece k ^ ch, so the 64 lanes that later read "their" channel hit distinct banks.
     const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
-    x_off = (in0 + ch) * p.ldx + 2 * sp;
-    y_off = (c0 + ch) * p.ldy + 2 * sp;
+    x_off = grp.xbase + ch * p.ldx + 2 * sp;
+    y_off = grp.ybase + ch * p.ldy + 2 * sp;
     x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
     x_tile = T; y_tile = T;
   }
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     }
     {
       const int64_t loads_after = (nt - 1 - i < kCRing - 1) ? (nt - 1 - i) : (kCRing - 1);
-      const int64_t stores_after = (i < kCRing - 1) ? i : (kCRing - 1);
+      const int64_t stores_after = p.nostore ? 0 : (i < kCRing - 1) ? i : (kCRing - 1);
       c_wait_vm((int)(loads_after + stores_after) * kCChunks);
     }
     char *tile = smem + slot * kCSlot + lane_off;
@@ -379,16 +415,22 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
       if constexpr (NS > 1) section_chunk<8, nb_of(PB1), PB1, PA1>(v, bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
       if constexpr (NS > 2) section_chunk<8, nb_of(PB2), PB2, PA2>(v, bc[2], na1[2], na2[2], dx[2], m1[2], m2[2]);
       if constexpr (NS > 3) section_chunk<8, nb_of(PB3), PB3, PA3>(v, bc[3], na1[3], na2[3], dx[3], m1[3], m2[3]);
+      if (!p.nostore) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) *reinterpret_cast<double *>(tile + ALZ_COFF(h * 8 + u)) = v[u];
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<double *>(tile + ALZ_COFF(h * 8 + u)) = v[u];
+      }
     }
-    double *yt = yg + i * y_tile;
-    const char *ts = smem + slot * kCSlot;
-    cdbl2 w[kCChunks];
+    if (!p.nostore) {
+      double *yt = yg + i * y_tile;
+      const char *ts = smem + slot * kCSlot;
+      cdbl2 w[kCChunks];
 #pragma unroll
-    for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ts + j * 1040 + lane * 16);
+      for (int j = 0; j < kCChunks; ++j) w[j] = *reinterpret_cast<const cdbl2 *>(ts + j * 1040 + lane * 16);
 #pragma unroll
-    for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+      for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slot is about to be refilled by DMA)
+    }
   }
 #undef ALZ_COFF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,7 +439,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   for (int s = 0; s < NS; ++s) {
 #pragma unroll
     for (int k = 0; k < 7; ++k)
-      if (k < p.nb[s] - 1) p.xh[s][(int64_t)k * p.channels + c] = dx[s][k];
+      if (k < p.nb[s] - 1 && !p.nostore) p.xh[s][(int64_t)k * p.channels + c] = dx[s][k];   // (zero-state pass: the prepared input history stays)
     if (p.na[s] > 1) p.yh[s][0 * p.channels + c] = m1[s];
     if (p.na[s] > 2) p.yh[s][1 * p.channels + c] = m2[s];
   }
@@ -506,7 +548,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const bool outer = p.mode == ALZ_BANK_OUTER;
   const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
-  const int64_t set = outer ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
+  const int64_t set = c_set(p, c);
+  const CGroup grp = c_group(p, c0);
   const int64_t nt = p.n_tiles;
   // stage w reads tile t - LAG w (and, overlapped, computes tile t - LAG w - 1) in interval t;
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
@@ -534,8 +577,8 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
     } else {
       const int ch = lane / 8, sp = (lane % 8) ^ (ch & 7);
-      x_off = (in0 + ch) * p.ldx + 2 * sp;
-      y_off = (c0 + ch) * p.ldy + 2 * sp;
+      x_off = grp.xbase + ch * p.ldx + 2 * sp;
+      y_off = grp.ybase + ch * p.ldy + 2 * sp;
       x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
       x_tile = T; y_tile = T;
     }
@@ -569,7 +612,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       PIPE_BARRIER();
       for (int64_t t = 0; t < n_iv; ++t) {
         if constexpr (DEPHASE) PIPE_BARRIER();   // (first half: stage 3 writes the tile read below)
-        if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4) && !DIRECT_OUT) {
+        if (t >= store_lag && t - store_lag < nt && !ALZ_DBG(p, 4) && !DIRECT_OUT && !p.nostore) {
           const int64_t tt = t - store_lag;
           const char *ys = yring + (int)(tt % 2) * kSlot;
           double *yt = yg + tt * y_tile;
@@ -821,7 +864,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
     } else if (DIRECT_IN && wave == 0) {
       // tile k lives in register set k % 4; interval t fetches tile t + 2 and works on tile t - 1
       // (the same schedule as the LDS path below), so three tiles of loads are in flight
-      const double *xl = CM ? p.x + (in0 + lane) * p.ldx : p.x + in0 + lane;
+      const double *xl = CM ? p.x + grp.xbase + lane * p.ldx : p.x + in0 + lane;
       double s0[16], s1[16], s2[16], s3[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) s2[u] = s3[u] = 0.0;
@@ -916,7 +959,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       for (int j = 0; j < SPW; ++j) {
 #pragma unroll
         for (int k = 0; k < 7; ++k)
-          if (k < nbv[j] - 1) xhs[j][(int64_t)k * p.channels + c] = dx[j][k];
+          if (k < nbv[j] - 1 && !p.nostore) xhs[j][(int64_t)k * p.channels + c] = dx[j][k];
         if (nav[j] > 1) yhs[j][0 * p.channels + c] = m1[j];
         if (nav[j] > 2) yhs[j][1 * p.channels + c] = m2[j];
       }
@@ -960,8 +1003,12 @@ static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
 
 // Whole cascade in one pass when its section patterns are one of the fused combinations.
 // Handles the full 16-sample tiles of the full 64-channel groups; reports what it covered.
-int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
-                   int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+// With `ch` (time-parallel mode, alz_scan.hip): channel-major blocks only; every channel's block is cut into
+// ch->n_chunks chunks of ch->chunk_len samples which run as n_chunks x channels virtual channels, each from /
+// into its own state slot of ch->vxh[s] / ch->vyh[s]; the launch then covers the whole bank or nothing.
+static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                               const CascChunks *ch, int64_t *done_samples, int64_t *done_channels,
+                               const char **kernel_name) {
   *done_samples = 0;
   *done_channels = 0;
   if (nsec < 2 || nsec > 4) return ALZ_OK;
@@ -984,9 +1031,16 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   // OUTER banks that read their input by input index: a workgroup's channels must be adjacent inputs of one band
   const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
   const int g = 64;
-  if (by_input && (io.n_inputs % g) != 0) return ALZ_OK;
-  const int64_t tiles = io.n / 16;
-  const int64_t groups = io.channels / g;
+  int64_t tiles = io.n / 16, groups = io.channels / g;
+  if (ch) {
+    // virtual channels: 64 consecutive chunks of one real channel per group
+    if (!cm || ch->n_chunks % g != 0 || ch->chunk_len % 16 != 0 || (ch->chunk_len & 1)) return ALZ_OK;
+    if (ch->n_chunks * ch->chunk_len != io.n) return ALZ_OK;
+    tiles = ch->chunk_len / 16;
+    groups = io.channels * ch->n_chunks / g;
+  } else if (by_input && (io.n_inputs % g) != 0) {
+    return ALZ_OK;
+  }
   if (groups == 0 || tiles == 0) return ALZ_OK;
   // Four sections: the wave pipeline (one section per stage wave) while there are fewer 64-channel groups than
   // SIMDs; from 1024 groups up every SIMD has a whole single-wave cascade of its own and the hand-over only
@@ -1007,9 +1061,17 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   p.c_first = 0; p.mode = io.mode; p.map_input = io.map_input; p.nsec = nsec;
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
+  p.kchunks = 0; p.ldx_outer = 0; p.ldy_outer = 0; p.nostore = 0;
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
+  }
+  if (ch) {
+    p.kchunks = ch->n_chunks; p.ldx_outer = ldx; p.ldy_outer = ldy;
+    p.ldx = p.ldy = ch->chunk_len; p.n_tiles = tiles;
+    p.channels = io.channels * ch->n_chunks;
+    p.nostore = ch->nostore ? 1 : 0;
+    for (int s = 0; s < nsec; ++s) { p.xh[s] = ch->vxh[s]; p.yh[s] = ch->vyh[s]; }
   }
   const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
   const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
@@ -1019,10 +1081,23 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)groups), dim3(pipe ? 64 * pipe_waves : 64), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
-  *done_samples = tiles * 16;
-  *done_channels = groups * g;
+  *done_samples = ch ? io.n : tiles * 16;
+  *done_channels = ch ? io.channels : groups * g;
   *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : "k_casc";
   return ALZ_OK;
+}
+
+int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                   int64_t *done_samples, int64_t *done_channels, const char **kernel_name) {
+  return launch_cascade_impl(secs, nsec, io, stream, nullptr, done_samples, done_channels, kernel_name);
+}
+
+int launch_cascade_chunks(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                          const CascChunks &ch, bool *taken, const char **kernel_name) {
+  int64_t dn = 0, dc = 0;
+  const int rc = launch_cascade_impl(secs, nsec, io, stream, &ch, &dn, &dc, kernel_name);
+  *taken = dc > 0;
+  return rc;
 }
 
 }  // namespace alz

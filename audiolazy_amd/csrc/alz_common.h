@@ -92,6 +92,16 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
 // samples / channels it covered (full 16-sample tiles of full 64-channel groups)
 int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
                    int64_t *done_samples, int64_t *done_channels, const char **kernel_name);
+// the same over n_chunks chunks of the time axis at once (time-parallel mode, channel-major blocks): per-section
+// state arrays of [taps - 1][n_chunks * io.channels], slot real_channel * n_chunks + chunk; `nostore` runs the
+// cascade for its end states only.  *taken = false: nothing launched.
+struct CascChunks {
+  int64_t n_chunks, chunk_len;
+  bool nostore;
+  double *vxh[4], *vyh[4];
+};
+int launch_cascade_chunks(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
+                          const CascChunks &ch, bool *taken, const char **kernel_name);
 // alz_comb.hip: sparse sections whose feedback delays are all long (comb filters), time-major,
 // x != y; *taken says whether the shape was this kernel's
 int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
@@ -137,6 +147,10 @@ int launch_levinson_dense(const double *r, int64_t n_frames, int n_lags, int ord
                           int *status, hipStream_t st);
 int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int64_t n_inputs, int64_t sxn, int64_t sxc,
                   int64_t sen, int64_t sec, hipStream_t stream);
+// time-parallel execution of a whole fused cascade on a channel-major block (see alz_scan.hip); *taken = false
+// when the shape is not covered (nothing written but scratch)
+int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
+                        ScanScratch *scratch, bool *taken, const char **kernel_name);
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
                 int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name);
 

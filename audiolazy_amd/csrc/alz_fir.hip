@@ -217,7 +217,8 @@ struct RingCtx {
 template <bool EDGE>
 __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, double (&dst)[kRingK]) {
   if constexpr (!EDGE) {
-    const int64_t tc = tb < 0 ? 0 : tb;
+    int64_t tc = tb < 0 ? 0 : tb;
+    if (tc > q.p->n - 1) tc = q.p->n - 1;                    // a group wholly past the block (window of the last run): never used
     const char *base = (const char *)q.p->x + tc * q.row_bytes;            // wave-uniform
     int64_t valid = (q.p->n - tc) * q.row_bytes;
     if (valid > 0x7fffffff) valid = 0x7fffffff;

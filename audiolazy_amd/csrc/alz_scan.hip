@@ -201,4 +201,234 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   return ALZ_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Time-parallel execution of a whole fused cascade (a gammatone band: four biquad-class sections).
+//
+// The reference's own filterbank shape is ONE signal through every band (lazy_auditory.py:158-218,
+// examples/gammatone_plots.py:47): 256 bands x 1 stream is 256 serial chains.  Section by section the mode
+// above costs four zero-state passes + four replays over an input that was first expanded to a column per
+// band (12 x the algorithmic traffic).  Here the cascade stays fused (alz_casc.hip) and the chunks of the
+// time axis become its channels: a channel-major block [S, N] read as [S * K, L] IS an OUTER bank on S * K
+// input rows, and its output [B, S * K, L] IS the block [B * S, N] -- no expansion, no copies.
+//
+//   prep    chunk j > 0 starts from zero outputs; section 0's input history is the block itself (exact),
+//           chunk 0 starts from the bank's state;
+//   pass 1  the fused cascade over all chunks, no stores: end states.  Chunk 0's is the true S_1;
+//   fix     per real channel, serially over the chunks: S_{j+1} = M S_j + z_j, S = the two last outputs of every
+//           section (the next section's input history is the same two numbers), M (2 nsec x 2 nsec) = the
+//           zero-input response over L steps, columns from unit states, cached per chunk length;
+//   pass 2  the fused cascade again from the true states, with stores.
+//
+// Traffic: the input is read twice (S x N doubles, tiny next to the output), the output written once:
+// 8 + 16 / B bytes per output sample against 8 + 8 / B algorithmic.
+// ---------------------------------------------------------------------------
+struct CScanArgs {
+  const double *x;
+  int64_t ldx;                 // elements between input rows (channel-major)
+  int64_t C, n_inputs, n_sets; // C = real channels of the bank
+  int mode, map_input, nsec;
+  int nb[4], na[4];
+  const double *b[4], *a[4];
+  double *xh[4], *yh[4];       // the bank's state [taps-1][C]
+  double *vxh[4], *vyh[4];     // per-chunk state [taps-1][C * K], slot real * K + chunk
+  int64_t L, K;
+  double *power;               // M[r][e] at power[(r * 8 + e) * C + c]
+};
+
+__global__ __launch_bounds__(256) void k_cscan_prep(CScanArgs p) {
+  const int64_t vc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t V = p.K * p.C;
+  if (vc >= V) return;
+  const int64_t real = vc / p.K, j = vc - real * p.K;
+  const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? real % p.n_inputs : real;
+  for (int s = 0; s < p.nsec; ++s) {
+    for (int k = 0; k < p.nb[s] - 1; ++k) {
+      double v = 0.0;
+      if (j == 0) v = p.xh[s][(int64_t)k * p.C + real];
+      else if (s == 0) v = p.x[in * p.ldx + j * p.L - 1 - k];
+      p.vxh[s][(int64_t)k * V + vc] = v;
+    }
+    for (int k = 0; k < p.na[s] - 1; ++k) p.vyh[s][(int64_t)k * V + vc] = j == 0 ? p.yh[s][(int64_t)k * p.C + real] : 0.0;
+  }
+}
+
+// column e of M: the cascade with zero input from the unit state e (state r = 2 s + k: output y_s[-1-k])
+__global__ __launch_bounds__(64) void k_cscan_power(CScanArgs p) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int ND = 2 * p.nsec;
+  if (i >= p.C * ND) return;
+  const int64_t c = i / ND;
+  const int e = (int)(i - c * ND);
+  const int64_t set = p.mode == ALZ_BANK_OUTER ? c / p.n_inputs : (p.n_sets == 1 ? 0 : c);
+  double b0[4], b1[4], b2[4], na1[4], na2[4], y1[4], y2[4];
+  for (int s = 0; s < 4; ++s) {
+    const bool on = s < p.nsec;
+    // section 0 sees a zero input: its numerator does not matter here
+    b0[s] = (on && s > 0 && p.nb[s] > 0) ? p.b[s][0 * p.n_sets + set] : 0.0;
+    b1[s] = (on && s > 0 && p.nb[s] > 1) ? p.b[s][1 * p.n_sets + set] : 0.0;
+    b2[s] = (on && s > 0 && p.nb[s] > 2) ? p.b[s][2 * p.n_sets + set] : 0.0;
+    na1[s] = (on && p.na[s] > 1) ? -p.a[s][1 * p.n_sets + set] : 0.0;
+    na2[s] = (on && p.na[s] > 2) ? -p.a[s][2 * p.n_sets + set] : 0.0;
+    y1[s] = (e == 2 * s) ? 1.0 : 0.0;
+    y2[s] = (e == 2 * s + 1) ? 1.0 : 0.0;
+  }
+  for (int64_t n = 0; n < p.L; ++n) {
+    double xin = 0.0, x1 = 0.0, x2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double o1 = y1[s], o2 = y2[s];
+      const double y = b0[s] * xin + b1[s] * x1 + b2[s] * x2 + na1[s] * o1 + na2[s] * o2;
+      y2[s] = o1;
+      y1[s] = y;
+      xin = y; x1 = o1; x2 = o2;
+    }
+  }
+  for (int s = 0; s < p.nsec; ++s) {
+    p.power[((int64_t)(2 * s) * 8 + e) * p.C + c] = y1[s];
+    p.power[((int64_t)(2 * s + 1) * 8 + e) * p.C + c] = y2[s];
+  }
+}
+
+// S_{j+1} = M S_j + z_j per real channel.  On entry vyh holds the end states of pass 1 (slot 0: the true S_1,
+// slots j > 0: z_j); on exit every slot holds its chunk's true initial state (slot 0: the bank's).
+__global__ __launch_bounds__(64) void k_cscan_fix(CScanArgs p) {
+  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.C) return;
+  const int64_t V = p.K * p.C, v0 = c * p.K;
+  const int ND = 2 * p.nsec;
+  double M[8][8], S[8], z[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) M[r][e] = (r < ND && e < ND) ? p.power[((int64_t)r * 8 + e) * p.C + c] : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int s = r >> 1, k = r & 1;
+    const bool on = r < ND && k < p.na[s] - 1;
+    S[r] = on ? p.vyh[s][(int64_t)k * V + v0] : 0.0;                       // end state of chunk 0
+    if (on) p.vyh[s][(int64_t)k * V + v0] = p.yh[s][(int64_t)k * p.C + c];  // chunk 0 replays from the bank's state
+    z[r] = (on && p.K > 1) ? p.vyh[s][(int64_t)k * V + v0 + 1] : 0.0;
+  }
+  for (int64_t j = 1; j < p.K; ++j) {
+    double zn[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                                          // next chunk's end state, ahead of the chain
+      const int s = r >> 1, k = r & 1;
+      const bool on = r < ND && k < p.na[s] - 1;
+      zn[r] = (on && j + 1 < p.K) ? p.vyh[s][(int64_t)k * V + v0 + j + 1] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int s = r >> 1, k = r & 1;
+      if (r < ND && k < p.na[s] - 1) p.vyh[s][(int64_t)k * V + v0 + j] = S[r];
+      // the next section's input history is this section's output history
+      if (r < ND && s + 1 < p.nsec && k < p.nb[s + 1] - 1) p.vxh[s + 1][(int64_t)k * V + v0 + j] = S[r];
+    }
+    double Sn[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double acc = z[r];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = __builtin_fma(M[r][e], S[e], acc);
+      Sn[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { S[r] = Sn[r]; z[r] = zn[r]; }
+  }
+}
+
+// the last chunk's end state (left by pass 2) is the bank's state after the block
+__global__ __launch_bounds__(256) void k_cscan_finish(CScanArgs p) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  const int64_t V = p.K * p.C, last = c * p.K + p.K - 1;
+  for (int s = 0; s < p.nsec; ++s) {
+    for (int k = 0; k < p.nb[s] - 1; ++k) p.xh[s][(int64_t)k * p.C + c] = p.vxh[s][(int64_t)k * V + last];
+    for (int k = 0; k < p.na[s] - 1; ++k) p.yh[s][(int64_t)k * p.C + c] = p.vyh[s][(int64_t)k * V + last];
+  }
+}
+
+int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
+                        ScanScratch *scratch, bool *taken, const char **kernel_name) {
+  *taken = false;
+  if (nsec < 2 || nsec > 4) return ALZ_OK;
+  const bool cm = io.sxn == 1 && io.syn == 1;
+  if (!cm) return ALZ_OK;
+  for (int s = 0; s < nsec; ++s) {
+    // every section keeps two outputs of state; only the first may look further back into its input
+    if (secs[s].na != 3 || secs[s].any_div || !secs[s].uniform) return ALZ_OK;
+    if (s > 0 && secs[s].nb > 3) return ALZ_OK;
+    if (secs[s].nb > 8 || secs[s].nb < 1) return ALZ_OK;
+  }
+  const int64_t C = io.channels;
+  // chunks: a multiple of 64 per real channel (a 64-lane group = 64 chunks of one channel) that divides the
+  // block into whole 16-sample tiles; by default enough of them to fill the chip (>= 1024 groups of 64)
+  int64_t K = 0;
+  if (chunk_len > 0) {
+    if (io.n % chunk_len == 0) K = io.n / chunk_len;
+  } else {
+    int64_t want = (65536 + C - 1) / C;
+    want = (want + 63) / 64 * 64;
+    for (int64_t k = want; k >= 64; k -= 64)
+      if (io.n % k == 0 && (io.n / k) % 16 == 0 && io.n / k >= 256) { K = k; break; }
+  }
+  if (K < 64 || K % 64 != 0) return ALZ_OK;
+  const int64_t L = io.n / K;
+  if (L % 16 != 0 || L < 64) return ALZ_OK;
+  const int64_t V = K * C;
+
+  // scratch: [section][x | y][2 or nb-1][V] + M
+  uint64_t need = 0;
+  for (int s = 0; s < nsec; ++s) need += (uint64_t)((secs[s].nb - 1) + (secs[s].na - 1)) * V * sizeof(double);
+  uint64_t have = scratch->v_bytes;
+  int rc = grow_scratch(&scratch->vxh, &have, need);
+  if (rc) return rc;
+  scratch->v_bytes = have;
+  uint64_t have_p = scratch->power_bytes;
+  rc = grow_scratch(&scratch->power, &have_p, (uint64_t)64 * C * sizeof(double));
+  if (rc) return rc;
+  if (have_p != scratch->power_bytes) scratch->power_len = 0;
+  scratch->power_bytes = have_p;
+
+  CScanArgs p;
+  CascChunks ch;
+  ch.n_chunks = K; ch.chunk_len = L;
+  p.x = io.x; p.ldx = io.sxc; p.C = C; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
+  p.mode = io.mode; p.map_input = io.map_input; p.nsec = nsec; p.L = L; p.K = K; p.power = scratch->power;
+  double *cur = scratch->vxh;
+  for (int s = 0; s < 4; ++s) {
+    const SectionDev &d = secs[s < nsec ? s : 0];
+    p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
+    p.vxh[s] = p.vyh[s] = nullptr;
+    if (s < nsec) {
+      p.vxh[s] = cur; cur += (int64_t)(d.nb - 1) * V;
+      p.vyh[s] = cur; cur += (int64_t)(d.na - 1) * V;
+    }
+    ch.vxh[s] = p.vxh[s]; ch.vyh[s] = p.vyh[s];
+  }
+  const char *inner = "";
+  hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
+  ch.nostore = true;
+  bool ok = false;
+  rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
+  if (rc) return rc;
+  if (!ok) return ALZ_OK;                 // (prep only touched scratch)
+  if (scratch->power_len != L || scratch->power_section != -2) {
+    hipLaunchKernelGGL(k_cscan_power, dim3((unsigned)((C * 2 * nsec + 63) / 64)), dim3(64), 0, stream, p);
+    scratch->power_len = L;
+    scratch->power_section = -2;          // (-2: this slot holds a cascade's matrix)
+  }
+  hipLaunchKernelGGL(k_cscan_fix, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, stream, p);
+  ch.nostore = false;
+  rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
+  if (rc) return rc;
+  if (!ok) return fail(ALZ_E_HIP, "time-parallel cascade: replay launch refused after the zero-state pass");
+  hipLaunchKernelGGL(k_cscan_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, p);
+  ALZ_HIP_CHECK(hipGetLastError());
+  *taken = true;
+  *kernel_name = inner[2] == 'p' ? "k_cscan(k_pipe)" : "k_cscan(k_casc)";
+  return ALZ_OK;
+}
+
 }  // namespace alz

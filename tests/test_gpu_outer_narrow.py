@@ -126,3 +126,57 @@ def test_abs_input_map_with_expanded_input(alz, oracle):
   y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
   ref = oracle.bank([1], [2], b, a, np.tile(np.abs(x).T, (C, 1)), layout="chan").T
   assert same_bits(y, ref), bank.last_kernel
+
+
+@pytest.mark.parametrize("strategy,streams,bands,n", [("slaney", 1, 256, 1 << 16), ("klapuri", 1, 64, 1 << 16),
+                                                         ("sampled", 2, 64, 1 << 15), ("slaney", 3, 128, 3 << 14)])
+def test_fused_time_parallel_cascade(alz, oracle, strategy, streams, bands, n):
+  """The reference's own filterbank shape -- few signals through every band -- in the opt-in time-parallel mode:
+  the whole four-section cascade stays fused, the chunks of the time axis are its channels (k_cscan), the input is
+  read un-expanded.  Not bit-exact by construction: <= 1e-9 normalised against the oracle (contract 1e-6); the
+  state left on the device continues the stream in the next block, in either mode."""
+  import torch
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., bands)]
+  bank = alz.gammatone_bank(fcs, streams, strategy=strategy, Hz=Hz).set_time_parallel(True)
+  bank.reset()
+  rng = np.random.default_rng(7 * bands + streams)
+  x = rng.uniform(-1, 1, (streams, n))
+  y = bank.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
+  assert "k_cscan" in bank.last_kernel, bank.last_kernel
+  x2 = rng.uniform(-1, 1, (streams, 1 << 14))
+  ref = gammatone_reference(alz, oracle, fcs, Hz, np.concatenate([x, x2], axis=1), strategy)
+  tol = 1e-9 if strategy != "sampled" else 1e-7        # (sampled: +-1e3 numerator taps with heavy cancellation, SURVEY.md 8a)
+  assert norm_err(y, ref[:, :n], 1) <= tol
+  # second block through the same mode: chunk 0 starts from the state the replay pass left
+  y2 = bank.process(torch.from_numpy(x2).cuda(), layout="chan").cpu().numpy()
+  assert "k_cscan" in bank.last_kernel, bank.last_kernel
+  assert norm_err(y2, ref[:, n:], 1) <= tol
+  # and a bit-exact continuation after switching the mode off: compare with a serial run fed the same state
+  bank.set_time_parallel(False)
+  x3 = rng.uniform(-1, 1, (streams, 1000))
+  y3 = bank.process(torch.from_numpy(x3).cuda(), layout="chan").cpu().numpy()
+  ref3 = gammatone_reference(alz, oracle, fcs, Hz, np.concatenate([x, x2, x3], axis=1), strategy)[:, n + (1 << 14):]
+  assert norm_err(y3, ref3, 1) <= tol
+
+
+def test_fused_time_parallel_cascade_explicit_chunks_and_fallback(alz, oracle):
+  """An explicit chunk length; a block the chunks do not divide falls back to the section-by-section mode."""
+  import torch
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., 64)]
+  rng = np.random.default_rng(3)
+  x = rng.uniform(-1, 1, (1, 1 << 15))
+  ref = gammatone_reference(alz, oracle, fcs, Hz, x)
+  for chunk in (128, 512):
+    bank = alz.gammatone_bank(fcs, 1, strategy="slaney", Hz=Hz).set_time_parallel(chunk)
+    bank.reset()
+    y = bank.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
+    assert "k_cscan" in bank.last_kernel, bank.last_kernel
+    assert norm_err(y, ref, 1) <= 1e-9
+  bank = alz.gammatone_bank(fcs, 1, strategy="slaney", Hz=Hz).set_time_parallel(True)
+  bank.reset()
+  xr = x[:, :30000 + 7]
+  y = bank.process(torch.from_numpy(np.ascontiguousarray(xr)).cuda(), layout="chan").cpu().numpy()
+  assert "k_cscan" not in bank.last_kernel
+  assert norm_err(y, ref[:, :xr.shape[1]], 1) <= 1e-8
