@@ -67,6 +67,9 @@ struct alz_bank {
   // process_host pipeline: copy-in / compute / copy-out streams and their hand-over events
   hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> host_events;
+  // section pipeline of narrow cascades (process_dev): one stream per section, events per (section, chunk)
+  hipStream_t sec_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> sec_events;
 };
 
 namespace {
@@ -299,6 +302,9 @@ int alz_bank_destroy(alz_bank_t *h) {
   for (hipStream_t st : h->host_streams)
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->host_events) (void)hipEventDestroy(ev);
+  for (hipStream_t st : h->sec_streams)
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : h->sec_events) (void)hipEventDestroy(ev);
   for (alz::ScanScratch &sc : h->scan) {
     if (sc.vxh) (void)hipFree(sc.vxh);
     if (sc.vyh) (void)hipFree(sc.vyh);
@@ -427,8 +433,12 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   io.fused = h->fused;
   int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
+  std::string last_noted;
   auto note = [&](const char *k) {
     h->last_kernel = k;
+    if (last_noted == k && h->last_kernels.size() > 96) return;   // (a chunked run repeats its kernels: keep the record short)
+    last_noted = k;
+    if (h->last_kernels.size() > 400) return;
     if (!h->last_kernels.empty()) h->last_kernels += "+";
     h->last_kernels += k;
   };
@@ -481,9 +491,10 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   // Section by section over channels [c_first, c_first + c_count) and samples
   // [t_first, t_first + t_count): the streaming kernel takes what it can (only when the range
   // is the whole bank), the lane-per-channel kernels finish the ragged rest.
-  auto run_sections = [&](int64_t c_first, int64_t c_count, int64_t t_first, int64_t t_count) -> int {
+  auto run_sections_on = [&](int64_t c_first, int64_t c_count, int64_t t_first, int64_t t_count, int s_lo, int s_hi,
+                             hipStream_t st) -> int {
     const bool whole = c_first == 0 && c_count == h->channels;
-    for (int s = 0; s < h->n_sections; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       const alz::SectionDev &sec = h->sec[s];
       const bool generic = !(sec.nb <= 16 && sec.na <= 9);
       io.n = t_count;
@@ -546,9 +557,68 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     }
     return ALZ_OK;
   };
+  auto run_sections = [&](int64_t c_first, int64_t c_count, int64_t t_first, int64_t t_count) -> int {
+    return run_sections_on(c_first, c_count, t_first, t_count, 0, h->n_sections, st);
+  };
+
+  // Narrow cascades: section pipeline over chunks of the time axis.  A cascade on a few hundred channels is a
+  // handful of fused-cascade workgroups on a 256-CU chip, each advancing one sample per ~60 ns (256 bands on one
+  // signal, the reference's own filterbank shape: 4 workgroups, 4.2 Gsamples/s), and run section after section
+  // it is four serial passes.  Here section s works on chunk j while section s + 1 works on chunk j - 1, each
+  // section on its own stream with the two-wave streaming kernel (16 channels per workgroup, the recurrence wave
+  // at its ~30-cycle step): the sections overlap, every sample is still produced by the same kernels in the same
+  // order -- bit-exact -- and the intermediate chunks are re-read from L2 / Infinity Cache.  The block costs
+  // (chunks + sections - 1) chunk times instead of sections x chunks.
+  auto pipelined = [&]() -> int {
+    if (h->n_sections < 2 || h->n_sections > 4 || h->time_parallel != 0 || x_dev == y_dev) return 0;
+    if (h->channels % 16 != 0 || h->channels >= ALZ_TUNE("ALZ_SECPIPE_MAX", 2048)) return 0;
+    for (int s = 0; s < h->n_sections; ++s) {
+      const alz::SectionDev &sec = h->sec[s];
+      if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform) || (sec.present_b | sec.present_a) == 0) return 0;
+    }
+    if (outer_by_input && (h->n_inputs % 16) != 0) return 0;   // (the streaming kernel reads whole 16-input groups)
+    int64_t chunk = ALZ_TUNE("ALZ_SECPIPE_CHUNK", 16384);
+    chunk = chunk / 64 * 64;
+    if (chunk < 64 || n < 4 * chunk) return 0;
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const int ns = h->n_sections;
+    for (int s = 0; s < ns; ++s)
+      if (!h->sec_streams[s] && hipStreamCreateWithFlags(&h->sec_streams[s], hipStreamNonBlocking) != hipSuccess) return 0;
+    const size_t need = (size_t)ns * n_chunks + 1;
+    while (h->sec_events.size() < need) {
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 0;
+      h->sec_events.push_back(ev);
+    }
+    auto ev_of = [&](int s, int64_t j) { return h->sec_events[(size_t)(j * ns + s)]; };
+    hipEvent_t start = h->sec_events[need - 1];
+    if (hipEventRecord(start, st) != hipSuccess) return -1000;         // everything queued on `st` so far (input map, expansion)
+    for (int s = 0; s < ns; ++s)
+      if (hipStreamWaitEvent(h->sec_streams[s], start, 0) != hipSuccess) return -1000;
+    for (int64_t j = 0; j < n_chunks; ++j) {
+      const int64_t t0 = j * chunk, tn = (t0 + chunk <= n) ? chunk : n - t0;
+      for (int s = 0; s < ns; ++s) {
+        hipStream_t ss = h->sec_streams[s];
+        if (s > 0 && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return -1000;
+        const int rc = run_sections_on(0, h->channels, t0, tn, s, s + 1, ss);
+        if (rc) return rc;
+        if (hipEventRecord(ev_of(s, j), ss) != hipSuccess) return -1000;
+      }
+    }
+    // the caller's stream continues after the last section's last chunk (which is ordered after everything else
+    // on its stream; earlier sections finished before it could start)
+    if (hipStreamWaitEvent(st, ev_of(ns - 1, n_chunks - 1), 0) != hipSuccess) return -1000;
+    h->last_kernels += "  [section pipeline: " + std::to_string(ns) + " streams x " + std::to_string(n_chunks) + " chunks]";
+    return 1;
+  };
 
   // fused cascade: all sections in one pass over the full tiles of the full channel groups;
   // the ragged remainder (and every other cascade) goes section by section
+  {
+    const int took = pipelined();
+    if (took < 0) return took == -1000 ? fail(ALZ_E_HIP, "section pipeline: stream / event call failed") : took;
+    if (took > 0) return ALZ_OK;
+  }
   int64_t fused_n = 0, fused_c = 0;
   if (h->n_sections >= 2 && x_dev != y_dev && h->time_parallel == 0) {
     io.n = n;

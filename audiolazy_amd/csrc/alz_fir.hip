@@ -190,11 +190,22 @@ typedef const double __attribute__((address_space(4))) *const_taps_t;
 #ifndef ALZ_FIR_MG
 #define ALZ_FIR_MG 4      // products formed per group in the bit-exact instantiation (4 or 2)
 #endif
+// taps per block (= rows per ring group) and the number of groups fetched AHEAD of the block that uses them:
+// a block is K * R multiply-adds long, so the rows of block kb + PF * K have PF blocks of arithmetic to arrive
+// in.  K = 8 / PF = 1 (rounds 1 - 2) left one 384-instruction block (~0.7 us per wave) -- less than a loaded
+// HBM round trip; K = 4 / PF = 3 keeps the same 64 window rows in registers and fetches 576 instructions ahead.
+#ifndef ALZ_FIR_RING_K
+#define ALZ_FIR_RING_K 4
+#endif
+#ifndef ALZ_FIR_RING_PF
+#define ALZ_FIR_RING_PF 3
+#endif
 static constexpr int kRingR = ALZ_FIR_RING_R;
-static constexpr int kRingTB = 8 * kRingR;   // output rows per wave
-static constexpr int kRingK = kFirSK;
-static constexpr int kRingG = kRingR / kRingK + 2;
-static_assert(kRingR % kRingK == 0, "ring groups");
+static constexpr int kRingTB = 8 * kRingR;   // output rows per wave (blocked mapping)
+static constexpr int kRingK = ALZ_FIR_RING_K;
+static constexpr int kRingPF = ALZ_FIR_RING_PF;
+static constexpr int kRingG = kRingR / kRingK + 1 + kRingPF;   // window groups + groups in flight
+static_assert(kRingR % kRingK == 0 && kRingK <= 8 && kRingPF >= 1, "ring groups");
 
 __device__ __forceinline__ bool tap_absent(double t) {
   long long sh;
@@ -255,7 +266,7 @@ __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, do
 }
 
 // one tap block (taps kb .. kb + K - 1) at ring phase PH: window row j lives in group
-// (j / K - PH) mod NG; group NG - 1 - PH is free and takes the next block's rows
+// (j / K - PH) mod NG; group (-PF - PH) mod NG is free and takes the first rows of block kb + PF * K
 __device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double (&tap)[kRingK]) {
   const int nb = q.p->nb;
 #pragma unroll
@@ -270,7 +281,8 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
                                           double (&acc)[kRingR], const double (&tap)[kRingK],
                                           double (&tap_next)[kRingK]) {
   constexpr int R = kRingR, K = kRingK, NG = kRingG;
-  ring_load_group<EDGE>(q, t0 - (kb + K) - (K - 1), xr[NG - 1 - PH]);   // unused after the last block
+  constexpr int PF = kRingPF;
+  ring_load_group<EDGE>(q, t0 - (kb + PF * K) - (K - 1), xr[(4 * NG - PF - PH) % NG]);   // unused after the last blocks
   ring_load_taps(q, kb + K, tap_next);                            // likewise (all 0.0 past the end)
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) {
@@ -348,11 +360,13 @@ __device__ __forceinline__ void ring_run(const FArgs &p, const RingCtx &q, int64
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = -0.0;
   double xr[NG][K];
+  // logical group g holds rows t0 - (K - 1) + g K ..: g = 0 .. R / K are the window of block 0, g = -1 .. -(PF - 1)
+  // the first rows of blocks 1 .. PF - 1 (already in flight); logical g lives in physical (g + NG) % NG at phase 0
 #pragma unroll
-  for (int g = NG - 2; g >= 0; --g)                          // groups 0 .. NG - 2: rows t0 - (K - 1) .. t0 + R - 1 (+ 1 unused)
-    ring_load_group<EDGE>(q, t0 - (K - 1) + g * K, xr[g]);
+  for (int g = R / K; g >= -(kRingPF - 1); --g)
+    ring_load_group<EDGE>(q, t0 - (K - 1) + (int64_t)g * K, xr[(g + NG) % NG]);
 #pragma unroll
-  for (int j = 0; j < K; ++j) xr[NG - 1][j] = 0.0;
+  for (int j = 0; j < K; ++j) xr[(NG - kRingPF) % NG][j] = 0.0;   // (the slot the first step loads into)
   int kb = 0;
   bool done = false;
   double tap_a[K], tap_b[K];
@@ -389,9 +403,9 @@ void k_fir_ring(FArgs p) {
   q.row_bytes = p.sxn * 8;
   q.taps = (const_taps_t)(uintptr_t)p.b;
   const double a0 = p.a[0];
-  // the lowest row a run starting at t0 reads is t0 - (nb_padded + K) - (K - 1) (the prefetch of the block
-  // after the last one): runs that start past that are interior
-  const int64_t reach = (int64_t)((p.nb + K - 1) / K) * K + 2 * K;
+  // the lowest row a run starting at t0 reads is t0 - (nb_padded - K + PF K) - (K - 1) (the prefetch issued by
+  // the last block): runs that start past that are interior
+  const int64_t reach = (int64_t)((p.nb + K - 1) / K) * K + (kRingPF + 1) * K;
   int64_t run = (int64_t)blockIdx.y * p.run_first_mul;
   for (int64_t s = 0; s < p.run_count; ++s, run += p.run_stride) {
     const int64_t t0 = run * R;
@@ -551,7 +565,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     hipLaunchKernelGGL(k_fir_cm, dim3((unsigned)io.c_count, gyc), dim3(64), lds, stream, p);
   } else if (sec.shared_sets && io.n_inputs * 8 < ((int64_t)1 << 31) && io.channels * 8 < ((int64_t)1 << 31) &&
              io.sxn * 8 * kRingK < ((int64_t)1 << 31) &&
-             (int64_t)(sec.nb + 4 * kRingK + kRingTB) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge tiles: 32-bit row offsets
+             (int64_t)(sec.nb + (kRingPF + 3) * kRingK + 2 * kRingR) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge runs: 32-bit row offsets
              (int64_t)(sec.nb - 1) * io.channels * 8 < ((int64_t)1 << 31)) {
     // Run-to-wave mapping.  A run (kRingR output rows of 64 channels) reads a window of kRingR + nb - 1 input rows,
     // so neighbouring runs share most of their input.  Interleaved (default): the grid is just large enough to

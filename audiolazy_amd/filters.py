@@ -143,17 +143,80 @@ class LinearFilter(object):
     """
     if any(k < 0 for k, _ in self.numpoly.terms()) or any(k < 0 for k, _ in self.denpoly.terms()):
       raise ValueError("Non-causal filter")
-    from . import timevar
-    if any(timevar.is_series(v) for _, v in self.numpoly.terms()) or \
-       any(timevar.is_series(v) for _, v in self.denpoly.terms()):
-      from .stream import Stream   # Stream coefficients: the time-varying kernel (reference :197-224)
-      return Stream(timevar.run(self.numlist, self.denlist, seq, memory=memory, zero=zero))
-    if self.denpoly[0] == 0:
+    from . import generic, timevar
+    from .stream import Stream
+    numlist, denlist = self.numlist, self.denlist
+    series = any(timevar.is_series(v) for v in numlist) or any(timevar.is_series(v) for v in denlist)
+    if not series and self.denpoly[0] == 0:
       raise ZeroDivisionError("Invalid filter gain")
+    # The accept gate: the engine computes in float64 on real scalars and rows of them.  What it
+    # cannot represent -- an all-integer configuration (ints stay ints, reference :735-742), complex / matrix /
+    # symbolic coefficients or items -- runs on the per-sample path with the reference's semantics.
+    if not generic.coefficients_fit_engine(numlist, denlist) or \
+       generic.all_int_configuration(numlist, denlist, memory, zero) or not _zero_fits_engine(zero):
+      return Stream(generic.df1(numlist, denlist, seq, memory=memory, zero=zero))
+    if series:
+      # Stream coefficients: the time-varying kernel (reference :197-224) when every value is a real number
+      return Stream(_gated(lambda s, cs: timevar.run(cs[0], cs[1], s, memory=memory, zero=zero),
+                           lambda s, cs: generic.df1(cs[0], cs[1], s, memory=memory, zero=zero), seq, numlist, denlist))
     from .bank import call_sections
     # (items that are rows of C values are C parallel streams through the same filter -- the
     # reference's vector-valued idiom; call_sections looks at the first item when it is pulled)
-    return call_sections([(self.numlist or [0.], self.denlist)], seq, memory=memory, zero=zero)
+    sections = [(numlist or [0.], denlist)]
+    return Stream(_gated(lambda s, cs: call_sections(sections, s, memory=memory, zero=zero),
+                         lambda s, cs: generic.df1(numlist, denlist, s, memory=memory, zero=zero), seq, numlist, denlist))
+
+
+def _members_fit_engine(members, args, kwargs):
+  """Every member an LTI LinearFilter whose call would pass the engine's coefficient / zero / memory gate."""
+  from . import generic
+  memory = args[1] if len(args) > 1 else kwargs.get("memory")
+  zero = args[2] if len(args) > 2 else kwargs.get("zero", 0.)
+  if not generic.is_engine_item(zero):
+    return False
+  for f in members:
+    if not (isinstance(f, LinearFilter) and f.is_lti()):
+      return False
+    if not generic.coefficients_fit_engine(f.numlist, f.denlist) or \
+       generic.all_int_configuration(f.numlist, f.denlist, memory, zero):
+      return False
+  return True
+
+
+def _zero_fits_engine(zero):
+  from . import generic
+  return generic.is_engine_item(zero)
+
+
+def _gated(engine, fallback, seq, numlist, denlist):
+  """Generator behind a filter call: nothing is pulled until the result is iterated (like the reference's
+  generator); then the FIRST input item and the first value of every coefficient series decide between the
+  GPU engine (real scalars / rows of them) and the per-sample path (everything else).  The peeked values are
+  chained back in front of their iterators."""
+  import itertools
+  from . import generic
+  it = iter(seq)
+  for first in it:
+    break
+  else:
+    return
+  fits = generic.is_engine_item(first)
+  sides = []
+  for coefs in (numlist, denlist):
+    out = []
+    for c in coefs:
+      if generic.is_series(c):
+        ci = iter(c)
+        for head in ci:
+          fits = fits and generic.is_engine_item(head)
+          c = itertools.chain([head], ci)
+          break
+        else:
+          c = iter(())
+      out.append(c)
+    sides.append(out)
+  for item in (engine if fits else fallback)(itertools.chain([first], it), sides):
+    yield item
 
 
 class ZFilter(LinearFilter):
@@ -341,9 +404,15 @@ class CascadeFilter(FilterList):
   def __call__(self, *args, **kwargs):
     seq = args[0]
     members = self.callables
-    if members and all(isinstance(f, LinearFilter) and f.is_lti() for f in members):
+    def one_by_one(data, _coefs=None):
+      for f in members:
+        data = f(data, *args[1:], **kwargs)
+      return data
+    if members and _members_fit_engine(members, args, kwargs):
       from .bank import call_sections, sections_of
-      return call_sections(sections_of(members), seq, *args[1:], **kwargs)
+      from .stream import Stream
+      # one fused engine call for items the engine takes; anything else goes through the members' own gates
+      return Stream(_gated(lambda s, cs: call_sections(sections_of(members), s, *args[1:], **kwargs), one_by_one, seq, [], []))
     data = seq
     for f in members:
       data = f(data, *args[1:], **kwargs)
@@ -390,20 +459,24 @@ class ParallelFilter(FilterList):
     if len(members) == 0:
       zero = kwargs.get("zero", 0.)
       return Stream(zero for _ in seq)
-    if all(isinstance(f, LinearFilter) and f.is_lti() for f in members) and len(args) == 1 \
-       and set(kwargs) <= {"memory", "zero", "block"}:
-      try:
-        return self._call_bank(seq, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block"))
-      except NotImplementedError:   # coefficients outside the engine's gate
-        pass
     import itertools
-    copies = itertools.tee(seq, len(members))
-    total = None
-    for f, src in zip(members, copies):
-      out = f(src, *args[1:], **kwargs)
-      out = out if isinstance(out, Stream) else Stream(out)
-      total = out if total is None else total + out
-    return total
+
+    def one_by_one(src, _coefs=None):
+      copies = itertools.tee(src, len(members))
+      total = None
+      for f, part in zip(members, copies):
+        out = f(part, *args[1:], **kwargs)
+        out = out if isinstance(out, Stream) else Stream(out)
+        total = out if total is None else total + out
+      return total
+    if _members_fit_engine(members, args, kwargs) and len(args) == 1 and set(kwargs) <= {"memory", "zero", "block"}:
+      def bank(src, _coefs=None):
+        try:
+          return self._call_bank(src, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block"))
+        except NotImplementedError:   # coefficients outside the engine's gate
+          return one_by_one(src)
+      return Stream(_gated(bank, one_by_one, seq, [], []))
+    return one_by_one(seq)
 
   @property
   def numpoly(self):

@@ -21,6 +21,7 @@ Reference entry points exercised (paths relative to /root/reference/):
   audiolazy/lazy_wav.py:31-130        WavStream
   audiolazy/lazy_io.py:44-94          chunks.struct
 """
+import itertools
 import json
 import os
 import random
@@ -291,6 +292,44 @@ def lpc_strategy_cases():
   return out
 
 
+def generic_item_cases():
+  """Items the float64 engine does not take, through the reference's type-generic generator
+  (lazy_filters.py:141-264): all-integer calls keep ints (doctest :735-742), complex numbers, Fractions,
+  NumPy matrices with matrix-valued coefficient Streams (tests/test_filters_extdep.py:49-89).  Results are
+  stored as ``repr`` strings: exact for every type involved."""
+  from fractions import Fraction
+  from math import pi, cos, sqrt
+  from audiolazy import cycle, count
+  out = []
+
+  def add(tag, result):
+    items = list(result)
+    out.append(dict(tag=tag, types=[type(v).__name__ for v in items],
+                    reprs=[repr(v.tolist()) if hasattr(v, "tolist") else repr(v) for v in items]))
+  filt = ZFilter([1, 1], [1, -1])
+  add("int_doctest", filt([1, 5, -4, -7, 9], memory=[3], zero=0))
+  add("int_doctest_delayed", (filt * z ** -1)([4, 10, 11, 0, 2], zero=0))
+  add("int_default_zero_is_float", filt([1, 5, -4, -7, 9]))
+  add("int_gain_only", ZFilter([3])([1, 2, -5]))
+  add("int_then_float_items", ZFilter([3, 1])([1, 2.5, 2, 7], zero=0))
+  add("int_division_by_gain", ZFilter([1, 1], [2, -1])([1, 5, -4, -7, 9], zero=0))
+  add("int_negative_gain", ZFilter([2, 1], [-1, 3])([1, 5, -4], zero=0))
+  add("complex_items", (1 - z ** -1)([1j, 2, 3 + 1j, -1.5j]))
+  add("complex_coefficients", ZFilter([1, .5j], [1, -.25 + .1j])([1j, 2, 3 + 1j, -1.5j, 0, 1]))
+  add("fraction_items", ZFilter([1, 2], [1, -1])([Fraction(1, 3), Fraction(2, 7), Fraction(-5, 2)], zero=0))
+  add("complex_series", (Stream(itertools.cycle([1j, 2.])) + z ** -1)([1., 2., 3., 4.]))
+  # the matrix case of tests/test_filters_extdep.py:49-89 (numpy.matrix: numpy.mat is gone from NumPy 2)
+  mat = np.matrix
+  m, n1, n2 = mat([[1, 2], [2, 2]]), mat([[1.2, 3.2], [1.2, 1.1]]), mat([[-1, 2], [-1, 2]])
+  a = mat([[.3, .4], [.5, .6]])
+  filt = (repeat(m) + cycle([n1, n2]) * z ** -1) / (1 - repeat(a) * z ** -1)
+  data = [Stream(1, 2), count(), count(start=1, step=2), cycle([.2, .33, .77, pi, cos(3)]), repeat(pi),
+          count(start=sqrt(2), step=pi / 3)]
+  sig = Stream(mat(vect).reshape(2, 3) for vect in zip(*data))
+  add("matrix_items_matrix_series", filt(sig, zero=mat([[0, 0, 0], [0, 0, 0]])).limit(12))
+  return out
+
+
 # --------------------------------------------------------------------------
 # 7. Stream.blocks
 # --------------------------------------------------------------------------
@@ -544,6 +583,9 @@ if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-maps":
     dump("maps.json", maps_cases())
+    sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-generic":
+    dump("generic_items.json", generic_item_cases())
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-lpc-strategies":
     dump("lpc_strategies.json", lpc_strategy_cases())

@@ -1,0 +1,101 @@
+"""Items the float64 engine does not take -- all-integer calls, complex numbers, Fractions, NumPy matrices with
+matrix-valued coefficient Streams -- run on audiolazy_amd/generic.py, the product's own per-sample path with the
+reference's semantics (SURVEY.md 8b accept gate: "else fall back to a per-sample Python generator").  Golden
+values: tests/golden/generic_items.json, produced by the reference itself (oracle/gen_golden.py, ``repr`` strings).
+No GPU involved: these calls never reach the engine."""
+import itertools
+from fractions import Fraction
+from math import cos, pi, sqrt
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+pytestmark = pytest.mark.filterwarnings("ignore::PendingDeprecationWarning")
+
+
+def golden():
+  return {c["tag"]: c for c in load_golden("generic_items.json")}
+
+
+def check(tag, result):
+  want = golden()[tag]
+  items = list(result)
+  assert [type(v).__name__ for v in items] == want["types"], tag
+  assert [repr(v.tolist()) if hasattr(v, "tolist") else repr(v) for v in items] == want["reprs"], tag
+
+
+def test_all_integer_calls_keep_integers():
+  from audiolazy_amd import ZFilter, z
+  filt = ZFilter([1, 1], [1, -1])
+  check("int_doctest", filt([1, 5, -4, -7, 9], memory=[3], zero=0))                 # lazy_filters.py:735-742
+  check("int_doctest_delayed", (filt * z ** -1)([4, 10, 11, 0, 2], zero=0))
+  check("int_gain_only", ZFilter([3])([1, 2, -5]))                                   # ``zero`` is never read
+  check("int_then_float_items", ZFilter([3, 1])([1, 2.5, 2, 7], zero=0))
+  check("int_division_by_gain", ZFilter([1, 1], [2, -1])([1, 5, -4, -7, 9], zero=0))
+  check("int_negative_gain", ZFilter([2, 1], [-1, 3])([1, 5, -4], zero=0))
+  check("fraction_items", ZFilter([1, 2], [1, -1])([Fraction(1, 3), Fraction(2, 7), Fraction(-5, 2)], zero=0))
+
+
+def test_complex_items_and_coefficients():
+  from audiolazy_amd import Stream, ZFilter, z
+  check("complex_items", (1 - z ** -1)([1j, 2, 3 + 1j, -1.5j]))
+  check("complex_coefficients", ZFilter([1, .5j], [1, -.25 + .1j])([1j, 2, 3 + 1j, -1.5j, 0, 1]))
+  check("complex_series", (Stream(itertools.cycle([1j, 2.])) + z ** -1)([1., 2., 3., 4.]))
+
+
+def test_matrix_items_with_matrix_coefficient_streams():
+  """tests/test_filters_extdep.py:49-89 of the reference: 2x2 matrix coefficient Streams on a 2x3 matrix signal."""
+  from audiolazy_amd import Stream, z
+  mat = np.matrix
+  rep = lambda v: Stream(itertools.repeat(v))
+  m, n1, n2 = mat([[1, 2], [2, 2]]), mat([[1.2, 3.2], [1.2, 1.1]]), mat([[-1, 2], [-1, 2]])
+  a = mat([[.3, .4], [.5, .6]])
+  filt = (rep(m) + Stream(itertools.cycle([n1, n2])) * z ** -1) / (1 - rep(a) * z ** -1)
+  data = [itertools.cycle([1, 2]), itertools.count(), itertools.count(1, 2), itertools.cycle([.2, .33, .77, pi, cos(3)]),
+          itertools.repeat(pi), (sqrt(2) + k * (pi / 3) for k in itertools.count())]
+  sig = (mat(vect).reshape(2, 3) for vect in zip(*data))
+  res = filt(sig, zero=mat([[0, 0, 0], [0, 0, 0]]))
+  want = golden()["matrix_items_matrix_series"]
+  got = list(itertools.islice(res, 12))
+  assert all(type(v).__name__ == "matrix" for v in got)
+  for v, r in zip(got, want["reprs"]):
+    # (count(start=sqrt(2), step=pi/3) accumulates in the reference; the closed form above may differ in the last bits)
+    np.testing.assert_allclose(np.asarray(v), np.asarray(eval(r)), rtol=1e-13)
+  # the reference's own check of this case: y = m x + n x' + a y'
+  xs = list(itertools.islice((mat(vect).reshape(2, 3) for vect in zip(
+      itertools.cycle([1, 2]), itertools.count(), itertools.count(1, 2), itertools.cycle([.2, .33, .77, pi, cos(3)]),
+      itertools.repeat(pi), (sqrt(2) + k * (pi / 3) for k in itertools.count()))), 12))
+  old_x = old_y = mat(np.zeros((2, 3)))
+  for k, (x, y) in enumerate(zip(xs, got)):
+    exp = m * x + (n1 if k % 2 == 0 else n2) * old_x + a * old_y
+    np.testing.assert_allclose(np.asarray(y), np.asarray(exp), rtol=1e-12)
+    old_x, old_y = x, exp
+
+
+def test_the_gate_itself():
+  from audiolazy_amd import generic
+  assert generic.all_int_configuration([1, 1], [1, -1], [3], 0)
+  assert not generic.all_int_configuration([1, 1], [1, -1], None, 0.)        # zero is read (delay tap, memory fill)
+  assert generic.all_int_configuration([3], [1], None, 0.)                    # ... and here it is not
+  assert generic.all_int_configuration([0.0, 1, 1], [1, -1], None, 0)         # the dense lists pad with 0.0
+  assert not generic.all_int_configuration([1., 1], [1, -1], None, 0)
+  assert not generic.all_int_configuration([1, 1], [1, -1], [3.5], 0)
+  assert generic.coefficients_fit_engine([1, 2.5, np.float64(3)], [1]) and not generic.coefficients_fit_engine([1j], [1])
+  assert generic.is_engine_item(1) and generic.is_engine_item(2.5) and generic.is_engine_item(np.zeros(4))
+  assert generic.is_engine_item([1., 2.]) and not generic.is_engine_item(1j) and not generic.is_engine_item(np.matrix([[1.]]))
+  assert not generic.is_engine_item(Fraction(1, 2)) and not generic.is_engine_item(np.zeros((2, 2)))
+  assert generic.initial_memory([.7], 2, 0.) == [0., .7]                      # LEFT-padded (lazy_filters.py:193-195)
+  assert generic.initial_memory(lambda n: range(n), 3, 0.) == [0, 1, 2] and generic.initial_memory(None, 2, 5) == [5, 5]
+  with pytest.raises(ZeroDivisionError):
+    list(generic.df1([1], [0, 1], [1, 2]))
+  assert list(generic.df1([0], [1], [1, 2, 3], zero=7)) == [7, 7, 7]           # no terms: ``zero`` per item (:227-231)
+
+
+def test_product_never_imports_the_oracle():
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  src = open(os.path.join(root, "audiolazy_amd", "generic.py")).read()
+  assert "import oracle" not in src and "from oracle" not in src and "/root/reference" not in src

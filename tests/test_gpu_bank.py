@@ -299,16 +299,15 @@ def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
   assert same_bits(bank.process(x2c, layout="chan"), whole[N:N + 40].T)
 
 
-@pytest.mark.parametrize("switch,name", [(None, "k_fir_ring"), ("ALZ_FIR_S", "k_fir_s"),
-                                         ("ALZ_FIR_OLD", "k_fir<shared>")])
 @pytest.mark.parametrize("nb,N,gain", [(20, 5, 1.0), (17, 77, 1.0), (64, 300, 2.0), (255, 1000, 1.0),
-                                       (256, 40, -1.0), (100, 2100, 0.5)])
-def test_fir_shared_taps_kernels_shapes(alz, oracle, monkeypatch, switch, name, nb, N, gain):
-  """The three shared-tap kernels (ring of row groups / prefetching / first version) on tap counts
-  that are not a multiple of the tap block, blocks shorter than a row group, zero taps (+0 and -0:
-  absent from the sum, an inf must not get through them) and a gain."""
-  if switch:
-    monkeypatch.setenv(switch, "1")
+                                       (256, 40, -1.0), (100, 2100, 0.5), (256, 4099, 1.0), (9, 1537, 1.0)])
+def test_fir_shared_taps_kernels_shapes(alz, oracle, nb, N, gain):
+  """The shared-tap ring kernel (edge runs that reach into the delay line, interior runs, the interleaved
+  run-to-wave mapping) on tap counts that are not a multiple of the tap block, blocks shorter than a row
+  group and blocks that end inside a run, zero taps (+0 and -0: absent from the sum, an inf must not get
+  through them) and a gain.  (The round-1 variants k_fir_s / k_fir<shared> are no longer selectable at run
+  time: the shipped library has no tuning switches.)"""
+  name = "k_fir_ring"
   rng = np.random.default_rng(nb * 7 + N)
   C = 70
   taps = rng.uniform(-1, 1, nb)

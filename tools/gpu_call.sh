@@ -2,7 +2,8 @@
 # One parameterised GPU-box call (replaces round 2's 40 one-off gpu_call_*.sh):
 #   gpurun --timeout T -- 'tools/gpu_call.sh <tag> <step> [<step> ...]'
 # Every step writes under gpurun_out/<tag>/.  Steps:
-#   tests            the whole -m gpu suite
+#   tests[:ARGS]     the -m gpu suite (ARGS: extra pytest arguments, e.g. -k+fir)
+#   sh:SCRIPT        bash tools/SCRIPT
 #   bench[:ARGS]     python bench.py ARGS           (':' separates, '+' stands for a blank)
 #   tune:ENV:ARGS    the same through the -DALZ_TUNING library (tools/variants/libalzhip_tuning.so) with ENV set
 #   py:SCRIPT[:ENV]  python tools/SCRIPT
@@ -20,7 +21,8 @@ for step in "$@"; do
   a=${a//+/ }; b=${b//+/ }
   cd $R
   case $kind in
-    tests) timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q -x $a > $O/pytest_gpu_$i.log 2>&1; tail -4 $O/pytest_gpu_$i.log ;;
+    sh)    timeout 600 bash tools/$a > $O/sh_$i.log 2>&1; echo "sh [$a] rc=$?"; tail -30 $O/sh_$i.log ;;
     bench) timeout 900 python bench.py $a > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench [$a] rc=$?"; python tools/show_line.py $O/bench_$i.json ;;
     tune)  env $a ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 900 python bench.py $b > $O/tune_$i.json 2> $O/tune_$i.err
            echo "tune [$a] [$b] rc=$?"; python tools/show_line.py $O/tune_$i.json ;;
