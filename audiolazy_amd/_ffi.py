@@ -64,6 +64,11 @@ SIGNATURES = {
   "alz_mix_tracks_dev": (_int, [_int, _vp, _vp, _vp, ctypes.c_double, _i64, _vp, _int, _vp]),
   "alz_pcm_decode_dev": (_int, [_vp, _int, _int, _i64, _vp, _int, _vp]),
   "alz_pcm_encode_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp]),
+  "alz_comm_unique_id": (_int, [_vp]),
+  "alz_comm_create": (_int, [_int, _int, _int, _vp, ctypes.POINTER(_vp)]),
+  "alz_comm_destroy": (_int, [_vp]),
+  "alz_comm_gather": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+  "alz_comm_sum": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
   "alz_tv_process_dev": (_int, [_int, _vp, _int, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp,
                                 ctypes.c_double, _int, _vp]),
 }

@@ -587,7 +587,10 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     const size_t need = (size_t)ns * n_chunks + 1;
     while (h->sec_events.size() < need) {
       hipEvent_t ev;
-      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return 0;
+      // (device-scope release: the waiting streams are on this device; a system-scope release per chunk would
+      // flush more than the hand-over needs)
+      if (hipEventCreateWithFlags(&ev, ALZ_TUNE("ALZ_SECPIPE_EVFLAGS", (int)(hipEventDisableTiming | hipEventReleaseToDevice))) != hipSuccess)
+        return 0;
       h->sec_events.push_back(ev);
     }
     auto ev_of = [&](int s, int64_t j) { return h->sec_events[(size_t)(j * ns + s)]; };
@@ -599,7 +602,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       const int64_t t0 = j * chunk, tn = (t0 + chunk <= n) ? chunk : n - t0;
       for (int s = 0; s < ns; ++s) {
         hipStream_t ss = h->sec_streams[s];
-        if (s > 0 && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return -1000;
+        if (s > 0 && !ALZ_TUNE("ALZ_SECPIPE_NOWAIT", 0) && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return -1000;
         const int rc = run_sections_on(0, h->channels, t0, tn, s, s + 1, ss);
         if (rc) return rc;
         if (hipEventRecord(ev_of(s, j), ss) != hipSuccess) return -1000;

@@ -101,3 +101,73 @@ def mixdown(y_local, group=None, dst=None, force=False):
     return out
   dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM, group=group)
   return out if dist.get_rank(group) == dst else None
+
+
+class DirectComm(object):
+  """The same single collective through the C ABI's own RCCL binding (include/alz.h: alz_comm_*) -- for callers
+  that drive the engine without torch.distributed.  One process per GPU; rank 0 makes the 128-byte id
+  (``DirectComm.unique_id()``) and hands it to the other ranks by whatever started them (an environment variable,
+  a file, MPI, a torch.distributed broadcast); every rank then constructs the communicator (collective call).
+
+  gather(x, dst=None): every rank's contiguous float64 CUDA tensor -> [world, *x.shape] on ``dst`` (on every rank
+  when None); rank-major order, so channel-major shards [C / G, N] concatenate into the [C, N] block.
+  sum(x, dst=None): element-wise sum over the ranks (the mix of per-rank partial mixes)."""
+
+  def __init__(self, rank, world, unique_id, device=None):
+    import ctypes
+    from . import _ffi
+    if len(unique_id) != 128:
+      raise ValueError("the RCCL unique id is 128 bytes")
+    self._L, self.rank, self.world = _ffi.load(), int(rank), int(world)
+    self.device = world_info()[2] if device is None else int(device)
+    self._h = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+    _ffi.check(self._L.alz_comm_create(self.device, self.world, self.rank, buf, ctypes.byref(self._h)))
+
+  @staticmethod
+  def unique_id():
+    import ctypes
+    from . import _ffi
+    buf = ctypes.create_string_buffer(128)
+    _ffi.check(_ffi.load().alz_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+  def _check(self, x):
+    import torch
+    if not (x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()):
+      raise ValueError("contiguous float64 CUDA tensors only")
+
+  def gather(self, x, dst=None):
+    import ctypes
+    import torch
+    from . import _ffi
+    self._check(x)
+    here = dst is None or dst == self.rank
+    out = torch.empty((self.world,) + tuple(x.shape), dtype=torch.float64, device=x.device) if here else None
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _ffi.check(self._L.alz_comm_gather(self._h, x.data_ptr(), out.data_ptr() if here else None, x.numel(),
+                                       -1 if dst is None else int(dst), ctypes.c_void_p(stream)))
+    return out
+
+  def sum(self, x, dst=None):
+    import ctypes
+    import torch
+    from . import _ffi
+    self._check(x)
+    here = dst is None or dst == self.rank
+    out = torch.empty_like(x) if here else None
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _ffi.check(self._L.alz_comm_sum(self._h, x.data_ptr(), out.data_ptr() if here else None, x.numel(),
+                                    -1 if dst is None else int(dst), ctypes.c_void_p(stream)))
+    return out
+
+  def close(self):
+    h, self._h = self._h, None
+    if h:
+      self._L.alz_comm_destroy(h)
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -66,14 +66,47 @@ def fir_taps(ntaps=256, fc=0.1):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the reference's path on the host cores (rank 0, N = 1, bounded sample)
 # ---------------------------------------------------------------------------------------------
+def reference_package():
+  """The unmodified reference, when this machine has it: AUDIOLAZY_REF (a directory that holds the ``audiolazy``
+  package) or /root/reference.  The GPU boxes do not have it; the CPU legs then run the restatement
+  (oracle/pyref.py), and ``cpu_baseline.kind`` says which one was timed."""
+  global _REF
+  if _REF is None:
+    _REF = False
+    root = os.environ.get("AUDIOLAZY_REF") or "/root/reference"
+    if os.path.isdir(os.path.join(root, "audiolazy")):
+      sys.dont_write_bytecode = True            # (/root/reference is read-only)
+      sys.path.insert(0, root)
+      try:
+        import audiolazy
+        _REF = audiolazy
+      except Exception:
+        _REF = False
+      finally:
+        sys.path.remove(root)
+  return _REF or None
+
+
+_REF = None
+
+
 def _py_channel(job):
   """One process's share of the reference path: white_noise -> filt -> .blocks(4096)."""
-  from oracle import pyref
   b, a, n, seed, passes = job
+  ref = reference_package()
   t0 = time.perf_counter()
   done = 0
-  for p in range(passes):
-    done += pyref.consume_blocks(pyref.df1(b, a, pyref.noise(n, seed + p)), 4096)
+  if ref is not None:                            # the reference itself: ZFilter(b, a)(white_noise(n)).blocks(4096)
+    import random
+    filt = ref.ZFilter(list(b), list(a))
+    for p in range(passes):
+      random.seed(seed + p)
+      for blk in filt(ref.white_noise(n)).blocks(4096):
+        done += len(blk)
+  else:
+    from oracle import pyref
+    for p in range(passes):
+      done += pyref.consume_blocks(pyref.df1(b, a, pyref.noise(n, seed + p)), 4096)
   return done, time.perf_counter() - t0
 
 
@@ -154,9 +187,19 @@ def cpu_baseline(b, a, budget_s=3.5):
   bs = [rep(np.ascontiguousarray(b[:, k])) if nz(b[:, k]) else 0.0 for k in range(b.shape[1])]
   as_ = [1.0] + [rep(np.ascontiguousarray(a[:, k])) if nz(a[:, k]) else 0.0 for k in range(1, a.shape[1])]
   zero = np.zeros(C)
+  ref = reference_package()
+  if ref is not None:
+    zf = ref.z
+    num = sum((bk if isinstance(bk, float) else ref.Stream(bk)) * zf ** -k for k, bk in enumerate(bs) if not isinstance(bk, float) or bk != 0.0)
+    den = 1 + sum((ak if isinstance(ak, float) else ref.Stream(ak)) * zf ** -k for k, ak in enumerate(as_) if k > 0 and (not isinstance(ak, float) or ak != 0.0))
+    ref_filt = num / den
   done, t0 = 0, time.perf_counter()
   while True:
-    done += pyref.consume_blocks(pyref.df1(bs, as_, iter(x), zero=zero), 4096) * C
+    if ref is not None:                           # tests/test_filters_extdep.py:49-89 idiom on the reference itself
+      for blk in ref_filt(iter(x), zero=zero).blocks(4096):
+        done += len(blk) * C
+    else:
+      done += pyref.consume_blocks(pyref.df1(bs, as_, iter(x), zero=zero), 4096) * C
     el = time.perf_counter() - t0
     if el >= budget_s:
       break
@@ -182,11 +225,13 @@ def cpu_baseline(b, a, budget_s=3.5):
                               % (Cc, C, n, done // (Cc * n))}
   head = legs["py_pool"]
   return {"value": head["value"], "unit": "Gsamples/s", "cores": head["cores"], "host_logical_cpus": cores,
-          "usable_cores": usable, "kind": "port",
-          "sample": "the reference's CPython path restated (oracle/pyref.py: the generated DF-I generator of "
-                    "lazy_filters.py:197-260 executed by this interpreter, fed by random.uniform noise, consumed "
-                    "through blocks(4096)) on resonators of configs[1]: " + head["sample"]
-                    + "; legs = one process / all cores / vector-valued rows / C port",
+          "usable_cores": usable, "kind": "reference" if reference_package() is not None else "port",
+          "sample": ("the unmodified reference (audiolazy %s: ZFilter(b, a)(white_noise(n)).blocks(4096)) "
+                     % getattr(reference_package(), "__version__", "?") if reference_package() is not None else
+                     "the reference's CPython path restated (oracle/pyref.py: the generated DF-I generator of "
+                     "lazy_filters.py:197-260 executed by this interpreter, fed by random.uniform noise, consumed "
+                     "through blocks(4096)) ") + "on resonators of configs[1]: " + head["sample"]
+                    + "; legs = one process / all cores / vector-valued rows / C port (the C port is always oracle/alz_oracle.c)",
           "legs": legs}
 
 
@@ -298,13 +343,16 @@ class Ctx(object):
     torch = self.torch
     for _ in range(warmup):
       step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # ONE pair of HIP events brackets the K steps on the launch stream (torch's current stream): device time per
+    # step = their distance / K.  (A pair per step, as in rounds 1 - 2, puts two marker packets between
+    # consecutive launches: +12 us on a 60 us LPC step, tools/lpc_time.py.)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     self.sync_all()
     t0 = time.perf_counter()
+    e0.record()
     for s in range(steps):
-      ev[s][0].record()                  # same stream the kernels are launched on (torch's current)
       step()
-      ev[s][1].record()
+    e1.record()
     self.sync_all()
     elapsed = time.perf_counter() - t0
     self.local_elapsed.append(elapsed)         # this rank's own clock (reported per rank next to the MAX)
@@ -312,7 +360,7 @@ class Ctx(object):
       t = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
       self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
       elapsed = float(t.item())
-    return elapsed, sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+    return elapsed, e0.elapsed_time(e1) / steps
 
   def noise(self, shape, seed_off=0):
     torch = self.torch
@@ -381,6 +429,27 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
         parity = "MISMATCH: " + parity
     else:
       parity = "MISMATCH"
+    # ... and the WHOLE block length on 64 strided channels (every tile and chunk boundary a 2^20-sample block
+    # walks; the C oracle does 64 channels x 2^20 samples in ~0.4 s)
+    if N > nchk and not parity.startswith("MISMATCH"):
+      bank.reset()
+      bank.process(x, layout=args.layout, out=y)
+      pick = np.unique(np.linspace(0, C - 1, min(C, 64)).astype(int))
+      idx = torch.from_numpy(pick).to(ctx.dev)
+      tm = args.layout == "time"
+      got = (y.index_select(1, idx) if tm else y.index_select(0, idx)).cpu().numpy()
+      xs = (x.index_select(1, idx) if tm else x.index_select(0, idx)).cpu().numpy()
+      ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), xs, layout=args.layout)
+      if bits_equal(got, ref):
+        parity += "; full block length: %d strided channels x %d samples bit-exact" % (len(pick), N)
+      elif not exact:
+        err = norm_err(got, ref, 0 if tm else 1)
+        parity += "; full block length (%d strided channels x %d samples): max normalised error %.3g" % (len(pick), N, err)
+        if not err <= 1e-6:
+          parity = "MISMATCH: " + parity
+      else:
+        parity = "MISMATCH on the full block length: " + parity
+      del got, xs, ref
   # yardstick, outside the timed region: a plain device-to-device copy of the same block
   d2d = None
   if ctx.rank == 0 and check:
@@ -491,9 +560,9 @@ def wl_gammatone(ctx, args, alz, steps, warmup, fused=False, streams=64, log2n=1
           "roofline": hbm_roof((8.0 + 8.0 / B) * B * S * N, k_ms), "B": B, "S": S, "N": N, "layout": layout}
 
 
-def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False):
+def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False, frames=65536):
   from audiolazy_amd.lpc import kautocor_frames
-  F, L, order = 65536, 480, 16
+  F, L, order = frames, 480, 16
   sig = ctx.noise((F * L,), 3)
   torch = ctx.torch
   out = (torch.empty((F, order + 1), dtype=torch.float64, device=ctx.dev), torch.empty((F,), dtype=torch.float64, device=ctx.dev),
@@ -517,7 +586,7 @@ def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False):
   del sig
   ctx.torch.cuda.empty_cache()
   return {"units": float(F), "elapsed": elapsed, "parity": parity,
-          "kernel": ("k_acorr_stage<17> + k_levinson_dense<17> (the reference's dense Levinson-Durbin)" if exact else
+          "kernel": ("k_acorr_stage<17,dense> (autocorrelation + the reference's dense Levinson-Durbin in ONE launch)" if exact else
                      "k_acorr_stage<17,lev%s> (autocorrelation + Levinson-Durbin in one launch)" % (",fma" if fused else "")),
           "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
 
@@ -619,6 +688,19 @@ def wl_collective(ctx, args, C, n):
     else:
       ok = got is None
     out[key]["check"] = "ok" if all(r[0] == 1.0 for r in ctx.all_ranks([1.0 if ok else 0.0])) else "MISMATCH"
+  if args.backend == "nccl" and ctx.world == 1:
+    # the same collective through the C ABI's own RCCL binding (include/alz.h alz_comm_*), one-rank communicator:
+    # the path of a caller that does not use torch.distributed at all
+    try:
+      comm = sharding.DirectComm(0, 1, sharding.DirectComm.unique_id(), device=ctx.local)
+      g = comm.gather(y, dst=0)
+      m = comm.sum(part)
+      torch.cuda.synchronize(ctx.dev)
+      ok = bool(torch.equal(g[0], y)) and bool(torch.equal(m, part))
+      comm.close()
+      out["c_abi_direct_rccl"] = {"check": "ok" if ok else "MISMATCH", "calls": "alz_comm_create / alz_comm_gather / alz_comm_sum"}
+    except Exception as exc:        # (reported, not fatal: the torch.distributed path above is the one bench.py relies on)
+      out["c_abi_direct_rccl"] = {"check": "ok", "skipped": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
   del y
   torch.cuda.empty_cache()
   bad = [k for k, v in out.items() if v["check"] != "ok"]
@@ -747,10 +829,15 @@ def main():
                                  "480-sample frames")
         r = wl_lpc(ctx, args, alz, 20, 3, exact=True)
         secondary["lpc_bit_identical"] = entry(r, 1, 20, "Gframes/s", "configs[4] with the reference's dense Levinson-Durbin "
-                                               "(ALZ_LPC_DENSE): coefficients and error bit-identical on every frame")
+                                               "(ALZ_LPC_DENSE), one launch: coefficients and error bit-identical on every frame")
         r = wl_lpc(ctx, args, alz, 20, 3, fused=True)
         secondary["lpc_fma"] = entry(r, 1, 20, "Gframes/s", "configs[4] with fused multiply-adds in the autocorrelation "
                                      "sums (opt-in ALZ_LPC_FUSED; not pinned to the last bit)")
+        r = wl_lpc(ctx, args, alz, 5, 1, frames=1 << 20)
+        secondary["lpc_1m"] = entry(r, 1, 5, "Gframes/s", "configs[4] as a 2^20-frame batch (SURVEY.md 8d: a bandwidth fraction "
+                                    "that is not dominated by the 65536-frame launch): 4 GB of signal per launch")
+        r = wl_lpc(ctx, args, alz, 5, 1, exact=True, frames=1 << 20)
+        secondary["lpc_1m_bit_identical"] = entry(r, 1, 5, "Gframes/s", "the same batch through the bit-identical path")
         r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
         secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
                                           "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel")

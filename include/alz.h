@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 201 /* 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
+#define ALZ_VERSION 300 /* 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
@@ -267,6 +267,24 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
                        int64_t channels, const double *x_dev, double *y_dev, int64_t n, int layout,
                        int64_t ldx, int64_t ldy, double *xh_dev, double *yh_dev, double zero,
                        int device, void *stream);
+
+/* ---- the optional downstream collective, on RCCL (no reference counterpart: the reference is one process,
+ * audiolazy/lazy_stream.py:114; SURVEY.md 8e / BASELINE.json north_star: "a single RCCL gather over xGMI only when
+ * a downstream mix needs every channel on one device").  Filtering itself never exchanges anything.  One process per
+ * GPU; rank 0 calls alz_comm_unique_id and hands the 128 bytes to the other ranks through its launcher; every rank
+ * then calls alz_comm_create (collective).  librccl.so is resolved at run time; without it these calls return
+ * ALZ_E_UNSUPPORTED and nothing else in the library is affected. */
+typedef struct alz_comm alz_comm_t;
+#define ALZ_COMM_ID_BYTES 128
+int alz_comm_unique_id(void *id_out /* ALZ_COMM_ID_BYTES */);
+int alz_comm_create(int device, int world, int rank, const void *id /* ALZ_COMM_ID_BYTES */, alz_comm_t **out);
+int alz_comm_destroy(alz_comm_t *c);
+/* every rank contributes `count` doubles; rank `root` (every rank when root < 0) receives world * count doubles in
+ * rank order: the [C / G, N] channel-major shards of a block become the [C, N] block.  Asynchronous on `stream`. */
+int alz_comm_gather(alz_comm_t *c, const double *send_dev, double *recv_dev, int64_t count, int root, void *stream);
+/* element-wise sum over the ranks of `count` doubles to `root` (to every rank when root < 0): the mix of per-rank
+ * partial mixes (ParallelFilter / Streamix over shards).  The order of the additions is the collective's. */
+int alz_comm_sum(alz_comm_t *c, const double *send_dev, double *recv_dev, int64_t count, int root, void *stream);
 
 #ifdef __cplusplus
 }

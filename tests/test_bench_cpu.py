@@ -12,7 +12,9 @@ def test_cpu_baseline_legs_run_and_rank_as_expected():
   assert b.shape == (64, 3) and a.shape == (64, 3) and np.all(a[:, 0] == 1) and np.all(b[:, 1] == 0)
   cpu = bench.cpu_baseline(b, a, budget_s=0.3)
   assert {"value", "unit", "cores", "kind", "sample", "legs", "usable_cores", "host_logical_cpus"} <= set(cpu)
-  assert cpu["kind"] == "port" and cpu["unit"] == "Gsamples/s" and cpu["host_logical_cpus"] == os.cpu_count()
+  # "reference" where the unmodified package is importable (this container), "port" elsewhere (the GPU boxes)
+  assert cpu["kind"] == ("reference" if bench.reference_package() is not None else "port")
+  assert cpu["unit"] == "Gsamples/s" and cpu["host_logical_cpus"] == os.cpu_count()
   legs = cpu["legs"]
   assert set(legs) == {"py_1proc", "py_pool", "py_rows", "c_port"}
   assert all(leg["value"] > 0 and leg["unit"] == "Gsamples/s" for leg in legs.values())
@@ -83,3 +85,13 @@ def test_launcher_env_wins_over_the_flag():
   line = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")][0]
   assert line["n_gpus"] == 2 and line["requested_gpus"] == 4
   assert "--gpus 4 but the launcher started 2" in out.stderr
+
+
+def test_cpu_baseline_falls_back_to_the_port_without_the_reference(monkeypatch):
+  import bench
+  monkeypatch.setenv("AUDIOLAZY_REF", "/nonexistent")
+  monkeypatch.setattr(bench, "_REF", None)
+  b, a = bench.resonator_coefs(16)
+  cpu = bench.cpu_baseline(b, a, budget_s=0.2)
+  assert cpu["kind"] == "port" and "restated" in cpu["sample"]
+  monkeypatch.setattr(bench, "_REF", None)

@@ -300,7 +300,7 @@ def test_fir256_shared_taps_bit_exact(alz, oracle, C, N):
 
 
 @pytest.mark.parametrize("nb,N,gain", [(20, 5, 1.0), (17, 77, 1.0), (64, 300, 2.0), (255, 1000, 1.0),
-                                       (256, 40, -1.0), (100, 2100, 0.5), (256, 4099, 1.0), (9, 1537, 1.0)])
+                                       (256, 40, -1.0), (100, 2100, 0.5), (256, 4099, 1.0), (24, 1537, 1.0)])
 def test_fir_shared_taps_kernels_shapes(alz, oracle, nb, N, gain):
   """The shared-tap ring kernel (edge runs that reach into the delay line, interior runs, the interleaved
   run-to-wave mapping) on tap counts that are not a multiple of the tap block, blocks shorter than a row

@@ -302,4 +302,6 @@ def test_bit_identical_batch_is_one_launch(lpc):
     c, e, st = lpc.kautocor_frames(sig, L, order, exact=True)
     rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
     assert np.array_equal(st, rs) and st[3] == -4
-    assert np.array_equal(c.view(np.uint64), rc.view(np.uint64)) and np.array_equal(e.view(np.uint64), re.view(np.uint64))
+    ok = st == 0                                              # (a ParCorError frame has a status, not coefficients)
+    assert np.array_equal(c[ok].view(np.uint64), rc[ok].view(np.uint64))
+    assert np.array_equal(e[ok].view(np.uint64), re[ok].view(np.uint64))

@@ -6,6 +6,7 @@
 #   sh:SCRIPT        bash tools/SCRIPT
 #   bench[:ARGS]     python bench.py ARGS           (':' separates, '+' stands for a blank)
 #   tune:ENV:ARGS    the same through the -DALZ_TUNING library (tools/variants/libalzhip_tuning.so) with ENV set
+#   lib:NAME:ARGS    python bench.py ARGS through tools/variants/libalzhip_NAME.so
 #   py:SCRIPT[:ENV]  python tools/SCRIPT
 #   stats[:ARGS]     rocprofv3 --kernel-trace --stats of python bench.py ARGS -> kernel_stats.csv / kernel_dispatches.csv
 #   pmc:CTR:ARGS     one rocprofv3 --pmc CTR pass (+ kernel trace only) of python bench.py ARGS, summarised per kernel
@@ -26,6 +27,8 @@ for step in "$@"; do
     bench) timeout 900 python bench.py $a > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench [$a] rc=$?"; python tools/show_line.py $O/bench_$i.json ;;
     tune)  env $a ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 900 python bench.py $b > $O/tune_$i.json 2> $O/tune_$i.err
            echo "tune [$a] [$b] rc=$?"; python tools/show_line.py $O/tune_$i.json ;;
+    lib)   ALZ_LIBRARY=$R/tools/variants/libalzhip_$a.so timeout 900 python bench.py $b > $O/lib_$i.json 2> $O/lib_$i.err
+           echo "lib [$a] [$b] rc=$?"; python tools/show_line.py $O/lib_$i.json ;;
     py)    env $b timeout 900 python tools/$a > $O/py_$i.log 2>&1; echo "py [$a] rc=$?"; tail -30 $O/py_$i.log ;;
     stats) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$i -o s -- python $R/bench.py $a > $O/stats_$i.log 2>&1
            find $O/stats_$i -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$i.csv \;
