@@ -582,8 +582,12 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     if (chunk < 64 || n < 4 * chunk) return 0;
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     const int ns = h->n_sections;
-    for (int s = 0; s < ns; ++s)
+    // the LAST section runs on the caller's stream, the others on streams of the handle: a process has four hardware
+    // queues by default (GPU_MAX_HW_QUEUES) and the caller's stream holds one -- with four streams of our own two
+    // sections shared a queue and took turns (rocprofv3 trace, profiles/NOTES_r03.md)
+    for (int s = 0; s + 1 < ns; ++s)
       if (!h->sec_streams[s] && hipStreamCreateWithFlags(&h->sec_streams[s], hipStreamNonBlocking) != hipSuccess) return 0;
+    auto stream_of = [&](int s) { return s + 1 < ns ? h->sec_streams[s] : st; };
     const size_t need = (size_t)ns * n_chunks + 1;
     while (h->sec_events.size() < need) {
       hipEvent_t ev;
@@ -596,21 +600,20 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     auto ev_of = [&](int s, int64_t j) { return h->sec_events[(size_t)(j * ns + s)]; };
     hipEvent_t start = h->sec_events[need - 1];
     if (hipEventRecord(start, st) != hipSuccess) return -1000;         // everything queued on `st` so far (input map, expansion)
-    for (int s = 0; s < ns; ++s)
+    for (int s = 0; s + 1 < ns; ++s)
       if (hipStreamWaitEvent(h->sec_streams[s], start, 0) != hipSuccess) return -1000;
     for (int64_t j = 0; j < n_chunks; ++j) {
       const int64_t t0 = j * chunk, tn = (t0 + chunk <= n) ? chunk : n - t0;
       for (int s = 0; s < ns; ++s) {
-        hipStream_t ss = h->sec_streams[s];
+        hipStream_t ss = stream_of(s);
         if (s > 0 && !ALZ_TUNE("ALZ_SECPIPE_NOWAIT", 0) && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return -1000;
         const int rc = run_sections_on(0, h->channels, t0, tn, s, s + 1, ss);
         if (rc) return rc;
         if (hipEventRecord(ev_of(s, j), ss) != hipSuccess) return -1000;
       }
     }
-    // the caller's stream continues after the last section's last chunk (which is ordered after everything else
-    // on its stream; earlier sections finished before it could start)
-    if (hipStreamWaitEvent(st, ev_of(ns - 1, n_chunks - 1), 0) != hipSuccess) return -1000;
+    // (the caller's stream ends with the last section's last chunk; every earlier section finished before that
+    // chunk could start)
     h->last_kernels += "  [section pipeline: " + std::to_string(ns) + " streams x " + std::to_string(n_chunks) + " chunks]";
     return 1;
   };

@@ -140,6 +140,10 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
 int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
                  const int *kind, const double *value, const double *const *series, const int *negated,
                  double *xh, double *yh, hipStream_t stream, int64_t *done_samples);
+// alz_tvpc.hip: time-varying biquad-class filter with PER-CHANNEL coefficient series (time-major rows), three-wave kernel
+int launch_tvpc(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int64_t channels, int nb, int na,
+                const int *kind, const double *value, const double *const *series, const int64_t *series_ld,
+                const int *negated, double *xh, double *yh, hipStream_t stream, int64_t *done_samples);
 // alz_map.hip: one elementwise op over n contiguous doubles (see alz_map_dev)
 int launch_map(int op, const double *x, const double *y, double p0, double p1, int64_t n, double *out,
                int *flags, hipStream_t stream);

@@ -518,6 +518,39 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
       if (p.n == 0) { if (prev != device) (void)hipSetDevice(prev); return ALZ_OK; }
     }
   }
+  // per-channel coefficient series on time-major rows (``repeat(ndarray)``-style coefficient Streams): the three-wave
+  // kernel takes the full tiles, the lane-per-channel kernels below continue with the ragged rest
+  if (ALZ_TUNE("ALZ_TV_PC", 1) && channels > 1 && nb <= 3 && na <= 3 && p.gain_mode == 0 && layout == ALZ_TIME_MAJOR) {
+    int kind[5], negated[5];
+    double value[5];
+    const double *series[5];
+    int64_t sld[5];
+    bool ok = true, any = false;
+    for (int t = 0; t < 5; ++t) {
+      const alz::TvSide &sd = t < 3 ? p.b : p.a;
+      const int k = t < 3 ? t : t - 2;
+      kind[t] = sd.kind[k]; value[t] = sd.value[k]; series[t] = sd.kind[k] == 2 ? sd.series[k] : nullptr;
+      negated[t] = sd.negated[k]; sld[t] = sd.sn[k];
+      if (sd.kind[k] == 2) {
+        any = true;
+        if (sd.sc[k] != 1 || sd.sn[k] < channels) ok = false;     // one coefficient per channel, rows at least a bank wide
+      }
+    }
+    int64_t done = 0;
+    if (ok && any) {
+      const int rc = alz::launch_tvpc(p.x, p.y, n, ldx, ldy, channels, nb, na, kind, value, series, sld, negated,
+                                      xh_dev, yh_dev, (hipStream_t)stream, &done);
+      if (rc) { if (prev != device) (void)hipSetDevice(prev); return rc; }
+    }
+    if (done > 0) {
+      p.x += done * p.sxn; p.y += done * p.syn; p.n -= done;
+      for (int k = 0; k < alz::kTvMax; ++k) {
+        if (p.b.kind[k] == 2) p.b.series[k] += done * p.b.sn[k];
+        if (p.a.kind[k] == 2) p.a.series[k] += done * p.a.sn[k];
+      }
+      if (p.n == 0) { if (prev != device) (void)hipSetDevice(prev); return ALZ_OK; }
+    }
+  }
   const unsigned grid = (unsigned)((channels + 63) / 64);
   if (channels == 1 && nb <= 3 && na <= 3) {
     unsigned pb = 0, pa = 0;

@@ -223,3 +223,51 @@ def test_bank_steered_by_shared_series(al, pattern, C, layout):
   for ch in (0, C // 2 + 1, C - 1):
     ref = oracle.tv_df1(b_ref, a_ref, x[:, ch], memory=[-.125] * (na - 1), zero=.25)
     assert same_bits(y[:, ch], ref), (pattern, ch)
+
+
+# ---------------------------------------------------------------------------------------------------
+# k_tvpc (csrc/alz_tvpc.hip): per-channel coefficient series on time-major rows -- full 64-row tiles on the
+# three-wave kernel, the ragged rest on the lane-per-channel kernels; every channel against the oracle.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pattern,series_taps", [((5, 3), "b0 a1 a2"), ((1, 3), "b0 a1 a2"), ((5, 3), "b0 b2 a1"), ((3, 3), "a1 a2"),
+                                                   ((7, 3), "b1"), ((1, 1), "b0 a1"), ((3, 1), "a1"), ((1, 3), "a2")])
+@pytest.mark.parametrize("C", [16, 80])
+def test_bank_with_per_channel_series(al, pattern, series_taps, C):
+  import torch
+  from audiolazy_amd import timevar
+  pb, pa = pattern
+  rng = np.random.default_rng(1000 * pb + 100 * pa + C + len(series_taps))
+  N1, N2 = 64 * 6 + 9, 64 * 4               # tiles + ragged tail, then the stream goes on
+  N = N1 + N2
+  x = rng.uniform(-1, 1, (N, C))
+  nb = max(k + 1 for k in range(3) if (pb >> k) & 1)
+  na = 1 + max(k for k in (1, 2) if (pa >> (k - 1)) & 1)
+  b_ref = [(rng.uniform(-.9, .9, (N, C)) if "b%d" % k in series_taps else .37 - .1 * k) if (pb >> k) & 1 else 0. for k in range(nb)]
+  a_ref = [1.] + [(rng.uniform(-.45, .45, (N, C)) if "a%d" % k in series_taps else .2 * k - .3) if (pa >> (k - 1)) & 1 else 0.
+                  for k in range(1, na)]
+  dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+  xh = torch.full((max(nb - 1, 1), C), .25, dtype=torch.float64, device="cuda")
+  yh = torch.full((max(na - 1, 1), C), -.125, dtype=torch.float64, device="cuda")
+  tap = lambda v, lo, hi: dev(v[lo:hi]) if isinstance(v, np.ndarray) else v
+  run = lambda lo, hi: timevar.process_block([tap(v, lo, hi) for v in b_ref], [tap(v, lo, hi) for v in a_ref], dev(x[lo:hi]),
+                                             xh=xh, yh=yh, zero=.25).cpu().numpy()
+  y = np.concatenate([run(0, N1), run(N1, N)])
+  pick = lambda v, ch: v[:, ch] if isinstance(v, np.ndarray) else v
+  for ch in range(C):
+    ref = oracle.tv_df1([pick(v, ch) for v in b_ref], [pick(v, ch) for v in a_ref], x[:, ch], memory=[-.125] * (na - 1), zero=.25)
+    assert same_bits(y[:, ch], ref), (pattern, series_taps, ch)
+
+
+def test_rows_idiom_with_per_channel_coefficient_streams(al):
+  """The reference's vector-valued idiom with coefficient Streams whose items are rows (one coefficient per channel):
+  ``(Stream(rows_b0) + ...) / (1 + Stream(rows_a1) z^-1 + ...)`` called on rows -- denominators negated on the host
+  (ALZ_TV_NEGATED), 16-channel groups on the three-wave kernel."""
+  C, N = 32, 64 * 7 + 5
+  rng = np.random.default_rng(42)
+  x = rng.uniform(-1, 1, (N, C))
+  b0, a1, a2 = rng.uniform(-.9, .9, (N, C)), rng.uniform(-.45, .45, (N, C)), rng.uniform(-.3, .3, (N, C))
+  filt = (al.Stream(iter(b0)) - .5 * al.z ** -2) / (1 + al.Stream(iter(a1)) * al.z ** -1 + al.Stream(iter(a2)) * al.z ** -2)
+  got = np.array(list(filt(iter(x), zero=np.zeros(C))))
+  for ch in range(C):
+    ref = oracle.tv_df1([b0[:, ch], 0., -.5], [1., a1[:, ch], a2[:, ch]], x[:, ch])
+    assert same_bits(got[:, ch], ref), ch

@@ -22,7 +22,7 @@ for step in "$@"; do
   a=${a//+/ }; b=${b//+/ }
   cd $R
   case $kind in
-    tests) timeout 1500 python -m pytest tests -m gpu -q -x $a > $O/pytest_gpu_$i.log 2>&1; tail -4 $O/pytest_gpu_$i.log ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 $a > $O/pytest_gpu_$i.log 2>&1; tail -4 $O/pytest_gpu_$i.log ;;
     sh)    timeout 600 bash tools/$a > $O/sh_$i.log 2>&1; echo "sh [$a] rc=$?"; tail -30 $O/sh_$i.log ;;
     bench) timeout 900 python bench.py $a > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench [$a] rc=$?"; python tools/show_line.py $O/bench_$i.json ;;
     tune)  env $a ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 900 python bench.py $b > $O/tune_$i.json 2> $O/tune_$i.err
