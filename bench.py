@@ -619,7 +619,7 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
           "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
-def wl_timevar(ctx, args, alz, C, N, steps, warmup):
+def wl_timevar(ctx, args, alz, C, N, steps, warmup, per_channel=False):
   """A bank steered by control streams: every channel runs the same time-varying
   resonator, b0[n] x[n] + b2[n] x[n-2] - a1[n] y[n-1] - a2[n] y[n-2], whose coefficient series sweep
   the centre frequency from 200 Hz to 4 kHz at 48 kHz -- ``resonator.z_exp(Stream(freqs), bw)`` called
@@ -632,6 +632,14 @@ def wl_timevar(ctx, args, alz, C, N, steps, warmup):
   g = (1 - r * r) / 2
   series = {"b0": np.full(N, g) * (1 + 1e-3 * np.sin(n / 997.)), "a1": -2 * r * np.cos(w), "a2": np.full(N, r * r)}
   dev = {k: torch.from_numpy(v).to(ctx.dev) for k, v in series.items()}
+  if per_channel:
+    # one series per channel and tap ([N, C] rows, the reference's ``repeat(ndarray)``-style coefficient Streams): every
+    # channel sweeps its own centre frequency (channel c is detuned by a factor 1 + c / 4 C)
+    det = 1.0 + torch.arange(C, dtype=torch.float64, device=ctx.dev) / (4.0 * C)
+    wd = dev_w = torch.from_numpy(w).to(ctx.dev)[:, None] * det[None, :]
+    dev = {"b0": dev["b0"][:, None].expand(N, C).contiguous(), "a1": (-2 * r) * torch.cos(wd),
+           "a2": dev["a2"][:, None].expand(N, C).contiguous()}
+    del wd, dev_w
   b = [dev["b0"], 0., -g]
   a = [1., dev["a1"], dev["a2"]]
   x = ctx.noise((N, C), 5)
@@ -647,12 +655,15 @@ def wl_timevar(ctx, args, alz, C, N, steps, warmup):
                                 [1., dev["a1"][:nchk].contiguous(), dev["a2"][:nchk].contiguous()], xs).cpu().numpy()
     xs = xs.cpu().numpy()
     pick = [0, 1, C // 2, C - 1]
-    ok = all(bits_equal(got[:, ch], np.array(oracle.tv_df1([series["b0"][:nchk], 0., -g],
-                                                             [1., series["a1"][:nchk], series["a2"][:nchk]], xs[:, ch])))
+    col = lambda k, ch: (dev[k][:nchk, ch].cpu().numpy() if per_channel else series[k][:nchk])
+    ok = all(bits_equal(got[:, ch], np.array(oracle.tv_df1([col("b0", ch), 0., -g], [1., col("a1", ch), col("a2", ch)], xs[:, ch])))
              for ch in pick)
     parity = ("bit-exact vs the pure-Python restatement, channels %s x %d samples" % (pick, nchk)) if ok else "MISMATCH"
   del x
   torch.cuda.empty_cache()
+  if per_channel:    # x + three series read, y written: 40 algorithmic bytes per channel-sample
+    return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvpc (three-wave streaming kernel, per-channel coefficient series)",
+            "parity": parity, "roofline": hbm_roof(40.0 * C * N, k_ms)}
   return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvduo (two-wave streaming kernel, shared coefficient series)",
           "parity": parity, "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
@@ -750,7 +761,7 @@ def main():
                        "downstream gather / mixdown run on the chosen backend (RCCL on a one-GPU box)")
   ap.add_argument("--launch-check", action="store_true",
                   help="start the ranks, run the protocol's collectives, print one line and exit (no device work)")
-  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope"], default="biquad",
+  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
@@ -845,6 +856,10 @@ def main():
         secondary["timevar_shared"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples "
                                             "steered by three coefficient series shared by the channels (Stream coefficients, "
                                             "lazy_filters.py:197-224)")
+        r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1, per_channel=True)
+        secondary["timevar_per_channel"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples, "
+                                                 "three coefficient series PER CHANNEL (rows of coefficients per sample: "
+                                                 "40 B per channel-sample)")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel")):
             r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
@@ -888,6 +903,18 @@ def main():
                           "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
                           "%s" % (res["B"], res["S"], res["N"],
                                   "x [N, S] -> y [N, B, S]" if res["layout"] == "time" else "x [S, N] -> y [B, S, N]"),
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  elif args.workload == "timevar":
+    per_ch = args.streams != 64          # (--streams 0: per-channel series; default: series shared by the bank)
+    if (C, N) == (4096, 1 << 20):
+      N = 1 << 18
+    res = wl_timevar(ctx, args, alz, C, N, args.steps, args.warmup, per_channel=per_ch)
+    total_units = float(world) * C * N
+    metric, unit = "Gsamples/s through a time-varying resonator bank (Stream coefficients)", "Gsamples/s"
+    config = {"workload": "time-varying resonator bank, %d channels x %d samples, coefficient series %s" % (
+                  C, N, "per channel" if per_ch else "shared by the bank"),
+              "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]",
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   else:

@@ -3,6 +3,7 @@
 #   gpurun --timeout T -- 'tools/gpu_call.sh <tag> <step> [<step> ...]'
 # Every step writes under gpurun_out/<tag>/.  Steps:
 #   tests[:ARGS]     the -m gpu suite (ARGS: extra pytest arguments, e.g. -k+fir)
+#   quick:ARGS       a selection of the suite under a 4-minute limit (new kernels: a hang must not eat the call)
 #   sh:SCRIPT        bash tools/SCRIPT
 #   bench[:ARGS]     python bench.py ARGS           (':' separates, '+' stands for a blank)
 #   tune:ENV:ARGS    the same through the -DALZ_TUNING library (tools/variants/libalzhip_tuning.so) with ENV set
@@ -23,6 +24,7 @@ for step in "$@"; do
   cd $R
   case $kind in
     tests) timeout 1500 python -m pytest tests -m gpu -q --maxfail=8 $a > $O/pytest_gpu_$i.log 2>&1; tail -4 $O/pytest_gpu_$i.log ;;
+    quick) timeout 240 python -m pytest tests -m gpu -q -x $a > $O/quick_$i.log 2>&1; echo "quick [$a] rc=$?"; tail -4 $O/quick_$i.log ;;
     sh)    timeout 600 bash tools/$a > $O/sh_$i.log 2>&1; echo "sh [$a] rc=$?"; tail -30 $O/sh_$i.log ;;
     bench) timeout 900 python bench.py $a > $O/bench_$i.json 2> $O/bench_$i.err; echo "bench [$a] rc=$?"; python tools/show_line.py $O/bench_$i.json ;;
     tune)  env $a ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 900 python bench.py $b > $O/tune_$i.json 2> $O/tune_$i.err
