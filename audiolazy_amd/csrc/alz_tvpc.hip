@@ -77,12 +77,20 @@ __device__ __forceinline__ void wait_vm(int n) {
 
 }  // namespace
 
-// PB / PA: taps present; NSB / NSA: how many of them are per-channel series (ring counts); NEG: the a-series
-// already hold -a_k[n] (ALZ_TV_NEGATED: the host negated them in Python arithmetic)
-template <unsigned PB, unsigned PA, int NSB, int NSA, bool NEG>
+// PB / PA: taps present (b0 b1 b2 / a1 a2); SB / SA: which of them are per-channel series -- compile-time, because a
+// run-time "is this tap a series" test in the recurrence wave's step became a branch per LDS read (first version:
+// 108 cycles per step, 86 Gsamples/s; profiles/NOTES_r03.md); NEG: the a-series already hold -a_k[n]
+// (ALZ_TV_NEGATED: the host negated them in Python arithmetic)
+constexpr int pc_bits(unsigned m) { return (int)((m & 1u) + ((m >> 1) & 1u) + ((m >> 2) & 1u)); }
+template <unsigned PB, unsigned PA, unsigned SB, unsigned SA, bool NEG>
 __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
+  constexpr int NSB = pc_bits(SB), NSA = pc_bits(SA);
+  static_assert((SB & ~PB) == 0 && (SA & ~PA) == 0 && NSB + NSA >= 1 && NSB + NSA <= 3, "series taps are present taps");
+  // ring of a series tap = its rank among the series taps of its side
+  constexpr int kBSlot[3] = {0, pc_bits(SB & 1u), pc_bits(SB & 3u)};
+  constexpr int kASlot2[2] = {0, pc_bits(SA & 1u)};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -120,8 +128,8 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
       const unsigned s = (unsigned)(t % kSRing);
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        if (NSB > 0 && p.kind[k] == 2) {
-          const unsigned dst = lds0 + (unsigned)(bring - smem) + ((unsigned)p.bslot[k] * kSRing + s) * kSlot;
+        if ((SB >> k) & 1u) {
+          const unsigned dst = lds0 + (unsigned)(bring - smem) + ((unsigned)kBSlot[k] * kSRing + s) * kSlot;
 #pragma unroll
           for (int j = 0; j < kChunks; ++j) dma16(src[k] + t * tile_step[k] + j * chunk_step[k], dst + j * (1024 + 16));
         }
@@ -130,8 +138,8 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
       const unsigned s = (unsigned)(t % kSRing);
 #pragma unroll
       for (int k = 3; k < 5; ++k)
-        if (NSA > 0 && p.kind[k] == 2) {
-          const unsigned dst = lds0 + (unsigned)(aring - smem) + ((unsigned)p.aslot[k - 3] * kSRing + s) * kASlot;
+        if ((SA >> (k - 3)) & 1u) {
+          const unsigned dst = lds0 + (unsigned)(aring - smem) + ((unsigned)kASlot2[k - 3] * kSRing + s) * kASlot;
 #pragma unroll
           for (int j = 0; j < kChunks; ++j) dma16(src[k] + t * tile_step[k] + j * chunk_step[k], dst + j * 1024);
         }
@@ -164,12 +172,13 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
 #pragma unroll
       for (int j = 0; j < kChunks; ++j) dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kSlot + j * (1024 + 16));
     };
-    const bool ser0 = p.kind[0] == 2, ser1 = p.kind[1] == 2, ser2 = p.kind[2] == 2;
+    constexpr bool ser0 = (SB & 1u) != 0, ser1 = (SB & 2u) != 0, ser2 = (SB & 4u) != 0;
     // the 16 coefficients of tap k for this lane's rows 4j + q: from the landed series tile (same addressing as x)
     // or the constant
-    auto fill16 = [&](bool is_series, int k, int64_t t, double (&out)[16]) {
-      if (is_series) {
-        const char *bs = bring + (p.bslot[k] * kSRing + (int)(t % kSRing)) * kSlot + lane_off + q * kStep;
+    auto fill16 = [&](auto is_series, auto kk, int64_t t, double (&out)[16]) {
+      constexpr int k = decltype(kk)::value;
+      if constexpr (decltype(is_series)::value) {
+        const char *bs = bring + (kBSlot[k] * kSRing + (int)(t % kSRing)) * kSlot + lane_off + q * kStep;
 #pragma unroll
         for (int j = 0; j < 16; ++j) out[j] = *reinterpret_cast<const double *>(bs + ALZ_EOFF(4 * j));
       } else {
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
       const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
       const char *x_d2[2] = {xs + (q - 2) * kStep - adj2, xs + (q - 2) * kStep};
       double x0[16], x1[16], x2[16], cb0[16], cb1[16], cb2[16];
-      if constexpr (PB & 1u) fill16(ser0, 0, t, cb0);
-      if constexpr (PB & 2u) fill16(ser1, 1, t, cb1);
-      if constexpr (PB & 4u) fill16(ser2, 2, t, cb2);
+      if constexpr (PB & 1u) fill16(std::integral_constant<bool, ser0>{}, std::integral_constant<int, 0>{}, t, cb0);
+      if constexpr (PB & 2u) fill16(std::integral_constant<bool, ser1>{}, std::integral_constant<int, 1>{}, t, cb1);
+      if constexpr (PB & 4u) fill16(std::integral_constant<bool, ser2>{}, std::integral_constant<int, 2>{}, t, cb2);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if constexpr (PB & 1u) x0[j] = *reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j));
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
     // ------------------------------ REC ------------------------------
     double m1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
     double m2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
-    const bool sa1 = p.kind[3] == 2, sa2 = p.kind[4] == 2;
+    constexpr bool sa1 = (SA & 1u) != 0, sa2 = (SA & 2u) != 0;
     double k1 = (PA & 1u) ? -p.value[3] : 0.0, k2 = (PA & 2u) ? -p.value[4] : 0.0;    // constant taps: -a_k
     asm volatile("" : "+v"(m1), "+v"(m2), "+v"(k1), "+v"(k2));
     // a_k of the previous tile's last three rows (rows T - 3, T - 2, T - 1), for the lagging groups
@@ -277,14 +286,14 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
       // this lane works on row (u - q) of the tile; u - q < 0 lives in the previous tile (p: its ring slot; a_k: keep)
       const char *cur = pring + ps_cur * kSlot + lane_off - q * kStep;
       const char *prv = pring + ps_prv * kSlot + lane_off + (T - q) * kStep;
-      const char *a1c = aring + (p.aslot[0] * kSRing + as_cur) * kASlot + lane_off - q * kStep;
-      const char *a2c = aring + (p.aslot[1] * kSRing + as_cur) * kASlot + lane_off - q * kStep;
+      const char *a1c = aring + (kASlot2[0] * kSRing + as_cur) * kASlot + lane_off - q * kStep;
+      const char *a2c = aring + (kASlot2[1] * kSRing + as_cur) * kASlot + lane_off - q * kStep;
       char *wr = yring + ys_cur * kSlot + lane_off - q * kStep;
       ps_prv = ps_cur;
       ps_cur = (ps_cur + 1 == kPRing) ? 0 : ps_cur + 1;
       ys_cur = (ys_cur + 1 == kYRing) ? 0 : ys_cur + 1;
       as_cur = (as_cur + 1 == kSRing) ? 0 : as_cur + 1;
-      constexpr int R1 = (PA & 1u) ? 3 : 1, R2 = (PA & 2u) ? 3 : 1;   // (an absent tap has no coefficient buffers)
+      constexpr int R1 = sa1 ? 3 : 1, R2 = sa2 ? 3 : 1;   // (a constant tap has no coefficient buffers)
       double pr[3][8], c1[R1][8], c2[R2][8];
       // kept row T - 3 + j for a per-lane j (registers cannot be indexed by a lane value: selects)
       auto kept = [](double a, double b, double c, int j) { return j <= 0 ? a : j == 1 ? b : c; };
@@ -294,20 +303,16 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
           if (k == 0 && u < 3) {
             const bool before = u < q;                           // (per-lane; u >= 3 never)
             pp[u] = *reinterpret_cast<const double *>((before ? prv : cur) + u * kStep);
-            if constexpr ((PA & 1u) != 0 && NSA > 0) {
-              if (sa1) { const double v = *reinterpret_cast<const double *>(a1c + (before ? q : 8 * k + u) * kStep); cc1[u] = before ? kept(k1a, k1b, k1c, u + 3 - q) : v; }
+            if constexpr (sa1) {
+              { const double v = *reinterpret_cast<const double *>(a1c + (before ? q : 8 * k + u) * kStep); cc1[u] = before ? kept(k1a, k1b, k1c, u + 3 - q) : v; }
             }
-            if constexpr ((PA & 2u) != 0 && NSA > 0) {
-              if (sa2) { const double v = *reinterpret_cast<const double *>(a2c + (before ? q : 8 * k + u) * kStep); cc2[u] = before ? kept(k2a, k2b, k2c, u + 3 - q) : v; }
+            if constexpr (sa2) {
+              { const double v = *reinterpret_cast<const double *>(a2c + (before ? q : 8 * k + u) * kStep); cc2[u] = before ? kept(k2a, k2b, k2c, u + 3 - q) : v; }
             }
           } else {
             pp[u] = *reinterpret_cast<const double *>(cur + (8 * k + u) * kStep);
-            if constexpr ((PA & 1u) != 0 && NSA > 0) {
-              if (sa1) cc1[u] = *reinterpret_cast<const double *>(a1c + (8 * k + u) * kStep);
-            }
-            if constexpr ((PA & 2u) != 0 && NSA > 0) {
-              if (sa2) cc2[u] = *reinterpret_cast<const double *>(a2c + (8 * k + u) * kStep);
-            }
+            if constexpr (sa1) cc1[u] = *reinterpret_cast<const double *>(a1c + (8 * k + u) * kStep);
+            if constexpr (sa2) cc2[u] = *reinterpret_cast<const double *>(a2c + (8 * k + u) * kStep);
           }
         }
       };
@@ -344,12 +349,12 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
       // a_k of this tile's last three rows, for the lagging groups' first steps of the next tile:
       // keep[j] = a_k[row T - 3 + j]
       if constexpr (NSA > 0) {
-        if ((PA & 1u) && sa1) {
+        if constexpr (sa1) {
           k1a = *reinterpret_cast<const double *>(a1c + (q + T - 3) * kStep);
           k1b = *reinterpret_cast<const double *>(a1c + (q + T - 2) * kStep);
           k1c = *reinterpret_cast<const double *>(a1c + (q + T - 1) * kStep);
         }
-        if ((PA & 2u) && sa2) {
+        if constexpr (sa2) {
           k2a = *reinterpret_cast<const double *>(a2c + (q + T - 3) * kStep);
           k2b = *reinterpret_cast<const double *>(a2c + (q + T - 2) * kStep);
           k2c = *reinterpret_cast<const double *>(a2c + (q + T - 1) * kStep);
@@ -368,18 +373,28 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
 
 typedef void (*tvpc_fn)(PCArgs);
 
-template <int NSB, int NSA, bool NEG>
-static tvpc_fn pick_tvpc_pat(unsigned pb, unsigned pa) {
-#define ALZ_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) return (tvpc_fn)k_tvpc<PB_, PA_, NSB, NSA, NEG>;
-  ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3)
-#undef ALZ_PAT
-  return nullptr;
-}
-
-static tvpc_fn pick_tvpc(unsigned pb, unsigned pa, int nsb, int nsa, bool neg) {
-#define ALZ_NS(B_, A_) if (nsb == B_ && nsa == A_) return neg ? pick_tvpc_pat<B_, A_, true>(pb, pa) : pick_tvpc_pat<B_, A_, false>(pb, pa);
-  ALZ_NS(1, 0) ALZ_NS(0, 1) ALZ_NS(1, 1) ALZ_NS(2, 0) ALZ_NS(0, 2) ALZ_NS(2, 1) ALZ_NS(1, 2)
-#undef ALZ_NS
+// (present taps, series taps) combinations with an instantiation: every split of one to three series taps over the
+// biquad-class patterns (two at most on the two densest ones); anything else stays on the lane-per-channel kernel
+static tvpc_fn pick_tvpc(unsigned pb, unsigned pa, unsigned sb, unsigned sa, bool neg) {
+#define ALZ_PC(PB_, PA_, SB_, SA_)                                                                   \
+  if (pb == PB_ && pa == PA_ && sb == SB_ && sa == SA_)                                              \
+    return (SA_ != 0 && neg) ? (tvpc_fn)k_tvpc<PB_, PA_, SB_, SA_, (SA_ != 0)> : (tvpc_fn)k_tvpc<PB_, PA_, SB_, SA_, false>;
+  ALZ_PC(1, 1, 0, 1) ALZ_PC(1, 1, 1, 0) ALZ_PC(1, 1, 1, 1) ALZ_PC(3, 1, 0, 1)
+  ALZ_PC(3, 1, 1, 0) ALZ_PC(3, 1, 1, 1) ALZ_PC(3, 1, 2, 0) ALZ_PC(3, 1, 2, 1)
+  ALZ_PC(3, 1, 3, 0) ALZ_PC(3, 1, 3, 1) ALZ_PC(1, 3, 0, 1) ALZ_PC(1, 3, 0, 2)
+  ALZ_PC(1, 3, 0, 3) ALZ_PC(1, 3, 1, 0) ALZ_PC(1, 3, 1, 1) ALZ_PC(1, 3, 1, 2)
+  ALZ_PC(1, 3, 1, 3) ALZ_PC(3, 3, 0, 1) ALZ_PC(3, 3, 0, 2) ALZ_PC(3, 3, 0, 3)
+  ALZ_PC(3, 3, 1, 0) ALZ_PC(3, 3, 1, 1) ALZ_PC(3, 3, 1, 2) ALZ_PC(3, 3, 1, 3)
+  ALZ_PC(3, 3, 2, 0) ALZ_PC(3, 3, 2, 1) ALZ_PC(3, 3, 2, 2) ALZ_PC(3, 3, 3, 0)
+  ALZ_PC(5, 3, 0, 1) ALZ_PC(5, 3, 0, 2) ALZ_PC(5, 3, 0, 3) ALZ_PC(5, 3, 1, 0)
+  ALZ_PC(5, 3, 1, 1) ALZ_PC(5, 3, 1, 2) ALZ_PC(5, 3, 1, 3) ALZ_PC(5, 3, 4, 0)
+  ALZ_PC(5, 3, 4, 1) ALZ_PC(5, 3, 4, 2) ALZ_PC(5, 3, 4, 3) ALZ_PC(5, 3, 5, 0)
+  ALZ_PC(5, 3, 5, 1) ALZ_PC(5, 3, 5, 2) ALZ_PC(7, 3, 0, 1) ALZ_PC(7, 3, 0, 2)
+  ALZ_PC(7, 3, 0, 3) ALZ_PC(7, 3, 1, 0) ALZ_PC(7, 3, 1, 1) ALZ_PC(7, 3, 1, 2)
+  ALZ_PC(7, 3, 1, 3) ALZ_PC(7, 3, 2, 0) ALZ_PC(7, 3, 2, 1) ALZ_PC(7, 3, 2, 2)
+  ALZ_PC(7, 3, 3, 0) ALZ_PC(7, 3, 4, 0) ALZ_PC(7, 3, 4, 1) ALZ_PC(7, 3, 4, 2)
+  ALZ_PC(7, 3, 5, 0) ALZ_PC(7, 3, 6, 0)
+#undef ALZ_PC
   return nullptr;
 }
 
@@ -410,7 +425,10 @@ int launch_tvpc(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy,
   }
   if (nsb + nsa == 0 || nsb + nsa > 3) return ALZ_OK;
   if (negs != 0 && negs != nsa) return ALZ_OK;               // (one sign convention per call)
-  tvpc_fn fn = pick_tvpc(pb, pa, nsb, nsa, negs != 0);
+  unsigned sb = 0, sa = 0;
+  for (int k = 0; k < 3; ++k) sb |= (unsigned)(kind[k] == 2) << k;
+  for (int k = 3; k < 5; ++k) sa |= (unsigned)(kind[k] == 2) << (k - 3);
+  tvpc_fn fn = pick_tvpc(pb, pa, sb, sa, negs != 0);
   if (!fn) return ALZ_OK;
   p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = n / 64; p.channels = channels;
   p.nb = nb; p.na = na; p.xh = xh; p.yh = yh;
