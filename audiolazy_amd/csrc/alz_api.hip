@@ -309,6 +309,7 @@ int alz_bank_destroy(alz_bank_t *h) {
     if (sc.vxh) (void)hipFree(sc.vxh);
     if (sc.vyh) (void)hipFree(sc.vyh);
     if (sc.power) (void)hipFree(sc.power);
+    if (sc.zbuf) (void)hipFree(sc.zbuf);
   }
   delete h;
   return ALZ_OK;

@@ -135,6 +135,8 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   uint64_t power_bytes = 0;
   int64_t power_len = 0;             // chunk length the cached matrix belongs to (0: none)
   int power_section = -1;
+  double *zbuf = nullptr;            // k_look: published chunk end states (+ an error word at the end)
+  uint64_t zbuf_bytes = 0;
 };
 // alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, two-wave streaming kernel
 int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
@@ -151,6 +153,11 @@ int launch_levinson_dense(const double *r, int64_t n_frames, int n_lags, int ord
                           int *status, hipStream_t st);
 int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int64_t n_inputs, int64_t sxn, int64_t sxc,
                   int64_t sen, int64_t sec, hipStream_t stream);
+// alz_look.hip: the time-parallel mode of one biquad-class section in ONE pass (chunks resident in LDS, chunk states
+// through global memory); see the file header
+int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
+                uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name);
+constexpr int64_t kLookChunk = 512;
 // time-parallel execution of a whole fused cascade on a channel-major block (see alz_scan.hip); *taken = false
 // when the shape is not covered (nothing written but scratch)
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,

@@ -134,6 +134,40 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (io.c_first != 0 || io.c_count != io.channels) return ALZ_OK;
   const int64_t C = io.channels;
   if (C % 16) return ALZ_OK;
+  // One pass where the shape allows it (time-major block, automatic chunk length): 512-sample chunks resident in
+  // LDS, the block read once (alz_look.hip); the three-launch form below takes everything else.
+  if (chunk_len <= 0 && sec.na > 1 && ALZ_TUNE("ALZ_LOOK", 1) && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
+    const int64_t groups = C / 16, Kl = io.n / kLookChunk;
+    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) + 64;
+    uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;
+    int rc2 = grow_scratch(&scratch->zbuf, &have_z, zneed);
+    if (rc2) return rc2;
+    scratch->zbuf_bytes = have_z;
+    rc2 = grow_scratch(&scratch->power, &have_p, (uint64_t)4 * C * sizeof(double));
+    if (rc2) return rc2;
+    if (have_p != scratch->power_bytes) scratch->power_len = 0;
+    scratch->power_bytes = have_p;
+    ScanArgs pw;
+    pw.x = io.x; pw.sxn = io.sxn; pw.sxc = io.sxc; pw.C = C; pw.n_inputs = io.n_inputs; pw.n_sets = io.n_sets;
+    pw.mode = io.mode; pw.map_input = io.map_input; pw.nb = sec.nb; pw.na = sec.na; pw.L = kLookChunk; pw.K = Kl;
+    pw.a = sec.a; pw.xh = sec.xh; pw.yh = sec.yh; pw.vxh = nullptr; pw.vyh = nullptr; pw.power = scratch->power;
+    const bool fresh = scratch->power_len != kLookChunk || scratch->power_section != section_index;
+    if (fresh) hipLaunchKernelGGL(k_scan_power, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, stream, pw);
+    int64_t done = 0;
+    int *err = (int *)((char *)scratch->zbuf + (zneed - 64));
+    rc2 = launch_look(sec, io, stream, scratch->power, scratch->zbuf, zneed - 64, err, &done, kernel_name);
+    if (rc2) return rc2;
+    if (fresh) {                      // (the matrix is valid whether or not the kernel took the block)
+      scratch->power_len = kLookChunk;
+      scratch->power_section = section_index;
+    }
+    if (done > 0) {
+      ALZ_HIP_CHECK(hipGetLastError());
+      *done_samples = done;
+      *kernel_name = "k_scan(k_look)";
+      return ALZ_OK;
+    }
+  }
   // chunk length: a multiple of the longest tile (64 samples); by default short enough that
   // chunks x channels fill the chip (>= 65536 lanes: one 64-lane wave per SIMD)
   int64_t L = chunk_len;

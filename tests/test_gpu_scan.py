@@ -127,3 +127,37 @@ def test_cascade_sections_one_after_the_other(alz, oracle):
   assert bank.last_kernel.count("k_scan") == 2, bank.last_kernel
   ref = oracle.bank([3, 3], [3, 3], np.concatenate([b, b[::-1]], 1), np.concatenate([a, a[::-1]], 1), x)
   assert norm_err(y, ref, 0) <= 1e-8
+
+
+@pytest.mark.parametrize("C,n,pattern", [(512, 1 << 16, "resonator"), (64, 8 * 512, "resonator"), (48, 5 * 512 + 100, "lowpass2"),
+                                          (1024, 1 << 14, "biquad"), (16, 1 << 15, "onepole")])
+def test_one_pass_mode(alz, oracle, C, n, pattern):
+  """Time-major blocks in the time-parallel mode take the ONE-pass kernel (k_look: 512-sample chunks resident in LDS,
+  chunk states through global memory): every chunk boundary, worker counts from 2 to 16 per channel group, a ragged
+  tail, the state left for the next block."""
+  import torch
+  rng = np.random.default_rng(C + n)
+  if pattern == "resonator":
+    b, a = resonators(4096)
+    pick = np.linspace(0, 4095, C).astype(int)
+    b, a, nb, na = b[pick].copy(), a[pick].copy(), 3, 3
+  elif pattern == "lowpass2":
+    pole = rng.uniform(0.5, 0.999, C)
+    b, a, nb, na = ((1 - pole) ** 2)[:, None], np.stack([np.ones(C), -2 * pole, pole * pole], axis=1), 1, 3
+  elif pattern == "biquad":
+    r, w = rng.uniform(0.8, 0.9995, C), rng.uniform(0.01, 3.0, C)
+    b = rng.uniform(-1, 1, (C, 3))
+    a, nb, na = np.stack([np.ones(C), -2 * r * np.cos(w), r * r], axis=1), 3, 3
+  else:
+    pole = rng.uniform(0.5, 0.9999, C)
+    b, a, nb, na = (1 - pole)[:, None], np.stack([np.ones(C), -pole], axis=1), 1, 2
+  x = rng.uniform(-1, 1, (n, C))
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(True)
+  bank.reset()
+  y = bank.process(torch.from_numpy(x).cuda(), layout="time").cpu().numpy()
+  assert "k_look" in bank.last_kernel, bank.last_kernel
+  x2 = rng.uniform(-1, 1, (4 * 512 + 3, C))
+  ref = oracle.bank([nb], [na], b, a, np.concatenate([x, x2]), layout="time")
+  assert norm_err(y, ref[:n], 0) <= 1e-8
+  y2 = bank.process(torch.from_numpy(x2).cuda(), layout="time").cpu().numpy()
+  assert norm_err(y2, ref[n:], 0) <= 1e-8
