@@ -377,9 +377,11 @@ class FilterBank(object):
     """Opt into the time-parallel mode for narrow banks (alz_bank_set_time_parallel): the time axis
     of every block is cut into chunks that run side by side (zero-state pass, propagation of the
     chunk states, replay).  ``chunk``: True / -1 = chunk length chosen by the engine, False / 0 =
-    off, a positive int = samples per chunk.  Not bit-identical to the reference (the contract's
-    1e-6 with orders of magnitude to spare); off by default."""
-    n = -1 if chunk is True else 0 if not chunk else int(chunk)
+    off, a positive int = samples per chunk, "one-pass" / -2 = the one-pass form (512-sample chunks
+    resident in LDS: the block is read once; single biquad-class sections on time-major blocks).
+    Not bit-identical to the reference (the contract's 1e-6 with orders of magnitude to spare); off
+    by default."""
+    n = -2 if chunk == "one-pass" else -1 if chunk is True else 0 if not chunk else int(chunk)
     _ffi.check(self._L.alz_bank_set_time_parallel(self._h, n))
     self._time_parallel = n
     return self

@@ -530,7 +530,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       if (h->time_parallel != 0 && whole && !generic) {
         // opt-in time-parallel mode: whole chunks of the whole bank; the ragged rest continues
         // serially from the state the replay pass left
-        rc = alz::launch_scan(sec, s, io, st, h->time_parallel < 0 ? 0 : h->time_parallel, &h->scan[(size_t)s],
+        rc = alz::launch_scan(sec, s, io, st, h->time_parallel == ALZ_TP_AUTO ? 0 : h->time_parallel, &h->scan[(size_t)s],
                               &done_n, &name);
         if (rc) return rc;
         if (done_n > 0) done_c = c_count;
@@ -758,7 +758,8 @@ int alz_bank_set_input_map(alz_bank_t *h, int op) {
 
 int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len) {
   if (!h) return fail(ALZ_E_ARG, "NULL handle");
-  if (chunk_len < -1) return fail(ALZ_E_ARG, "chunk length must be -1 (automatic), 0 (off) or positive");
+  if (chunk_len < ALZ_TP_ONE_PASS)
+    return fail(ALZ_E_ARG, "chunk length must be -2 (one pass), -1 (automatic), 0 (off) or positive");
   h->time_parallel = chunk_len;
   return ALZ_OK;
 }

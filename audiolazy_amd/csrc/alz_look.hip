@@ -6,24 +6,33 @@
 // in LDS between the two uses (512 samples x 16 channels = 64 KiB), so the block is read ONCE:
 //
 //   * a workgroup owns 16 channels and every W-th chunk of them (W workgroups per channel group, all resident);
-//     three waves pipeline over 64-sample tiles with one barrier per tile, as k_duo does:
+//     two waves pipeline over 64-sample tiles with one barrier per tile, as k_duo does:
 //       AUX  queues the tile DMA (global_load_lds) into a ring of 16 tile slots, turns a landed tile into
 //            feed-forward sums p[n] IN PLACE, and stores finished tiles;
-//       ZS   runs the recurrence over p from a ZERO state, one chunk + 2 tiles ahead of REC, only for the chunk's
-//            end state z_j, which it publishes in global memory (64-bit agent-scope atomic stores into an array
-//            pre-filled with a NaN pattern no computation produces: no flags, no fences);
-//       REC  runs the recurrence from the TRUE state and overwrites p with y.
-//   * the true state of chunk j needs no other workgroup's replay: REC keeps the exact end state of its own previous
-//     chunk j - W and applies  S <- M S + z  for the W - 1 chunks in between (M = A^L per channel, the matrix
-//     alz_scan.hip caches; z_{j-W+1} .. z_{j-1} from the other workgroups' ZS waves, which run a chunk ahead).
-//     Waits only ever point to smaller chunk indices, and every workgroup of the launch is resident (<= one per
-//     CU): no deadlock; a bounded spin guards against the impossible.
+//       the recurrence wave runs BOTH passes in its 64 lanes -- 16 channels x 2 roles x 2 skewed copies:
+//            ZS lanes  the recurrence over p from a ZERO state, a chunk and three tiles ahead, only for the chunk's
+//                      end state z_j, which they publish in global memory (64-bit agent-scope atomic stores into an
+//                      array pre-filled with a NaN pattern no computation produces: no flags, no fences);
+//            REC lanes the recurrence from the TRUE state, overwriting p with y.
+//   * the true state of chunk j needs no other workgroup's replay: it is chained in zero-state space,
+//     S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}   (M = A^L per channel, the matrix alz_scan.hip
+//     caches), from the workgroup's own previous start state and the z of the W chunks in between, fetched by four
+//     1 KiB global -> LDS transfers two tiles before the replay needs them.  Waits only ever point to smaller
+//     chunk indices and earlier intervals, and every workgroup of the launch is resident (one per CU): no deadlock;
+//     a bounded spin guards against the impossible.
+//
+// What was measured on the way (profiles/NOTES_r03.md 7): a third wave for the zero-state pass slowed the replay wave
+// by 15 %; run-time role / chunk-start tests inside the 64 steps made it 52 cycles per step; chunk states loaded into
+// registers made the compiler wait for them on the spot.  This form: 214 Gsamples/s at 512 channels x 2^20 with
+// 16 B/sample of HBM traffic, against 228 with 24 B/sample for the three-launch form -- hence an option
+// (ALZ_TP_ONE_PASS), not the default.
 //
 // Every output sample is still the reference's DF-I statement (lazy_filters.py:197-257) in the kernels' own order;
 // only the chunk-start states carry a different rounding -- the same numerics as the three-launch mode (1e-10 ..
 // 1e-9 on the configs[1] resonators).  Time-major blocks, a0 == 1, channels % 16 == 0, blocks of whole 512-sample
 // chunks; everything else stays on the three-launch mode.
 #include "alz_common.h"
+#include <type_traits>
 
 namespace alz {
 
@@ -35,6 +44,12 @@ constexpr int kSlots = 2 * kNT;              // tile slots in LDS
 constexpr int kSlot = 8192 + kChunks * 16;   // a tile in the DMA layout (16 bytes of pad per 1 KiB chunk)
 constexpr int kHist = 256;                   // the two rows before a tile: [2][16] doubles
 constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (hipMemset 0xFF)
+constexpr int kMaxW = 16;                    // workgroups per channel group (the predecessors' states live in registers)
+#ifdef ALZ_ABLATE
+#define ALZ_LOOK_CAP(p) ((p).dbg ? 1 : kSpinCap)      // (an ablated run publishes nothing: do not wait for it)
+#else
+#define ALZ_LOOK_CAP(p) kSpinCap
+#endif
 constexpr int kSpinCap = 1 << 18;            // ~0.1 s: three orders of magnitude beyond any legitimate wait
 
 struct LArgs {
@@ -50,6 +65,8 @@ struct LArgs {
   const double *power;         // M = A^512 per channel: [4][channels] (M11 M12 M21 M22)
   unsigned long long *z;       // [groups][n_chunks][2][16] published zero-state end states
   int *err;                    // set when a spin ran into its cap
+  int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no recurrence
+                               // wave arithmetic, 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -65,6 +82,20 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// the same with agent-scope coherence (sc1: the data was written by another XCD's atomic stores, L2s are per XCD)
+__device__ __forceinline__ void dma16_coherent(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off sc1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
@@ -72,15 +103,80 @@ __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
 
 }  // namespace
 
+// One 64-sample tile of the recurrence wave.  Its 64 lanes are 16 channels x 2 ROLES x 2 skewed copies:
+//   lanes  0..31  REC: the replay from the true state, tile t - lag, overwrites p with y;
+//   lanes 32..63  ZS:  the zero-state pass, tile t (a chunk and three tiles ahead), writes nothing that is kept.
+// The two passes are the same instruction stream on different tiles, so the zero-state pass rides in lanes that
+// k_duo's recurrence wave spends on ghost copies (it keeps four skewed copies so that one ds_write_b64 stores four
+// rows; here two copies, one write per two rows) -- a separate ZS wave slowed the replay wave by 15 % (LDS / issue
+// contention on the CU, ablations in profiles/NOTES_r03.md) and its branches cost more.
+//   cur     the lane's column in ITS tile slot, minus its skew (row r of the lane = cur + (r + q) * 128)
+//   wr      where the lane stores: cur for the REC lanes, a dummy slot for the ZS lanes (EXEC stays full)
+//   start   CS instantiation: this lane's tile opens a chunk -> the lane switches to (s1, s2) at its step q
+//   kp      p of the previous tile's last row (the lagging copy's first step); updated for the next tile
+struct LookState { double m1, m2, t2, kp; };
+template <unsigned PA, bool CS>
+__device__ __forceinline__ LookState look_tile(const char *cur, char *wr, int q, bool start, double s1, double s2,
+                                               double na1, double na2, LookState st) {
+  constexpr int T = 64, kStep = 128, NCH = T / 8;
+  double m1 = st.m1, m2 = st.m2, t2 = st.t2;
+  // this tile's last p row, for the lagging copy's first step of the NEXT tile (REC overwrites it)
+  const double nk = *reinterpret_cast<const double *>(cur + (q + T - 1) * kStep);
+  double pr[3][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double v = *reinterpret_cast<const double *>(cur + (u < q ? q : u) * kStep);
+    pr[0][u] = (u == 0 && q == 1) ? st.kp : v;           // (row -1 of the lagging copy: the previous tile's last row)
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    if (k + 2 < NCH) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if constexpr (CS) {
+        if (k == 0 && u <= 1) {
+          // row 0 of the chunk is this copy's step q: (re)start from the chunk's initial state there
+          const bool now = start && u == q;
+          m1 = now ? s1 : m1;
+          m2 = now ? s2 : m2;
+          t2 = now ? na2 * s2 : t2;
+        }
+      }
+      double acc = pr[k % 3][u];
+      double t2n = 0.0;
+      if constexpr (PA == 3u) {
+        const double t1 = na1 * m1;
+        t2n = na2 * m1;
+        acc = (acc + t1) + t2;
+      } else {
+        if constexpr (PA & 1u) acc = acc + na1 * m1;
+        if constexpr (PA & 2u) acc = acc + na2 * m2;
+      }
+      m2 = m1;
+      m1 = acc;
+      t2 = t2n;
+      if ((u & 1) == 1) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;   // rows u - 1 (copy 1), u (copy 0)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return LookState{m1, m2, t2, nk};
+}
+
 template <unsigned PB, unsigned PA>
-__global__ __launch_bounds__(192) void k_look(LArgs p) {
+__global__ __launch_bounds__(128) void k_look(LArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64, NT = kNT;
   constexpr int kStep = G * 8;
   // pipeline offsets, in tiles of this workgroup's own tile sequence (see the header): at interval i
   //   AUX stores tile i - kRecLag - 1, queues the DMA of tile i + kDmaLead, prepares tile i + 1,
   //   ZS works on tile i, REC on tile i - kRecLag
-  constexpr int kRecLag = NT + 2, kDmaLead = 4;
+  constexpr int kRecLag = NT + 3, kDmaLead = 3;
   static_assert(kSlots >= kRecLag + 1 + kDmaLead + 1, "a slot is stored before it is refilled");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -94,7 +190,8 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   const int64_t TOT = my_chunks * NT;
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
-  char *exch = hist + kSlots * kHist;                         // [2][16] doubles: REC's end state, group 0 -> all groups
+  char *dummy = hist + kSlots * kHist;                        // one tile slot nobody reads: the ZS lanes' stores, idle roles' tiles
+  char *zlds = dummy + kSlot;                                 // [kMaxW][2][16] doubles: the requested chunk end states
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int lane_off = cl * 8;
 #define ALZ_EOFF(u) ((u) * G * 8 + (((u) * G) >> 7) * 16)
@@ -191,16 +288,16 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     const int64_t n_iv = TOT + kRecLag + 2;
     for (int64_t i = 0; i < n_iv; ++i) {
       const int64_t ts = i - kRecLag - 1;
-      if (ts >= 0 && ts < TOT) store_tile(ts);
-      if (i + kDmaLead < TOT) queue_tile(i + kDmaLead);
+      if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) store_tile(ts);
+      if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
       if (i + 1 < TOT) {
-        // issued after tile i + 1's transfers: three more tiles (9 each) and the stores of the last three intervals
+        // issued after tile i + 1's transfers: two more tiles (9 each) and the stores of the last two intervals
         // (8 each, once tiles are being stored); the last tiles of the sequence simply wait for everything
+        static_assert(kDmaLead == 3, "the counts below");
         if (i + kDmaLead < TOT) {
-          if (ts >= 2) asm volatile("s_waitcnt vmcnt(51)" ::: "memory");
-          else if (ts == 1) asm volatile("s_waitcnt vmcnt(43)" ::: "memory");
-          else if (ts == 0) asm volatile("s_waitcnt vmcnt(35)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+          if (ts >= 1) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+          else if (ts == 0) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -209,127 +306,99 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
           if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
           if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
         }
-        prepare_tile(i + 1);
+        if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    // ------------------------------ ZS (wave 2) and REC (wave 0): the recurrence ------------------------------
-    const bool is_rec = wave == 0;
+    // ------------------------------ the recurrence wave: REC lanes 0..31, ZS lanes 32..63 ------------------------------
+    const int role = lane >> 5, rq = (lane >> 4) & 1;        // role 0 REC / 1 ZS; copy rq lags rq steps
     double na1 = 0, na2 = 0;
     if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
     if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
     const double m11 = p.power[0 * p.channels + c], m12 = p.power[1 * p.channels + c];
     const double m21 = p.power[2 * p.channels + c], m22 = p.power[3 * p.channels + c];
-    double base1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;      // REC: the state its next chunk is derived from
-    double base2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;      // (the bank's state, then its own end states)
-    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(base1), "+v"(base2));
-    double m1 = 0.0, m2 = 0.0, t2 = 0.0;
+    // S: the true state at the start of this workgroup's chunks, advanced in zero-state space --
+    // S_c = M ( ... M (M S_{c-W} + z_{c-W}) + z_{c-W+1} ... ) + z_{c-1} -- from the states every workgroup's ZS lanes
+    // publish; the first chunk starts the chain from the bank's state
+    double S1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
+    double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(S1), "+v"(S2));
+    LookState st = {0.0, 0.0, 0.0, 0.0};
     bool gave_up = false;
-    double kp0 = 0.0, kp1 = 0.0, kp2 = 0.0;                  // p of the previous tile's rows T-3, T-2, T-1 (lagging groups)
-    const int lag = is_rec ? kRecLag : 0;
+    // z of the chunks between this workgroup's previous chunk and its next one: requested ALL AT ONCE, two tiles
+    // before the replay needs the state, as four 1 KiB global -> LDS transfers the compiler does not know about (loads
+    // into registers made it wait for them on the spot: one exposed memory round trip per chunk, 20 % of the run)
+    int64_t req_first = 0;
+    int req_cnt = 0;
     const int64_t n_iv = TOT + kRecLag + 2;
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < n_iv; ++i) {
-      const int64_t t = i - lag;                             // the tile this wave works on
-      if (t >= 0 && t < TOT) {
-        char *cur = smem + (int)(t % kSlots) * kSlot + lane_off - q * kStep;
-        const bool chunk_start = (t % NT) == 0;
-        double s1 = 0.0, s2 = 0.0;                           // the state row 0 of a new chunk starts from
-        if (chunk_start && is_rec) {
-          // true state of chunk j: S <- M S + z over the chunks between the base state and j
-          const int64_t seq = t / NT, j = (int64_t)w + seq * W;
-          if (seq > 0) {                                     // base = this wave's own end state of chunk j - W (group 0 has it)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            base1 = *reinterpret_cast<const double *>(exch + cl * 8);
-            base2 = *reinterpret_cast<const double *>(exch + 128 + cl * 8);
-          }
-          const int64_t first = seq > 0 ? j - W + 1 : 0;     // z_first .. z_{j-1}
-          s1 = base1; s2 = base2;
-          for (int64_t jj = first; jj < j; ++jj) {
-            unsigned long long v1 = kSentinel, v2 = kSentinel;
-            const unsigned long long *src = zg + jj * 32 + cl;
-            int spins = gave_up ? kSpinCap : 0;
-            while (spins < kSpinCap) {
-              v1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              v2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (v1 != kSentinel && v2 != kSentinel) break;
-              ++spins;
-              __builtin_amdgcn_s_sleep(8);
+      const int64_t t_r = i - kRecLag, t_z = i;
+      const bool act_r = t_r >= 0 && t_r < TOT, act_z = t_z < TOT;
+      // two tiles before a REC chunk starts: ask for the states its start state is chained from
+      if (t_r + 2 >= 0 && t_r + 2 < TOT && ((t_r + 2) % NT) == 0 && !ALZ_DBG(p, 32)) {
+        const int64_t seq = (t_r + 2) / NT, cj = (int64_t)w + seq * W;
+        req_first = seq > 0 ? cj - W : 0;                    // z_first .. z_{cj-1}
+        req_cnt = (int)(cj - req_first);
+#pragma unroll
+        for (int o = 0; o < kMaxW / 4; ++o) {                // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
+          int64_t ch = req_first + 4 * o + (lane >> 4);
+          if (ch > K - 1) ch = K - 1;                        // (beyond the request: any valid address, never read)
+          dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
+        }
+      }
+      if ((act_r || act_z) && !ALZ_DBG(p, 2)) {
+        const bool cs_r = act_r && (t_r % NT) == 0, cs_z = act_z && (t_z % NT) == 0;
+        if (cs_r && !ALZ_DBG(p, 32)) {
+          // the state the replay of this chunk starts from (the transfers were queued two intervals ago; this wave's
+          // only other vector-memory operations are the few stores below)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int e = 0; e < kMaxW; ++e) {
+            if (e < req_cnt) {
+              const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
+              unsigned long long a1 = zl[0], a2 = zl[16];
+              if (a1 == kSentinel || a2 == kSentinel) {        // not published when the transfer read it (rare): poll
+                const unsigned long long *src = zg + (req_first + e) * 32 + cl;
+                int spins = gave_up ? kSpinCap : 0;
+                do {
+                  a1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  a2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (a1 != kSentinel && a2 != kSentinel) break;
+                  __builtin_amdgcn_s_sleep(8);
+                } while (++spins < ALZ_LOOK_CAP(p));
+                if (a1 == kSentinel || a2 == kSentinel) { *p.err = 1; a1 = 0; a2 = 0; gave_up = true; }
+              }
+              const double z1 = __longlong_as_double((long long)a1), z2 = __longlong_as_double((long long)a2);
+              const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
+              const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
+              S1 = n1; S2 = n2;
             }
-            if (spins >= kSpinCap) { *p.err = 1; v1 = 0; v2 = 0; gave_up = true; }   // (results are garbage from here on; no further waits)
-            const double z1 = __longlong_as_double((long long)v1), z2 = __longlong_as_double((long long)v2);
-            const double n1 = __builtin_fma(m11, s1, __builtin_fma(m12, s2, z1));
-            const double n2 = __builtin_fma(m21, s1, __builtin_fma(m22, s2, z2));
-            s1 = n1; s2 = n2;
           }
         }
-        // this tile's last three p rows, for the lagging groups' first steps of the NEXT tile (REC overwrites them)
-        const double nk0 = *reinterpret_cast<const double *>(cur + (q + T - 3) * kStep);
-        const double nk1 = *reinterpret_cast<const double *>(cur + (q + T - 2) * kStep);
-        const double nk2 = *reinterpret_cast<const double *>(cur + (q + T - 1) * kStep);
-        constexpr int NCH = T / 8;
-        double pr[3][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const double v = *reinterpret_cast<const double *>(cur + (u < q ? q : u) * kStep);
-          const int jx = u + 3 - q;                          // (u < q: row T + u - q of the previous tile)
-          pr[0][u] = (u < 3 && u < q) ? (jx <= 0 ? kp0 : jx == 1 ? kp1 : kp2) : v;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          if (k + 2 < NCH) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (k == 0 && u <= 3 && chunk_start) {
-              // row 0 of the chunk is this lane group's step q: (re)start from the chunk's initial state there;
-              // at the very start of the stream the lagging groups have nothing to do before that step
-              const bool start = u == q;
-              m1 = start ? s1 : m1;
-              m2 = start ? s2 : m2;
-              t2 = start ? na2 * s2 : t2;
-            }
-            double acc = pr[k % 3][u];
-            double t2n = 0.0;
-            if constexpr (PA == 3u) {
-              const double t1 = na1 * m1;
-              t2n = na2 * m1;
-              acc = (acc + t1) + t2;
-            } else {
-              if constexpr (PA & 1u) acc = acc + na1 * m1;
-              if constexpr (PA & 2u) acc = acc + na2 * m2;
-            }
-            m2 = m1;
-            m1 = acc;
-            t2 = t2n;
-            if (is_rec && (u & 3) == 3) *reinterpret_cast<double *>(cur + (k * 8 + u) * kStep) = acc;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        kp0 = nk0; kp1 = nk1; kp2 = nk2;
-        if ((t % NT) == NT - 1 && q == 0) {
-          // group 0 has just finished the chunk: its (m1, m2) is the chunk's end state
-          const int64_t j = (int64_t)w + (t / NT) * W;
-          if (is_rec) {
-            *reinterpret_cast<double *>(exch + cl * 8) = m1;
-            *reinterpret_cast<double *>(exch + 128 + cl * 8) = m2;
-            if (j == K - 1) {                                // the bank's state after the block
-              if (p.na > 1) p.yh[0 * p.channels + c] = m1;
-              if (p.na > 2) p.yh[1 * p.channels + c] = m2;
-            }
-          } else {
-            __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(m1), __ATOMIC_RELAXED,
+        const int64_t t = role ? t_z : t_r;
+        const bool act = role ? act_z : act_r;
+        const char *cur = (act ? smem + (int)(t % kSlots) * kSlot : dummy) + lane_off - rq * kStep;
+        char *wr = ((act && role == 0) ? smem + (int)(t % kSlots) * kSlot : dummy) + lane_off - rq * kStep;
+        const bool start = role ? cs_z : cs_r;
+        const double s1 = role ? 0.0 : S1, s2 = role ? 0.0 : S2;
+        if (cs_r || cs_z) st = look_tile<PA, true>(cur, wr, rq, start, s1, s2, na1, na2, st);
+        else st = look_tile<PA, false>(cur, wr, rq, false, 0.0, 0.0, na1, na2, st);
+        if (rq == 0) {
+          // copy 0 has just finished its tile: at a chunk's last tile its (m1, m2) is the chunk's end state
+          if (role == 1 && act_z && (t_z % NT) == NT - 1) {
+            const int64_t j = (int64_t)w + (t_z / NT) * W;
+            __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(st.m1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(m2), __ATOMIC_RELAXED,
+            __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(st.m2), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (role == 0 && act_r && t_r == TOT - 1 && ((K - 1) % W) == w) {   // the bank's state after the block
+            if (p.na > 1) p.yh[0 * p.channels + c] = st.m1;
+            if (p.na > 2) p.yh[1 * p.channels + c] = st.m2;
           }
         }
       }
@@ -361,9 +430,14 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   if (C % 16 || io.c_first != 0 || io.c_count != C || io.x == io.y) return ALZ_OK;
   if ((((uintptr_t)io.x | (uintptr_t)io.y) & 15) || ((io.sxn | io.syn) & 1)) return ALZ_OK;
   const int64_t K = io.n / L, groups = C / 16;
-  int W = (int)(256 / groups);                               // every workgroup of the launch resident: one per CU
+  // every workgroup of the launch must be resident (one per CU: 137 KiB of LDS each)
+  int dev = 0, cus = 0;
+  ALZ_HIP_CHECK(hipGetDevice(&dev));
+  ALZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int W = (int)(cus / groups);
   if (W > K) W = (int)K;
-  if (W < 2 || groups > 128 || K < 4) return ALZ_OK;
+  if (W > kMaxW) W = kMaxW;
+  if (W < 2 || K < 4) return ALZ_OK;
   if ((uint64_t)groups * K * 32 * sizeof(double) > zbuf_bytes) return ALZ_OK;
   look_fn fn = pick_look(sec.present_b, sec.present_a);
   if (!fn) return ALZ_OK;
@@ -372,11 +446,13 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   p.n_inputs = io.mode == ALZ_BANK_OUTER ? io.n_inputs : 0; p.n_sets = io.n_sets; p.workers = W;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   p.power = power; p.z = (unsigned long long *)zbuf; p.err = err;
+  static const int dbg_env = ALZ_DBG_ENV();
+  p.dbg = dbg_env;
   ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
-  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + 256;
+  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + kSlot + (size_t)kMaxW * 256;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(192), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(128), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = K * L;
   *kernel_name = "k_look";

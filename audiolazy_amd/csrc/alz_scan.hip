@@ -134,9 +134,13 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (io.c_first != 0 || io.c_count != io.channels) return ALZ_OK;
   const int64_t C = io.channels;
   if (C % 16) return ALZ_OK;
-  // One pass where the shape allows it (time-major block, automatic chunk length): 512-sample chunks resident in
-  // LDS, the block read once (alz_look.hip); the three-launch form below takes everything else.
-  if (chunk_len <= 0 && sec.na > 1 && ALZ_TUNE("ALZ_LOOK", 1) && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
+  // chunk_len == ALZ_TP_ONE_PASS: one pass where the shape allows it (time-major block): 512-sample chunks resident
+  // in LDS, the block read once (alz_look.hip); the three-launch form below takes everything else.  Measured at 512
+  // channels x 2^20: 214 Gsamples/s with 16 B/sample of traffic against 228 with 24 (profiles/NOTES_r03.md): a
+  // choice for the caller (HBM shared with other work), not the default.
+  const bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
+  if (chunk_len < 0) chunk_len = 0;
+  if (one_pass && sec.na > 1 && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
     const int64_t groups = C / 16, Kl = io.n / kLookChunk;
     const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) + 64;
     uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;

@@ -399,14 +399,14 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
   if args.fused:
     bank.set_fused(True)
   if time_parallel is not None:
-    bank.set_time_parallel(True if time_parallel == 1 else time_parallel)
+    bank.set_time_parallel(True if time_parallel == 1 else "one-pass" if time_parallel == -2 else time_parallel)
   bank.reset()
   shape = (N, C) if args.layout == "time" else (C, N)
   x = ctx.noise(shape)
   y = torch.empty(shape, dtype=torch.float64, device=ctx.dev)
   elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout=args.layout, out=y), steps, warmup)
   kernel = bank.last_kernel
-  exact = not args.fused and not (time_parallel and "k_scan" in kernel)
+  exact = not args.fused and not (time_parallel and ("k_scan" in kernel or "k_look" in kernel))
   parity = "skipped (--no-parity-check)"
   if check and ctx.rank == 0 and not args.no_parity_check:
     # the WHOLE bank width on a fresh stream, against the oracle
@@ -861,10 +861,11 @@ def main():
                                                  "three coefficient series PER CHANNEL (rows of coefficients per sample: "
                                                  "40 B per channel-sample)")
         if hasattr(alz.FilterBank, "set_time_parallel"):
-          for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel")):
+          for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel"), (-2, "narrow512_time_parallel_one_pass")):
             r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
             secondary[key] = entry(r, 1, 5, "Gsamples/s", "one GPU's share of configs[1] sharded over 8: 512 channels "
-                                   "x 2^20 samples" + (", time-parallel kernel (opt-in, not bit-exact)" if mode else ""))
+                                   "x 2^20 samples" + (", time-parallel mode (opt-in, not bit-exact)" if mode else "")
+                                   + (", ONE-pass form: chunks resident in LDS, 16 B of traffic per sample instead of 24" if mode == -2 else ""))
       elif args.scaling == "weak" and C % world == 0:
         from audiolazy_amd.sharding import shard_range
         lo, hi = shard_range(C, world, rank)

@@ -132,9 +132,9 @@ def test_cascade_sections_one_after_the_other(alz, oracle):
 @pytest.mark.parametrize("C,n,pattern", [(512, 1 << 16, "resonator"), (64, 8 * 512, "resonator"), (48, 5 * 512 + 100, "lowpass2"),
                                           (1024, 1 << 14, "biquad"), (16, 1 << 15, "onepole")])
 def test_one_pass_mode(alz, oracle, C, n, pattern):
-  """Time-major blocks in the time-parallel mode take the ONE-pass kernel (k_look: 512-sample chunks resident in LDS,
-  chunk states through global memory): every chunk boundary, worker counts from 2 to 16 per channel group, a ragged
-  tail, the state left for the next block."""
+  """The one-pass form of the time-parallel mode (k_look: 512-sample chunks resident in LDS, the zero-state pass in the
+  recurrence wave's spare lanes, chunk states through global memory): every chunk boundary, worker counts from 2 to
+  16 per channel group, a ragged tail, the state left for the next block."""
   import torch
   rng = np.random.default_rng(C + n)
   if pattern == "resonator":
@@ -152,7 +152,7 @@ def test_one_pass_mode(alz, oracle, C, n, pattern):
     pole = rng.uniform(0.5, 0.9999, C)
     b, a, nb, na = (1 - pole)[:, None], np.stack([np.ones(C), -pole], axis=1), 1, 2
   x = rng.uniform(-1, 1, (n, C))
-  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(True)
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
   bank.reset()
   y = bank.process(torch.from_numpy(x).cuda(), layout="time").cpu().numpy()
   assert "k_look" in bank.last_kernel, bank.last_kernel
