@@ -504,7 +504,7 @@ def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
   tf = flops / (k_ms * 1e-3) / 1e12
   roof = {"bound": "valu_f64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": tf / FP64_PEAK_TFLOPS, "traffic": None, "kernel_ms_avg": k_ms,
-          "algorithmic_flops_per_launch": flops,
+          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * C * N,
           "hbm_GBps": ALG_BYTES_PER_SAMPLE * C * N / (k_ms * 1e-3) / 1e9}
   if not fused:
     roof["note"] = ("bit-exact mode: separately rounded v_mul_f64 + v_add_f64, two instructions per tap, so at "
@@ -722,9 +722,36 @@ def wl_collective(ctx, args, C, n):
           "collectives": out}
 
 
-def entry(res, world, steps, unit, workload):
+_PMC = None
+
+
+def fill_traffic(roof, key):
+  """roofline.traffic from the committed per-workload PMC table (profiles/r03_pmc_traffic_table.json), scaled to this
+  launch's algorithmic bytes; labelled as what it is: measured by rocprofv3 in separate runs, not inside this one."""
+  global _PMC
+  if _PMC is None:
+    try:
+      _PMC = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_table.json")))["workloads"]
+    except (OSError, KeyError, ValueError):
+      _PMC = {}
+  row = _PMC.get(key)
+  if not row:
+    return
+  alg = roof.get("algorithmic_bytes_per_launch")
+  if not alg:
+    return
+  roof["traffic"] = row["traffic_over_algorithmic"] * alg
+  roof["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                            "(profiles/r03_pmc_traffic_table.json, key %r): x%.4f of algorithmic%s"
+                            % (key, row["traffic_over_algorithmic"], "" if row.get("fetch_correction") == 2.0 else
+                               " (8 B/lane reads: FETCH_SIZE uncalibrated)"))
+
+
+def entry(res, world, steps, unit, workload, key=None):
   """A secondary-workload record: same fields as the main line's core."""
   roof = dict(res["roofline"])
+  if key:
+    fill_traffic(roof, key)
   # the same fraction priced on the wall time of a step (launch gaps included), next to the kernel-time one
   roof["frac_from_ms_per_step"] = roof["frac"] * roof["kernel_ms_avg"] / (res["elapsed"] / steps * 1e3)
   return {"workload": workload, "value": world * res["units"] * steps / res["elapsed"] / 1e9, "unit": unit,
@@ -754,6 +781,8 @@ def main():
   ap.add_argument("--time-parallel", type=int, default=None,
                   help="force the time-parallel (chunked state propagation) kernel on (1) / off (0) for the "
                        "biquad bank; default: the engine's own choice (bit-exact kernels)")
+  ap.add_argument("--lpc-exact", action="store_true", help="--workload lpc: the bit-identical path (ALZ_LPC_DENSE)")
+  ap.add_argument("--lpc-frames", type=int, default=65536, help="--workload lpc: frames per launch")
   ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                   help="process-group backend for N > 1 (nccl = RCCL; gloo lets tests run several ranks on one GPU)")
   ap.add_argument("--init-dist", action="store_true",
@@ -806,66 +835,59 @@ def main():
               "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
-    # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the figure
-    # is the committed rocprofv3 --pmc measurement of this kernel (tools/pmc_traffic.py), scaled
-    try:
-      pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-      if pmc["kernel"].split("<")[0] in res["kernel"]:
-        roof["traffic"] = pmc["traffic_over_algorithmic"] * roof["algorithmic_bytes_per_launch"]
-        roof["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the "
-                                  "same kernel at %s-sample blocks (%s), x%.5f of algorithmic"
-                                  % (pmc.get("block_samples", "?"), pmc.get("file", "profiles/pmc_traffic.json"),
-                                     pmc["traffic_over_algorithmic"]))
-    except (OSError, KeyError, ValueError):
-      pass
+    # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the figures are the
+    # committed rocprofv3 --pmc measurements of the same workloads (tools/pmc_workloads.sh -> pmc_table.py)
+    if (C, N) == (4096, 1 << 20) and args.layout == "time" and not args.fused and not args.time_parallel:
+      fill_traffic(roof, "headline")
     if not args.no_secondary and (C, N) == (4096, 1 << 20):
       if world == 1:
         r = wl_fir(ctx, args, alz, 8192, 1 << 18, 5, 1, fused=False)
         secondary["fir256_bit_exact"] = entry(r, 1, 5, "Gsamples/s", "configs[2]: 256-tap FIR lowpass (Hamming-"
-                                              "windowed sinc, shared taps) x 8192 channels x 2^18 samples, float64")
+                                              "windowed sinc, shared taps) x 8192 channels x 2^18 samples, float64", key="fir256_bit_exact")
         r = wl_fir(ctx, args, alz, 8192, 1 << 18, 5, 1, fused=True)
-        secondary["fir256_fma"] = entry(r, 1, 5, "Gsamples/s", "configs[2] in the opt-in FMA mode (alz_bank_set_fused)")
+        secondary["fir256_fma"] = entry(r, 1, 5, "Gsamples/s", "configs[2] in the opt-in FMA mode (alz_bank_set_fused)", key="fir256_fma")
         r = wl_gammatone(ctx, args, alz, 10, 2)
         secondary["gammatone"] = entry(r, 1, 10, "Gsamples/s", "configs[3]: ERB gammatone filterbank (gammatone.slaney), "
-                                       "256 bands x 64 input streams per GPU (512 over 8), 2^16-sample blocks")
+                                       "256 bands x 64 input streams per GPU (512 over 8), 2^16-sample blocks", key="gammatone")
         r = wl_gammatone(ctx, args, alz, 10, 2, fused=True)
-        secondary["gammatone_fma"] = entry(r, 1, 10, "Gsamples/s", "configs[3] in the opt-in FMA mode (alz_bank_set_fused)")
+        secondary["gammatone_fma"] = entry(r, 1, 10, "Gsamples/s", "configs[3] in the opt-in FMA mode (alz_bank_set_fused)", key="gammatone_fma")
         r = wl_gammatone(ctx, args, alz, 10, 2, streams=1, log2n=20)
         secondary["gammatone_one_stream"] = entry(r, 1, 10, "Gsamples/s", "the reference's own shape of configs[3]: 256 bands "
-                                                  "on ONE stream x 2^20 samples (input expanded to a column per band, k_expand)")
+                                                  "on ONE stream x 2^20 samples (input expanded to a column per band, then the sections as a pipeline over chunks of the time axis)", key="gammatone_one_stream")
         r = wl_gammatone(ctx, args, alz, 10, 2, streams=1, log2n=20, time_parallel=True)
-        secondary["gammatone_one_stream_time_parallel"] = entry(r, 1, 10, "Gsamples/s", "same, opt-in time-parallel mode")
+        secondary["gammatone_one_stream_time_parallel"] = entry(r, 1, 10, "Gsamples/s", "same, opt-in time-parallel mode", key="gammatone_one_stream_time_parallel")
         r = wl_lpc(ctx, args, alz, 20, 3)
         secondary["lpc"] = entry(r, 1, 20, "Gframes/s", "configs[4]: lpc.kautocor order 16 on 65536 concurrent "
-                                 "480-sample frames")
+                                 "480-sample frames", key="lpc")
         r = wl_lpc(ctx, args, alz, 20, 3, exact=True)
         secondary["lpc_bit_identical"] = entry(r, 1, 20, "Gframes/s", "configs[4] with the reference's dense Levinson-Durbin "
-                                               "(ALZ_LPC_DENSE), one launch: coefficients and error bit-identical on every frame")
+                                               "(ALZ_LPC_DENSE), one launch: coefficients and error bit-identical on every frame", key="lpc_bit_identical")
         r = wl_lpc(ctx, args, alz, 20, 3, fused=True)
         secondary["lpc_fma"] = entry(r, 1, 20, "Gframes/s", "configs[4] with fused multiply-adds in the autocorrelation "
-                                     "sums (opt-in ALZ_LPC_FUSED; not pinned to the last bit)")
+                                     "sums (opt-in ALZ_LPC_FUSED; not pinned to the last bit)", key="lpc_fma")
         r = wl_lpc(ctx, args, alz, 5, 1, frames=1 << 20)
         secondary["lpc_1m"] = entry(r, 1, 5, "Gframes/s", "configs[4] as a 2^20-frame batch (SURVEY.md 8d: a bandwidth fraction "
-                                    "that is not dominated by the 65536-frame launch): 4 GB of signal per launch")
+                                    "that is not dominated by the 65536-frame launch): 4 GB of signal per launch", key="lpc_1m")
         r = wl_lpc(ctx, args, alz, 5, 1, exact=True, frames=1 << 20)
-        secondary["lpc_1m_bit_identical"] = entry(r, 1, 5, "Gframes/s", "the same batch through the bit-identical path")
+        secondary["lpc_1m_bit_identical"] = entry(r, 1, 5, "Gframes/s", "the same batch through the bit-identical path", key="lpc_1m_bit_identical")
         r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
         secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
-                                          "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel")
+                                          "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel", key="envelope_abs")
         r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1)
         secondary["timevar_shared"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples "
                                             "steered by three coefficient series shared by the channels (Stream coefficients, "
-                                            "lazy_filters.py:197-224)")
+                                            "lazy_filters.py:197-224)", key="timevar_shared")
         r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1, per_channel=True)
         secondary["timevar_per_channel"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples, "
                                                  "three coefficient series PER CHANNEL (rows of coefficients per sample: "
-                                                 "40 B per channel-sample)")
+                                                 "40 B per channel-sample)", key="timevar_per_channel")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel"), (-2, "narrow512_time_parallel_one_pass")):
             r = wl_biquad(ctx, args, alz, 512, N, 0, 4096, 5, 1, check=True, time_parallel=mode)
             secondary[key] = entry(r, 1, 5, "Gsamples/s", "one GPU's share of configs[1] sharded over 8: 512 channels "
                                    "x 2^20 samples" + (", time-parallel mode (opt-in, not bit-exact)" if mode else "")
-                                   + (", ONE-pass form: chunks resident in LDS, 16 B of traffic per sample instead of 24" if mode == -2 else ""))
+                                   + (", ONE-pass form: chunks resident in LDS, 16 B of traffic per sample instead of 24" if mode == -2 else ""),
+                                   key=key)
       elif args.scaling == "weak" and C % world == 0:
         from audiolazy_amd.sharding import shard_range
         lo, hi = shard_range(C, world, rank)
@@ -919,7 +941,7 @@ def main():
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   else:
-    res = wl_lpc(ctx, args, alz, args.steps, args.warmup, fused=args.fused)
+    res = wl_lpc(ctx, args, alz, args.steps, args.warmup, fused=args.fused, exact=args.lpc_exact, frames=args.lpc_frames)
     total_units = float(world) * res["units"]
     metric, unit = "Gframes/s through lpc.kautocor (autocorrelation + Levinson-Durbin, order 16, 10 ms frames)", "Gframes/s"
     config = {"workload": "configs[4]: lazy_lpc order-16 on %d concurrent 480-sample frames, float64" % res["F"],

@@ -1,0 +1,37 @@
+#!/bin/bash
+# HBM traffic of every workload bench.py reports, by rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
+# kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes): one run per workload and counter, the
+# counter summed over this library's kernels and divided by the number of steps.  Output: gpurun_out/<tag>/pmc_*.json,
+# merged by tools/pmc_table.py into profiles/r03_pmc_traffic_table.json.
+#   usage: tools/pmc_workloads.sh <tag>
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$1
+mkdir -p $O
+export TMPDIR=/tmp
+COMMON="--no-cpu-baseline --no-secondary --no-parity-check --steps 3 --warmup 1"
+run() {  # key, bench args
+  key=$1; shift
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    cd /tmp
+    timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/raw_${key}_$ctr -o p -- python $R/bench.py $COMMON "$@" > $O/raw_${key}_$ctr.log 2>&1
+    python $R/tools/pmc_sum.py $O/raw_${key}_$ctr $ctr 4 > $O/pmc_${key}_$ctr.json 2>> $O/errors.log
+    rm -rf $O/raw_${key}_$ctr
+  done
+  echo "$key: $(cat $O/pmc_${key}_FETCH_SIZE.json | head -c 200)"
+}
+run headline
+run fir256_bit_exact --workload fir
+run fir256_fma --workload fir --fused
+run gammatone --workload gammatone
+run gammatone_one_stream --workload gammatone --streams 1
+run gammatone_one_stream_time_parallel --workload gammatone --streams 1 --time-parallel 1
+run lpc --workload lpc
+run lpc_bit_identical --workload lpc --lpc-exact
+run lpc_fma --workload lpc --fused
+run lpc_1m --workload lpc --lpc-frames 1048576
+run envelope_abs --workload envelope
+run timevar_shared --workload timevar
+run timevar_per_channel --workload timevar --streams 0
+run narrow512_bit_exact --channels 512 --time-parallel 0
+run narrow512_time_parallel --channels 512 --time-parallel 1
+run narrow512_time_parallel_one_pass --channels 512 --time-parallel -2
