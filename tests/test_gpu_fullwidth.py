@@ -181,3 +181,80 @@ def test_cfg4_fused_mode_within_contract(alz, oracle):
   yf = fused.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
   assert "fma" in fused.last_kernel, fused.last_kernel
   assert norm_err(yf, y, 1) <= 1e-9 and not same_bits(yf, y)
+
+
+# ---- the long axis: whole benchmark-length blocks on strided channels (round-2 verdict, weak #1) -----------------------
+def _gpu_noise(shape, seed):
+  import torch
+  g = torch.Generator(device="cuda").manual_seed(seed)
+  x = torch.empty(shape, dtype=torch.float64, device="cuda")
+  rows = max(1, shape[0] // 16)
+  for r0 in range(0, shape[0], rows):
+    x[r0:r0 + rows].uniform_(-1.0, 1.0, generator=g)
+  return x
+
+
+def test_cfg2_full_block_length_on_strided_channels(alz, oracle, bench):
+  """configs[1] at its real block length: 4096 channels x 2^20 samples through k_duo, 64 strided channels compared with
+  the C oracle over the WHOLE block (every one of the 16 384 tiles a benchmark step walks), bit for bit."""
+  import torch
+  C, N = 4096, 1 << 20
+  b, a = bench.resonator_coefs(C)
+  x = _gpu_noise((N, C), 5)
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset()
+  y = bank.process(x, layout="time")
+  assert "k_duo" in bank.last_kernel
+  pick = np.linspace(0, C - 1, 64).astype(int)
+  idx = torch.from_numpy(pick).cuda()
+  got, xs = y.index_select(1, idx).cpu().numpy(), x.index_select(1, idx).cpu().numpy()
+  del x, y
+  torch.cuda.empty_cache()
+  ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), xs, layout="time")
+  assert same_bits(got, ref)
+
+
+@pytest.mark.parametrize("mode", [True, "one-pass"])
+def test_narrow_bank_time_parallel_full_block_length(alz, oracle, bench, mode):
+  """The time-parallel modes over a whole 2^20-sample block of the 512-channel shard (2048 chunk boundaries in the
+  one-pass form, 128 in the three-launch form): 64 strided channels against the oracle, <= 1e-8 normalised."""
+  import torch
+  C, N = 512, 1 << 20
+  b, a = bench.resonator_coefs(4096)
+  b, a = b[:C].copy(), a[:C].copy()                 # the lowest (highest-Q) resonators of the bank: the hard end
+  x = _gpu_noise((N, C), 6)
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(mode)
+  bank.reset()
+  y = bank.process(x, layout="time")
+  assert ("k_look" if mode == "one-pass" else "k_scan") in bank.last_kernel, bank.last_kernel
+  pick = np.linspace(0, C - 1, 64).astype(int)
+  idx = torch.from_numpy(pick).cuda()
+  got, xs = y.index_select(1, idx).cpu().numpy(), x.index_select(1, idx).cpu().numpy()
+  ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), xs, layout="time")
+  assert norm_err(got, ref, 0) <= 1e-8
+
+
+def test_cfg4_pipeline_full_block_length_on_strided_channels(alz, oracle):
+  """configs[3] at its real block length: 256 bands x 64 streams x 2^16 samples through k_pipe (4096 tiles per
+  channel group), 96 strided (band, stream) channels against the oracle over the whole block, bit for bit."""
+  import torch
+  B, S, N = 256, 64, 1 << 16
+  s_, Hz = alz.sHz(48000)
+  fcs = [f * Hz for f in alz.erb_space(50., 20000., B)]
+  bank = alz.gammatone_bank(fcs, S, strategy="slaney", Hz=Hz)
+  bank.reset()
+  x = _gpu_noise((S, N), 7)
+  y = bank.process(x, layout="chan")
+  assert "k_pipe" in bank.last_kernel, bank.last_kernel
+  pick = np.linspace(0, B * S - 1, 96).astype(int)
+  got = y.index_select(0, torch.from_numpy(pick).cuda()).cpu().numpy()
+  xs = x.cpu().numpy()
+  k = alz.gammatone_erb_constants(4)[0]
+  rows_b, rows_a, rows_x = [], [], []
+  for ch in pick:
+    band = alz.gammatone.slaney(fcs[ch // S], k * alz.erb(fcs[ch // S], Hz))
+    rows_b.append(sum((f.numlist for f in band), []))
+    rows_a.append(sum((f.denlist for f in band), []))
+    rows_x.append(xs[ch % S])
+  ref = oracle.bank([2] * 4, [3] * 4, np.array(rows_b), np.array(rows_a), np.array(rows_x), layout="chan")
+  assert same_bits(got, ref)
