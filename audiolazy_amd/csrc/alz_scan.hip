@@ -329,50 +329,63 @@ __global__ __launch_bounds__(64) void k_cscan_power(CScanArgs p) {
 
 // S_{j+1} = M S_j + z_j per real channel.  On entry vyh holds the end states of pass 1 (slot 0: the true S_1,
 // slots j > 0: z_j); on exit every slot holds its chunk's true initial state (slot 0: the bank's).
+// Eight lanes per channel, one per state row: lane r keeps row r of M, walks the channel's chunks in order (they are
+// contiguous in memory, [k][channel * K + j]) with the z of the next block of eight chunks in flight, and the eight
+// lanes of a channel exchange their state components through LDS once per chunk.  (One lane per channel with the
+// whole matrix in registers issued 14 scattered stores and 8 scattered loads per chunk from each of 64 lanes: 586 us
+// per call at one chunk of look-ahead, 254 us at eight -- more than either cascade pass; profiles/NOTES_r03.md.)
 __global__ __launch_bounds__(64) void k_cscan_fix(CScanArgs p) {
-  const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (c >= p.C) return;
+  __shared__ double xs[64];
+  const int lane = threadIdx.x, r = lane & 7, g = lane >> 3;
+  int64_t c = (int64_t)blockIdx.x * 8 + g;
+  const bool live_c = c < p.C;
+  if (!live_c) c = p.C - 1;                                  // (keeps the wave's LDS exchange uniform; nothing is stored)
   const int64_t V = p.K * p.C, v0 = c * p.K;
   const int ND = 2 * p.nsec;
-  double M[8][8], S[8], z[8];
+  constexpr int B = 8;
+  const int s = r >> 1, k = r & 1;
+  const bool on = r < ND && k < p.na[s < p.nsec ? s : 0] - 1;
+  double M[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  for (int e = 0; e < 8; ++e) M[e] = (r < ND && e < ND) ? p.power[((int64_t)r * 8 + e) * p.C + c] : 0.0;
+  const double *zsrc = on ? p.vyh[s] + (int64_t)k * V + v0 : p.power;
+  double *ydst = (on && live_c) ? p.vyh[s] + (int64_t)k * V + v0 : nullptr;
+  // the next section's input history is this section's output history
+  double *xdst = (r < ND && live_c && s + 1 < p.nsec && k < p.nb[s + 1] - 1) ? p.vxh[s + 1] + (int64_t)k * V + v0 : nullptr;
+  double S = on ? zsrc[0] : 0.0;                             // end state of chunk 0 = the true S_1 (row r of it)
+  if (ydst) ydst[0] = p.yh[s][(int64_t)k * p.C + c];         // chunk 0 replays from the bank's state
+  auto fetch = [&](int64_t j0, double (&z)[B]) {             // z_r of chunks j0 .. j0 + B - 1 (clamped)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) M[r][e] = (r < ND && e < ND) ? p.power[((int64_t)r * 8 + e) * p.C + c] : 0.0;
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int s = r >> 1, k = r & 1;
-    const bool on = r < ND && k < p.na[s] - 1;
-    S[r] = on ? p.vyh[s][(int64_t)k * V + v0] : 0.0;                       // end state of chunk 0
-    if (on) p.vyh[s][(int64_t)k * V + v0] = p.yh[s][(int64_t)k * p.C + c];  // chunk 0 replays from the bank's state
-    z[r] = (on && p.K > 1) ? p.vyh[s][(int64_t)k * V + v0 + 1] : 0.0;
-  }
-  for (int64_t j = 1; j < p.K; ++j) {
-    double zn[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {                                          // next chunk's end state, ahead of the chain
-      const int s = r >> 1, k = r & 1;
-      const bool on = r < ND && k < p.na[s] - 1;
-      zn[r] = (on && j + 1 < p.K) ? p.vyh[s][(int64_t)k * V + v0 + j + 1] : 0.0;
+    for (int u = 0; u < B; ++u) {
+      const int64_t j = j0 + u < p.K ? j0 + u : p.K - 1;
+      z[u] = on ? zsrc[j] : 0.0;
     }
+  };
+  auto chain = [&](int64_t j0, const double (&z)[B]) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int s = r >> 1, k = r & 1;
-      if (r < ND && k < p.na[s] - 1) p.vyh[s][(int64_t)k * V + v0 + j] = S[r];
-      // the next section's input history is this section's output history
-      if (r < ND && s + 1 < p.nsec && k < p.nb[s + 1] - 1) p.vxh[s + 1][(int64_t)k * V + v0 + j] = S[r];
+    for (int u = 0; u < B; ++u) {
+      const int64_t j = j0 + u;
+      if (j < p.K) {                                         // (uniform)
+        if (ydst) ydst[j] = S;
+        if (xdst) xdst[j] = S;
+        xs[lane] = S;
+        __builtin_amdgcn_wave_barrier();
+        double acc = z[u];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_fma(M[e], xs[g * 8 + e], acc);
+        __builtin_amdgcn_wave_barrier();
+        S = acc;
+      }
     }
-    double Sn[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      double acc = z[r];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc = __builtin_fma(M[r][e], S[e], acc);
-      Sn[r] = acc;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { S[r] = Sn[r]; z[r] = zn[r]; }
+  };
+  // chunks 1 .. K - 1 in blocks of B, two register sets
+  double za[B], zb[B];
+  fetch(1, za);
+  for (int64_t j0 = 1; j0 < p.K; j0 += 2 * B) {
+    fetch(j0 + B, zb);
+    chain(j0, za);
+    fetch(j0 + 2 * B, za);
+    chain(j0 + B, zb);
   }
 }
 
@@ -459,7 +472,7 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     scratch->power_len = L;
     scratch->power_section = -2;          // (-2: this slot holds a cascade's matrix)
   }
-  hipLaunchKernelGGL(k_cscan_fix, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, stream, p);
+  hipLaunchKernelGGL(k_cscan_fix, dim3((unsigned)((C + 7) / 8)), dim3(64), 0, stream, p);
   ch.nostore = false;
   rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
   if (rc) return rc;
