@@ -40,7 +40,16 @@ namespace {
 
 constexpr int kChunks = 8;                   // 1 KiB DMA transfers per tile
 constexpr int kNT = 8;                       // tiles per chunk (L = 512)
-constexpr int kSlots = 2 * kNT;              // tile slots in LDS
+#ifndef ALZ_LOOK_SLOTS
+#define ALZ_LOOK_SLOTS 16
+#endif
+#ifndef ALZ_LOOK_LEAD
+#define ALZ_LOOK_LEAD 3
+#endif
+#ifndef ALZ_LOOK_LAG
+#define ALZ_LOOK_LAG 11
+#endif
+constexpr int kSlots = ALZ_LOOK_SLOTS;       // tile slots in LDS
 constexpr int kSlot = 8192 + kChunks * 16;   // a tile in the DMA layout (16 bytes of pad per 1 KiB chunk)
 constexpr int kHist = 256;                   // the two rows before a tile: [2][16] doubles
 constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (hipMemset 0xFF)
@@ -65,8 +74,9 @@ struct LArgs {
   const double *power;         // M = A^512 per channel: [4][channels] (M11 M12 M21 M22)
   unsigned long long *z;       // [groups][n_chunks][2][16] published zero-state end states
   int *err;                    // set when a spin ran into its cap
-  int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no recurrence
-                               // wave arithmetic, 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain
+  int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no replay arithmetic,
+                               // 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain,
+                               // 64 no zero-state sums; 256 / 512 print the replay / the other waves' cycle counts
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -103,52 +113,57 @@ __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
 
 }  // namespace
 
-// One 64-sample tile of the recurrence wave.  Its 64 lanes are 16 channels x 2 ROLES x 2 skewed copies:
-//   lanes  0..31  REC: the replay from the true state, tile t - lag, overwrites p with y;
-//   lanes 32..63  ZS:  the zero-state pass, tile t (a chunk and three tiles ahead), writes nothing that is kept.
-// The two passes are the same instruction stream on different tiles, so the zero-state pass rides in lanes that
-// k_duo's recurrence wave spends on ghost copies (it keeps four skewed copies so that one ds_write_b64 stores four
-// rows; here two copies, one write per two rows) -- a separate ZS wave slowed the replay wave by 15 % (LDS / issue
-// contention on the CU, ablations in profiles/NOTES_r03.md) and its branches cost more.
-//   cur     the lane's column in ITS tile slot, minus its skew (row r of the lane = cur + (r + q) * 128)
-//   wr      where the lane stores: cur for the REC lanes, a dummy slot for the ZS lanes (EXEC stays full)
-//   start   CS instantiation: this lane's tile opens a chunk -> the lane switches to (s1, s2) at its step q
-//   kp      p of the previous tile's last row (the lagging copy's first step); updated for the next tile
-struct LookState { double m1, m2, t2, kp; };
+// One 64-sample tile of the replay wave: 16 channels x 4 skewed copies (copy q runs q steps behind, so one
+// ds_write_b64 of the wave stores four finished rows -- k_duo's scheme), over p in the tile slot, overwriting it with y.
+//   cur     the lane's column in the tile slot, minus its skew (the lane's step u is row u - q = cur + u * 128)
+//   nxt     the same for the NEXT tile of the workgroup's sequence: p is prepared many intervals ahead here, so the
+//           register ring of 8-row groups (pr, four deep so that a tile's eight groups keep their places) simply runs
+//           on across the tile boundary and no tile starts by waiting for its first rows
+//   CS      instantiation for a tile that opens a chunk: copy q switches to the chunk's start state (s1, s2) at its
+//           step q (its steps before that finish the previous tile of the sequence)
+//   k1..k3  p of the previous tile's last three rows (the lagging copies' first steps; the replay has overwritten
+//           them by now), replaced by this tile's for the next call
+struct LookState { double m1, m2, t2, k1, k2, k3; };
 template <unsigned PA, bool CS>
-__device__ __forceinline__ LookState look_tile(const char *cur, char *wr, int q, bool start, double s1, double s2,
-                                               double na1, double na2, LookState st) {
+__device__ __forceinline__ void look_tile(char *cur, const char *nxt, int q, double s1, double s2, double na1,
+                                          double na2, LookState &st, double (&pr)[4][8]) {
   constexpr int T = 64, kStep = 128, NCH = T / 8;
   double m1 = st.m1, m2 = st.m2, t2 = st.t2;
-  // this tile's last p row, for the lagging copy's first step of the NEXT tile (REC overwrites it)
-  const double nk = *reinterpret_cast<const double *>(cur + (q + T - 1) * kStep);
-  double pr[3][8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const double v = *reinterpret_cast<const double *>(cur + (u < q ? q : u) * kStep);
-    pr[0][u] = (u == 0 && q == 1) ? st.kp : v;           // (row -1 of the lagging copy: the previous tile's last row)
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
+  double n1 = 0.0, n2 = 0.0, n3 = 0.0;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     if (k + 2 < NCH) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pr[(k + 2) % 3][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
+      for (int u = 0; u < 8; ++u) pr[(k + 2) % 4][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
+    } else {
+      const int kk = k + 2 - NCH;                          // the next tile's group 0 / 1
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = kk * 8 + u;                          // (rows before the tile: any address of it, see k1..k3)
+        pr[(k + 2) % 4][u] = *reinterpret_cast<const double *>(nxt + ((kk == 0 && u < 3 && u < q) ? q : r) * kStep);
+      }
+    }
+    if (k == NCH - 2) {                                    // before the last group overwrites them
+      n1 = *reinterpret_cast<const double *>(cur + (q + T - 1) * kStep);
+      n2 = *reinterpret_cast<const double *>(cur + (q + T - 2) * kStep);
+      n3 = *reinterpret_cast<const double *>(cur + (q + T - 3) * kStep);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      double acc = pr[k % 4][u];
+      if (k == 0 && u < 3) {
+        const int d = q - u;                               // > 0: row -d of the tile
+        acc = d == 1 ? st.k1 : d == 2 ? st.k2 : d == 3 ? st.k3 : acc;
+      }
       if constexpr (CS) {
-        if (k == 0 && u <= 1) {
-          // row 0 of the chunk is this copy's step q: (re)start from the chunk's initial state there
-          const bool now = start && u == q;
+        if (k == 0 && u <= 3) {
+          const bool now = u == q;
           m1 = now ? s1 : m1;
           m2 = now ? s2 : m2;
           t2 = now ? na2 * s2 : t2;
         }
       }
-      double acc = pr[k % 3][u];
       double t2n = 0.0;
       if constexpr (PA == 3u) {
         const double t1 = na1 * m1;
@@ -161,23 +176,38 @@ __device__ __forceinline__ LookState look_tile(const char *cur, char *wr, int q,
       m2 = m1;
       m1 = acc;
       t2 = t2n;
-      if ((u & 1) == 1) *reinterpret_cast<double *>(wr + (k * 8 + u) * kStep) = acc;   // rows u - 1 (copy 1), u (copy 0)
+      if ((u & 3) == 3) *reinterpret_cast<double *>(cur + (k * 8 + u) * kStep) = acc;   // rows u - 3 .. u, one per copy
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  return LookState{m1, m2, t2, nk};
+  st = LookState{m1, m2, t2, n1, n2, n3};
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#ifdef ALZ_ABLATE
+#define ALZ_LOOK_CLOCK(n) long long cyc[n] = {}, c_prev = __builtin_readcyclecounter();
+#define ALZ_LOOK_MARK(k) { const long long c_now = __builtin_readcyclecounter(); cyc[k] += c_now - c_prev; c_prev = c_now; }
+#else
+#define ALZ_LOOK_CLOCK(n)
+#define ALZ_LOOK_MARK(k)
+#endif
+
 template <unsigned PB, unsigned PA>
-__global__ __launch_bounds__(128) void k_look(LArgs p) {
+__global__ __launch_bounds__(192) void k_look(LArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64, NT = kNT;
   constexpr int kStep = G * 8;
-  // pipeline offsets, in tiles of this workgroup's own tile sequence (see the header): at interval i
-  //   AUX stores tile i - kRecLag - 1, queues the DMA of tile i + kDmaLead, prepares tile i + 1,
-  //   ZS works on tile i, REC on tile i - kRecLag
-  constexpr int kRecLag = NT + 3, kDmaLead = 3;
+  // pipeline offsets, in tiles of this workgroup's own tile sequence (see the header): in interval i
+  //   LOAD   queues the DMA of tile i + kDmaLead and prepares tile i + 1;
+  //   HELP   stores tile i - kRecLag - 1, forms tile i's part of its chunk's zero-state end state (published with the
+  //          chunk's last tile), asks for the neighbours' states three intervals before the replay opens a chunk and
+  //          chains the chunk's start state from them one interval before;
+  //   REPLAY works on tile i - kRecLag.
+  constexpr int kRecLag = ALZ_LOOK_LAG, kDmaLead = ALZ_LOOK_LEAD;
   static_assert(kSlots >= kRecLag + 1 + kDmaLead + 1, "a slot is stored before it is refilled");
+  static_assert(kRecLag >= NT + 3, "a chunk's state is asked for after the neighbour has published its own");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -186,25 +216,28 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
   const int w = (int)((int64_t)blockIdx.x - group * W);
   const int64_t c0 = group * G, c = c0 + cl;
   const int64_t K = p.n_chunks;
-  const int64_t my_chunks = (K - w + W - 1) / W;             // chunks w, w + W, ...
-  const int64_t TOT = my_chunks * NT;
+  const int my_chunks = (int)((K - w + W - 1) / W);           // chunks w, w + W, ...
+  const int TOT = my_chunks * NT;
+  const int n_iv = TOT + kRecLag + 2;
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
-  char *dummy = hist + kSlots * kHist;                        // one tile slot nobody reads: the ZS lanes' stores, idle roles' tiles
-  char *zlds = dummy + kSlot;                                 // [kMaxW][2][16] doubles: the requested chunk end states
+  char *zlds = hist + kSlots * kHist;                         // [kMaxW][2][16] doubles: the requested chunk end states
+  char *sbuf = zlds + kMaxW * 256;                            // [2][2][16] doubles: chunk start states, by chunk parity
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int lane_off = cl * 8;
 #define ALZ_EOFF(u) ((u) * G * 8 + (((u) * G) >> 7) * 16)
   // global row of tile t's first sample: chunk (w + (t / NT) W), tile t % NT of it
-  auto tile_row = [&](int64_t t) -> int64_t { return ((int64_t)w + (t / NT) * W) * (NT * T) + (t % NT) * T; };
+  auto tile_row = [&](int t) -> int64_t { return ((int64_t)w + (int64_t)(t / NT) * W) * (NT * T) + (t % NT) * T; };
   unsigned long long *zg = p.z + group * K * 32;              // this group's [K][2][16]
+  double na1 = 0, na2 = 0;
+  if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
+  if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
 
   if (wave == 1) {
-    // ------------------------------ AUX ------------------------------
+    // ------------------------------ LOAD ------------------------------
     const int row = lane / 8, cp = lane % 8;
     const double *xg = p.x + (int64_t)row * p.ldx + c0 + 2 * cp;
-    double *yg = p.y + (int64_t)row * p.ldy + c0 + 2 * cp;
-    const int64_t x_chunk = 8 * p.ldx, y_chunk = 8 * p.ldy;
+    const int64_t x_chunk = 8 * p.ldx;
     double b0 = 0, b1 = 0, b2 = 0;
     if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
     if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
@@ -214,8 +247,8 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
     double bb0 = b0, bb1 = b1, bb2 = b2, hh1 = h1, hh2 = h2;
     asm volatile("" : "+v"(bb0), "+v"(bb1), "+v"(bb2), "+v"(hh1), "+v"(hh2));
     // nine transfers per tile: the tile, and (16 lanes only) the two rows before it
-    auto queue_tile = [&](int64_t t) {
-      const int s = (int)(t % kSlots);
+    auto queue_tile = [&](int t) {
+      const int s = t % kSlots;
       const int64_t r0 = tile_row(t);
       const double *src = xg + r0 * p.ldx;
 #pragma unroll
@@ -225,9 +258,9 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
       const double *hsrc = p.x + (rh + (lane >> 3 & 1)) * p.ldx + c0 + 2 * (lane & 7);
       if (lane < 16) dma16(hsrc, lds0 + (unsigned)(hist - smem) + s * kHist);
     };
-    auto prepare_tile = [&](int64_t t) {
-      char *xs = smem + (int)(t % kSlots) * kSlot + lane_off;
-      const char *hs = hist + (int)(t % kSlots) * kHist + cl * 8;
+    auto prepare_tile = [&](int t) {
+      char *xs = smem + (t % kSlots) * kSlot + lane_off;
+      const char *hs = hist + (t % kSlots) * kHist + cl * 8;
       const int adj1 = (q == 0) ? 16 : 0, adj2 = (q < 2) ? 16 : 0;
       const char *x_d0 = xs + q * kStep;
       const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
@@ -246,8 +279,8 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
       if constexpr ((PB & 6u) != 0) {
         // x[-2], x[-1] relative to this tile: the landed history rows, or the bank's history at the start of the stream
         const bool stream_start = tile_row(t) == 0;
-        const double g2 = *reinterpret_cast<const double *>(hs), g1 = *reinterpret_cast<const double *>(hs + 128);
-        const double pm1 = stream_start ? hh1 : g1, pm2 = stream_start ? hh2 : g2;
+        const double q2 = *reinterpret_cast<const double *>(hs), q1 = *reinterpret_cast<const double *>(hs + 128);
+        const double pm1 = stream_start ? hh1 : q1, pm2 = stream_start ? hh2 : q2;
         const double s0 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(0));
         const double s1 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(1));
         const double s2 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(2));
@@ -269,15 +302,6 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) *reinterpret_cast<double *>(xs + (4 * j + q) * kStep) = acc[j];
     };
-    auto store_tile = [&](int64_t t) {
-      const char *ys = smem + (int)(t % kSlots) * kSlot;
-      double *yt = yg + tile_row(t) * p.ldy;
-      dbl2 v[kChunks];
-#pragma unroll
-      for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
-#pragma unroll
-      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
-    };
     // the input history the bank keeps for the next block: the last two x rows of the block (owner of the last chunk)
     const bool owns_last = ((K - 1) % W) == w;
     for (int t = 0; t < kDmaLead && t < TOT; ++t) queue_tile(t);
@@ -285,77 +309,89 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
     prepare_tile(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int64_t n_iv = TOT + kRecLag + 2;
-    for (int64_t i = 0; i < n_iv; ++i) {
-      const int64_t ts = i - kRecLag - 1;
-      if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) store_tile(ts);
+    ALZ_LOOK_CLOCK(4)                                          // queue / wait / prepare / barrier
+    for (int i = 0; i < n_iv; ++i) {
       if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
+      ALZ_LOOK_MARK(0)
       if (i + 1 < TOT) {
-        // issued after tile i + 1's transfers: two more tiles (9 each) and the stores of the last two intervals
-        // (8 each, once tiles are being stored); the last tiles of the sequence simply wait for everything
-        static_assert(kDmaLead == 3, "the counts below");
-        if (i + kDmaLead < TOT) {
-          if (ts >= 1) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-          else if (ts == 0) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // issued after tile i + 1's transfers: those of kDmaLead - 1 more tiles (the last tiles of the sequence simply
+        // wait for everything)
+        static_assert((kDmaLead - 1) * (kChunks + 1) <= 63, "vmcnt is a 6-bit count");
+        if (i + kDmaLead < TOT) wait_vm<(kDmaLead - 1) * (kChunks + 1)>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
-          const char *xs = smem + (int)((i + 1) % kSlots) * kSlot + lane_off;
+          const char *xs = smem + ((i + 1) % kSlots) * kSlot + lane_off;
           if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
           if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
         }
+        ALZ_LOOK_MARK(1)
         if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ALZ_LOOK_MARK(2)
       __builtin_amdgcn_s_barrier();
+      ALZ_LOOK_MARK(3)
     }
+#ifdef ALZ_ABLATE
+    if (blockIdx.x == 5 && lane == 0 && (p.dbg & 512))
+      printf("k_look LOAD wave, cycles per interval: queue %.1f wait %.1f prepare %.1f barrier %.1f\n",
+             (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    // ------------------------------ the recurrence wave: REC lanes 0..31, ZS lanes 32..63 ------------------------------
-    const int role = lane >> 5, rq = (lane >> 4) & 1;        // role 0 REC / 1 ZS; copy rq lags rq steps
-    double na1 = 0, na2 = 0;
-    if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
-    if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
+  } else if (wave == 2) {
+    // ------------------------------ HELP ------------------------------
+    const int row = lane / 8, cp = lane % 8;
+    double *yg = p.y + (int64_t)row * p.ldy + c0 + 2 * cp;
+    const int64_t y_chunk = 8 * p.ldy;
     const double m11 = p.power[0 * p.channels + c], m12 = p.power[1 * p.channels + c];
     const double m21 = p.power[2 * p.channels + c], m22 = p.power[3 * p.channels + c];
     // S: the true state at the start of this workgroup's chunks, advanced in zero-state space --
-    // S_c = M ( ... M (M S_{c-W} + z_{c-W}) + z_{c-W+1} ... ) + z_{c-1} -- from the states every workgroup's ZS lanes
-    // publish; the first chunk starts the chain from the bank's state
+    // S_c = M ( ... M (M S_{c-W} + z_{c-W}) + z_{c-W+1} ... ) + z_{c-1} -- from the states every workgroup publishes;
+    // the first chunk starts the chain from the bank's state
     double S1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
     double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
-    asm volatile("" : "+v"(na1), "+v"(na2), "+v"(S1), "+v"(S2));
-    LookState st = {0.0, 0.0, 0.0, 0.0};
+    asm volatile("" : "+v"(S1), "+v"(S2));
+    // The zero-state end state of a tile is a dot product, not a recurrence: with h the impulse response of 1/A(z),
+    // (y[63], y[62]) = sum_r (h[63-r], h[62-r]) p[r].  This lane takes rows 4 j + q: its 2 x 16 weights, and
+    // A^64 = [[h64, -a2 h63], [h63, -a2 h62]] to carry the sum from tile to tile, come from 65 steps of h's own
+    // recurrence, once per launch.
+    double g1[16], g2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { g1[j] = 0.0; g2[j] = 0.0; }
+    double M11, M12, M21, M22;
+    {
+      double hk = 1.0, hp = 0.0, h62 = 0.0, h63 = 0.0, h64 = 0.0;
+#pragma unroll
+      for (int k = 0; k <= 64; ++k) {
+        if (k <= 63) { const int r = 63 - k; g1[r >> 2] = (q == (r & 3)) ? hk : g1[r >> 2]; }
+        if (k <= 62) { const int r = 62 - k; g2[r >> 2] = (q == (r & 3)) ? hk : g2[r >> 2]; }
+        if (k == 62) h62 = hk;
+        if (k == 63) h63 = hk;
+        if (k == 64) h64 = hk;
+        const double nx = __builtin_fma(na1, hk, na2 * hp);
+        hp = hk;
+        hk = nx;
+      }
+      M11 = h64; M12 = na2 * h63; M21 = h63; M22 = na2 * h62;
+    }
+    double Z1 = 0.0, Z2 = 0.0;
     bool gave_up = false;
-    // z of the chunks between this workgroup's previous chunk and its next one: requested ALL AT ONCE, two tiles
-    // before the replay needs the state, as four 1 KiB global -> LDS transfers the compiler does not know about (loads
-    // into registers made it wait for them on the spot: one exposed memory round trip per chunk, 20 % of the run)
     int64_t req_first = 0;
     int req_cnt = 0;
-    const int64_t n_iv = TOT + kRecLag + 2;
+    if (w == 0 && q == 0) {                                   // chunk 0 starts from the bank's state
+      *reinterpret_cast<double *>(sbuf + cl * 8) = S1;
+      *reinterpret_cast<double *>(sbuf + 128 + cl * 8) = S2;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int64_t i = 0; i < n_iv; ++i) {
-      const int64_t t_r = i - kRecLag, t_z = i;
-      const bool act_r = t_r >= 0 && t_r < TOT, act_z = t_z < TOT;
-      // two tiles before a REC chunk starts: ask for the states its start state is chained from
-      if (t_r + 2 >= 0 && t_r + 2 < TOT && ((t_r + 2) % NT) == 0 && !ALZ_DBG(p, 32)) {
-        const int64_t seq = (t_r + 2) / NT, cj = (int64_t)w + seq * W;
-        req_first = seq > 0 ? cj - W : 0;                    // z_first .. z_{cj-1}
-        req_cnt = (int)(cj - req_first);
-#pragma unroll
-        for (int o = 0; o < kMaxW / 4; ++o) {                // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
-          int64_t ch = req_first + 4 * o + (lane >> 4);
-          if (ch > K - 1) ch = K - 1;                        // (beyond the request: any valid address, never read)
-          dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
-        }
-      }
-      if ((act_r || act_z) && !ALZ_DBG(p, 2)) {
-        const bool cs_r = act_r && (t_r % NT) == 0, cs_z = act_z && (t_z % NT) == 0;
-        if (cs_r && !ALZ_DBG(p, 32)) {
-          // the state the replay of this chunk starts from (the transfers were queued two intervals ago; this wave's
-          // only other vector-memory operations are the few stores below)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ALZ_LOOK_CLOCK(5)                                          // chain / store / zero-state / request / barrier
+    for (int i = 0; i < n_iv; ++i) {
+      // (1) one interval before the replay opens chunk number seq of this workgroup: its start state
+      {
+        const int t_c = i + 1 - kRecLag;                       // the replay's tile in the NEXT interval
+        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0 && (t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+          const int seq = t_c / NT;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transfers asked for two intervals ago
 #pragma unroll
           for (int e = 0; e < kMaxW; ++e) {
             if (e < req_cnt) {
@@ -378,36 +414,143 @@ __global__ __launch_bounds__(128) void k_look(LArgs p) {
               S1 = n1; S2 = n2;
             }
           }
-        }
-        const int64_t t = role ? t_z : t_r;
-        const bool act = role ? act_z : act_r;
-        const char *cur = (act ? smem + (int)(t % kSlots) * kSlot : dummy) + lane_off - rq * kStep;
-        char *wr = ((act && role == 0) ? smem + (int)(t % kSlots) * kSlot : dummy) + lane_off - rq * kStep;
-        const bool start = role ? cs_z : cs_r;
-        const double s1 = role ? 0.0 : S1, s2 = role ? 0.0 : S2;
-        if (cs_r || cs_z) st = look_tile<PA, true>(cur, wr, rq, start, s1, s2, na1, na2, st);
-        else st = look_tile<PA, false>(cur, wr, rq, false, 0.0, 0.0, na1, na2, st);
-        if (rq == 0) {
-          // copy 0 has just finished its tile: at a chunk's last tile its (m1, m2) is the chunk's end state
-          if (role == 1 && act_z && (t_z % NT) == NT - 1) {
-            const int64_t j = (int64_t)w + (t_z / NT) * W;
-            __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(st.m1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(st.m2), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+          if (q == 0) {
+            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
+            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
           }
-          if (role == 0 && act_r && t_r == TOT - 1 && ((K - 1) % W) == w) {   // the bank's state after the block
-            if (p.na > 1) p.yh[0 * p.channels + c] = st.m1;
-            if (p.na > 2) p.yh[1 * p.channels + c] = st.m2;
+        }
+      }
+      ALZ_LOOK_MARK(0)
+      // (2) the tile the replay finished in the last interval
+      {
+        const int ts = i - kRecLag - 1;
+        if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) {
+          const char *ys = smem + (ts % kSlots) * kSlot;
+          double *yt = yg + tile_row(ts) * p.ldy;
+          dbl2 v[kChunks];
+#pragma unroll
+          for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+#pragma unroll
+          for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
+        }
+      }
+      ALZ_LOOK_MARK(1)
+      // (3) tile i's part of its chunk's zero-state end state (prepared in the last interval)
+      if (i < TOT && !ALZ_DBG(p, 64)) {
+        const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
+        double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const double a = *reinterpret_cast<const double *>(zsrc + j * 512);
+          const double b = *reinterpret_cast<const double *>(zsrc + (j + 1) * 512);
+          u1 = __builtin_fma(g1[j], a, u1);
+          u2 = __builtin_fma(g2[j], a, u2);
+          v1 = __builtin_fma(g1[j + 1], b, v1);
+          v2 = __builtin_fma(g2[j + 1], b, v2);
+        }
+        // the four row classes of a channel sit 16 lanes apart; then carry the chunk's sum over this tile
+        double z1 = u1 + v1, z2 = u2 + v2;
+        z1 += __shfl_xor(z1, 16);
+        z2 += __shfl_xor(z2, 16);
+        z1 += __shfl_xor(z1, 32);
+        z2 += __shfl_xor(z2, 32);
+        const int tt = i % NT;
+        const double c1 = __builtin_fma(M11, Z1, __builtin_fma(M12, Z2, z1));
+        const double c2 = __builtin_fma(M21, Z1, __builtin_fma(M22, Z2, z2));
+        Z1 = tt == 0 ? z1 : c1;
+        Z2 = tt == 0 ? z2 : c2;
+        if (tt == NT - 1 && q == 0) {
+          const int64_t j = (int64_t)w + (int64_t)(i / NT) * W;
+          __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(Z1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(Z2), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      ALZ_LOOK_MARK(2)
+      // (4) three intervals before the replay opens a chunk: ask for the states its start state is chained from, ALL
+      // AT ONCE, as four 1 KiB global -> LDS transfers the compiler does not know about (loads into registers made it
+      // wait for them on the spot)
+      {
+        const int t_q = i + 3 - kRecLag;
+        if (t_q >= 0 && t_q < TOT && (t_q % NT) == 0 && (t_q > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+          const int64_t seq = t_q / NT, cj = (int64_t)w + seq * W;
+          req_first = seq > 0 ? cj - W : 0;                  // z_first .. z_{cj-1}
+          req_cnt = (int)(cj - req_first);
+#pragma unroll
+          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
+            int64_t ch = req_first + 4 * o + (lane >> 4);
+            if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
+            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
           }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ALZ_LOOK_MARK(3)
       __builtin_amdgcn_s_barrier();
+      ALZ_LOOK_MARK(4)
     }
+#ifdef ALZ_ABLATE
+    if (blockIdx.x == 5 && lane == 0 && (p.dbg & 512))
+      printf("k_look HELP wave, cycles per interval: chain %.1f store %.1f zero-state %.1f request %.1f barrier %.1f\n",
+             (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv, (double)cyc[4] / n_iv);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    // ------------------------------ REPLAY ------------------------------
+    asm volatile("" : "+v"(na1), "+v"(na2));
+    LookState st = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double pr[4][8];
+    __builtin_amdgcn_s_barrier();                            // (the prologue's)
+    for (int i = 0; i < kRecLag; ++i) __builtin_amdgcn_s_barrier();
+    ALZ_LOOK_CLOCK(3)                                          // tile / tail / barrier
+    {
+      const char *cur = smem + lane_off - q * kStep;         // tile 0: groups 0 and 1 of the register ring
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[0][u] = *reinterpret_cast<const double *>(cur + ((u < 3 && u < q) ? q : u) * kStep);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
+    }
+    int sr = 0, tic = 0, par = 0;                            // slot, tile of the chunk, chunk parity: rotated by hand
+    for (int t = 0; t < TOT; ++t) {
+      char *cur = smem + sr * kSlot + lane_off - q * kStep;
+      const int sn = (sr + 1 == kSlots) ? 0 : sr + 1;
+      const char *nxt = (t + 1 < TOT) ? smem + sn * kSlot + lane_off - q * kStep : cur;
+      if (!ALZ_DBG(p, 2)) {
+        if (tic == 0) {
+          const double s1 = *reinterpret_cast<const double *>(sbuf + par * 256 + cl * 8);
+          const double s2 = *reinterpret_cast<const double *>(sbuf + par * 256 + 128 + cl * 8);
+          look_tile<PA, true>(cur, nxt, q, s1, s2, na1, na2, st, pr);
+        } else {
+          look_tile<PA, false>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
+        }
+      }
+      ALZ_LOOK_MARK(0)
+      // copy 0 has just finished the tile: after the last one its (m1, m2) is the bank's state after the block
+      if (t == TOT - 1 && q == 0 && ((K - 1) % W) == w) {
+        if (p.na > 1) p.yh[0 * p.channels + c] = st.m1;
+        if (p.na > 2) p.yh[1 * p.channels + c] = st.m2;
+      }
+      sr = sn;
+      tic = (tic + 1 == NT) ? 0 : tic + 1;
+      par ^= (tic == 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ALZ_LOOK_MARK(1)
+      __builtin_amdgcn_s_barrier();
+      ALZ_LOOK_MARK(2)
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+#ifdef ALZ_ABLATE
+    if (blockIdx.x == 5 && lane == 0 && (p.dbg & 256))
+      printf("k_look replay wave, cycles per tile: tile %.1f tail %.1f barrier %.1f (%d tiles)\n",
+             (double)cyc[0] / TOT, (double)cyc[1] / TOT, (double)cyc[2] / TOT, TOT);
+#endif
   }
 #undef ALZ_EOFF
 }
+#undef ALZ_LOOK_CLOCK
+#undef ALZ_LOOK_MARK
 
 typedef void (*look_fn)(LArgs);
 static look_fn pick_look(unsigned pb, unsigned pa) {
@@ -449,10 +592,10 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
-  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + kSlot + (size_t)kMaxW * 256;
+  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(128), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(192), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = K * L;
   *kernel_name = "k_look";

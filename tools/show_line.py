@@ -1,5 +1,11 @@
 """Print the headline and the secondary entries of a bench.py JSON line (file argument) compactly."""
 import json, sys
+seen = set()
+for ln in open(sys.argv[1]):
+  if ln.startswith("k_") and ln not in seen:        # device-side printf of an -DALZ_ABLATE build (first of each)
+    seen.add(ln)
+    if len(seen) <= 6:
+      print("  " + ln.rstrip())
 try:
   d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
 except Exception as exc:
