@@ -41,10 +41,19 @@ namespace {
 constexpr int kChunks = 8;                   // 1 KiB DMA transfers per tile
 constexpr int kNT = 8;                       // tiles per chunk (L = 512)
 #ifndef ALZ_LOOK_SLOTS
-#define ALZ_LOOK_SLOTS 16
+#define ALZ_LOOK_SLOTS 17
 #endif
 #ifndef ALZ_LOOK_LEAD
 #define ALZ_LOOK_LEAD 3
+#endif
+#ifndef ALZ_LOOK_CHUNKWAIT
+#define ALZ_LOOK_CHUNKWAIT 1
+#endif
+#ifndef ALZ_LOOK_VAR
+#define ALZ_LOOK_VAR 0       // experiments (tools/variants only): 1 no LDS writes, 2 no LDS reads in the replay's tile
+#endif
+#ifndef ALZ_LOOK_STORE_LAG
+#define ALZ_LOOK_STORE_LAG 2
 #endif
 #ifndef ALZ_LOOK_LAG
 #define ALZ_LOOK_LAG 11
@@ -132,6 +141,10 @@ __device__ __forceinline__ void look_tile(char *cur, const char *nxt, int q, dou
   double n1 = 0.0, n2 = 0.0, n3 = 0.0;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
+#if (ALZ_LOOK_VAR & 2)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(pr[(k + 2) % 4][u]));
+#else
     if (k + 2 < NCH) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) pr[(k + 2) % 4][u] = *reinterpret_cast<const double *>(cur + ((k + 2) * 8 + u) * kStep);
@@ -143,12 +156,28 @@ __device__ __forceinline__ void look_tile(char *cur, const char *nxt, int q, dou
         pr[(k + 2) % 4][u] = *reinterpret_cast<const double *>(nxt + ((kk == 0 && u < 3 && u < q) ? q : r) * kStep);
       }
     }
+#endif
     if (k == NCH - 2) {                                    // before the last group overwrites them
       n1 = *reinterpret_cast<const double *>(cur + (q + T - 1) * kStep);
       n2 = *reinterpret_cast<const double *>(cur + (q + T - 2) * kStep);
       n3 = *reinterpret_cast<const double *>(cur + (q + T - 3) * kStep);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if ALZ_LOOK_CHUNKWAIT
+    {
+      // ONE wait per group for its four paired reads, through the builtin so that the compiler's wait-count pass sees
+      // it and does not put a wait of its own into the chain (k_duo's finding).  LDS operations issued after group k's
+      // reads that may stay outstanding: one paired write per group, four paired reads per group, and the eight reads
+      // that open the next tile (its first rows and this tile's last three); a count too small only waits longer.
+      switch (k == 0 ? 4 : k == 1 ? 9 : k < NCH - 2 ? 10 : 13) {   // (k is an unrolled loop index: folded at compile time)
+        case 4: __builtin_amdgcn_s_waitcnt(0xC47F); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0xC97F); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0xCA7F); break;
+        default: __builtin_amdgcn_s_waitcnt(0xCD7F); break;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       double acc = pr[k % 4][u];
@@ -176,11 +205,28 @@ __device__ __forceinline__ void look_tile(char *cur, const char *nxt, int q, dou
       m2 = m1;
       m1 = acc;
       t2 = t2n;
+#if !(ALZ_LOOK_VAR & 1)
       if ((u & 3) == 3) *reinterpret_cast<double *>(cur + (k * 8 + u) * kStep) = acc;   // rows u - 3 .. u, one per copy
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   st = LookState{m1, m2, t2, n1, n2, n3};
+}
+
+// The sum of a value over the wave's four 16-lane rows, in every lane: gfx950's row / half swaps (two VALU operations per
+// 32-bit half and level) instead of four LDS round trips through ds_bpermute.  v_permlane16_swap exchanges the odd rows
+// of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half: with
+// both operands the same value, the two results hold the two partners of every lane.
+__device__ __forceinline__ double sum_rows(double x) {
+  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  auto a0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto a1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double y = __hiloint2double((int)a1[0], (int)a0[0]) + __hiloint2double((int)a1[1], (int)a0[1]);
+  lo = (unsigned)__double2loint(y); hi = (unsigned)__double2hiint(y);
+  auto b0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b1[0], (int)b0[0]) + __hiloint2double((int)b1[1], (int)b0[1]);
 }
 
 template <int N>
@@ -201,13 +247,18 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   constexpr int kStep = G * 8;
   // pipeline offsets, in tiles of this workgroup's own tile sequence (see the header): in interval i
   //   LOAD   queues the DMA of tile i + kDmaLead and prepares tile i + 1;
-  //   HELP   stores tile i - kRecLag - 1, forms tile i's part of its chunk's zero-state end state (published with the
+  //   HELP   stores tile i - kRecLag - kStoreLag, forms tile i's part of its chunk's zero-state end state (published with the
   //          chunk's last tile), asks for the neighbours' states three intervals before the replay opens a chunk and
   //          chains the chunk's start state from them one interval before;
   //   REPLAY works on tile i - kRecLag.
   constexpr int kRecLag = ALZ_LOOK_LAG, kDmaLead = ALZ_LOOK_LEAD;
-  static_assert(kSlots >= kRecLag + 1 + kDmaLead + 1, "a slot is stored before it is refilled");
+  // the store follows the replay by kStoreLag intervals: with 2, the replay wave need not wait for its last LDS write
+  // before the barrier (the next tile's counted waits retire it)
+  constexpr int kStoreLag = ALZ_LOOK_STORE_LAG;
+  static_assert(kSlots >= kRecLag + kStoreLag + kDmaLead + 1, "a slot is stored before it is refilled");
   static_assert(kRecLag >= NT + 3, "a chunk's state is asked for after the neighbour has published its own");
+  static_assert((kRecLag - 2) % NT != NT - 1 && (kRecLag - 3) % NT != NT - 1,
+                "no chunk ends (two state stores) between a request and its use");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -218,7 +269,7 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   const int64_t K = p.n_chunks;
   const int my_chunks = (int)((K - w + W - 1) / W);           // chunks w, w + W, ...
   const int TOT = my_chunks * NT;
-  const int n_iv = TOT + kRecLag + 2;
+  const int n_iv = TOT + kRecLag + kStoreLag + 1;
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
   char *zlds = hist + kSlots * kHist;                         // [kMaxW][2][16] doubles: the requested chunk end states
@@ -386,91 +437,9 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     __builtin_amdgcn_s_barrier();
     ALZ_LOOK_CLOCK(5)                                          // chain / store / zero-state / request / barrier
     for (int i = 0; i < n_iv; ++i) {
-      // (1) one interval before the replay opens chunk number seq of this workgroup: its start state
-      {
-        const int t_c = i + 1 - kRecLag;                       // the replay's tile in the NEXT interval
-        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0 && (t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
-          const int seq = t_c / NT;
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transfers asked for two intervals ago
-#pragma unroll
-          for (int e = 0; e < kMaxW; ++e) {
-            if (e < req_cnt) {
-              const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
-              unsigned long long a1 = zl[0], a2 = zl[16];
-              if (a1 == kSentinel || a2 == kSentinel) {        // not published when the transfer read it (rare): poll
-                const unsigned long long *src = zg + (req_first + e) * 32 + cl;
-                int spins = gave_up ? kSpinCap : 0;
-                do {
-                  a1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  a2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if (a1 != kSentinel && a2 != kSentinel) break;
-                  __builtin_amdgcn_s_sleep(8);
-                } while (++spins < ALZ_LOOK_CAP(p));
-                if (a1 == kSentinel || a2 == kSentinel) { *p.err = 1; a1 = 0; a2 = 0; gave_up = true; }
-              }
-              const double z1 = __longlong_as_double((long long)a1), z2 = __longlong_as_double((long long)a2);
-              const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
-              const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
-              S1 = n1; S2 = n2;
-            }
-          }
-          if (q == 0) {
-            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
-            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
-          }
-        }
-      }
-      ALZ_LOOK_MARK(0)
-      // (2) the tile the replay finished in the last interval
-      {
-        const int ts = i - kRecLag - 1;
-        if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) {
-          const char *ys = smem + (ts % kSlots) * kSlot;
-          double *yt = yg + tile_row(ts) * p.ldy;
-          dbl2 v[kChunks];
-#pragma unroll
-          for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
-#pragma unroll
-          for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
-        }
-      }
-      ALZ_LOOK_MARK(1)
-      // (3) tile i's part of its chunk's zero-state end state (prepared in the last interval)
-      if (i < TOT && !ALZ_DBG(p, 64)) {
-        const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
-        double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          const double a = *reinterpret_cast<const double *>(zsrc + j * 512);
-          const double b = *reinterpret_cast<const double *>(zsrc + (j + 1) * 512);
-          u1 = __builtin_fma(g1[j], a, u1);
-          u2 = __builtin_fma(g2[j], a, u2);
-          v1 = __builtin_fma(g1[j + 1], b, v1);
-          v2 = __builtin_fma(g2[j + 1], b, v2);
-        }
-        // the four row classes of a channel sit 16 lanes apart; then carry the chunk's sum over this tile
-        double z1 = u1 + v1, z2 = u2 + v2;
-        z1 += __shfl_xor(z1, 16);
-        z2 += __shfl_xor(z2, 16);
-        z1 += __shfl_xor(z1, 32);
-        z2 += __shfl_xor(z2, 32);
-        const int tt = i % NT;
-        const double c1 = __builtin_fma(M11, Z1, __builtin_fma(M12, Z2, z1));
-        const double c2 = __builtin_fma(M21, Z1, __builtin_fma(M22, Z2, z2));
-        Z1 = tt == 0 ? z1 : c1;
-        Z2 = tt == 0 ? z2 : c2;
-        if (tt == NT - 1 && q == 0) {
-          const int64_t j = (int64_t)w + (int64_t)(i / NT) * W;
-          __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(Z1), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(Z2), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      ALZ_LOOK_MARK(2)
-      // (4) three intervals before the replay opens a chunk: ask for the states its start state is chained from, ALL
-      // AT ONCE, as four 1 KiB global -> LDS transfers the compiler does not know about (loads into registers made it
-      // wait for them on the spot)
+      // (1) three intervals before the replay opens a chunk, first thing: ask for the states its start state is chained
+      // from, ALL AT ONCE, as four 1 KiB global -> LDS transfers the compiler does not know about (loads into registers
+      // made it wait for them on the spot); they have two intervals to land
       {
         const int t_q = i + 3 - kRecLag;
         if (t_q >= 0 && t_q < TOT && (t_q % NT) == 0 && (t_q > 0 || w > 0) && !ALZ_DBG(p, 32)) {
@@ -485,6 +454,114 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
           }
         }
       }
+      ALZ_LOOK_MARK(3)
+      // (2) one interval before the replay opens chunk number seq of this workgroup: its start state
+      {
+        const int t_c = i + 1 - kRecLag;                       // the replay's tile in the NEXT interval
+        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0 && (t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+          const int seq = t_c / NT;
+          // the transfers asked for two intervals ago; the only vector-memory operations of this wave since then are
+          // the tile stores (eight each) of those two intervals, where they had a tile to store -- no chunk ends
+          // between a request and its use
+          const int ts1 = i - 1 - kRecLag - kStoreLag, ts2 = i - 2 - kRecLag - kStoreLag;
+          const int n_st = ALZ_DBG(p, 8) ? 0 : (ts1 >= 0 && ts1 < TOT ? 1 : 0) + (ts2 >= 0 && ts2 < TOT ? 1 : 0);
+          if (n_st == 2) wait_vm<2 * kChunks>();
+          else if (n_st == 1) wait_vm<kChunks>();
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // all the landed states at once (one LDS round trip), then the chain; a state that was not yet published when
+          // the transfer read it (rare) is polled for
+          unsigned long long a1[kMaxW], a2[kMaxW];
+          bool missing = false;
+#pragma unroll
+          for (int e = 0; e < kMaxW; ++e) {
+            const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
+            a1[e] = zl[0];
+            a2[e] = zl[16];
+            missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
+          }
+          if (__builtin_amdgcn_ballot_w64(missing) != 0) {
+#pragma unroll
+            for (int e = 0; e < kMaxW; ++e) {
+              if (e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel)) {
+                const unsigned long long *src = zg + (req_first + e) * 32 + cl;
+                unsigned long long b1, b2;
+                int spins = gave_up ? kSpinCap : 0;
+                do {
+                  b1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  b2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (b1 != kSentinel && b2 != kSentinel) break;
+                  __builtin_amdgcn_s_sleep(8);
+                } while (++spins < ALZ_LOOK_CAP(p));
+                if (b1 == kSentinel || b2 == kSentinel) { *p.err = 1; b1 = 0; b2 = 0; gave_up = true; }
+                a1[e] = b1;
+                a2[e] = b2;
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < kMaxW; ++e) {
+            if (e < req_cnt) {
+              const double z1 = __longlong_as_double((long long)a1[e]), z2 = __longlong_as_double((long long)a2[e]);
+              const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
+              const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
+              S1 = n1; S2 = n2;
+            }
+          }
+          if (q == 0) {
+            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
+            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
+          }
+        }
+      }
+      ALZ_LOOK_MARK(0)
+      // (3) tile i's rows for (4), read first: they arrive while the finished tile is being stored
+      const bool zs_on = i < TOT && !ALZ_DBG(p, 64);
+      double zp[16];
+      if (zs_on) {
+        const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zp[j] = *reinterpret_cast<const double *>(zsrc + j * 512);
+      }
+      // the tile the replay finished in the last interval
+      {
+        const int ts = i - kRecLag - kStoreLag;
+        if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) {
+          const char *ys = smem + (ts % kSlots) * kSlot;
+          double *yt = yg + tile_row(ts) * p.ldy;
+          dbl2 v[kChunks];
+#pragma unroll
+          for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+#pragma unroll
+          for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
+        }
+      }
+      ALZ_LOOK_MARK(1)
+      // (4) tile i's part of its chunk's zero-state end state (the tile was prepared in the last interval)
+      if (zs_on) {
+        double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          u1 = __builtin_fma(g1[j], zp[j], u1);
+          u2 = __builtin_fma(g2[j], zp[j], u2);
+          v1 = __builtin_fma(g1[j + 1], zp[j + 1], v1);
+          v2 = __builtin_fma(g2[j + 1], zp[j + 1], v2);
+        }
+        // the four row classes of a channel sit 16 lanes apart; then carry the chunk's sum over this tile
+        const double z1 = sum_rows(u1 + v1), z2 = sum_rows(u2 + v2);
+        const int tt = i % NT;
+        const double c1 = __builtin_fma(M11, Z1, __builtin_fma(M12, Z2, z1));
+        const double c2 = __builtin_fma(M21, Z1, __builtin_fma(M22, Z2, z2));
+        Z1 = tt == 0 ? z1 : c1;
+        Z2 = tt == 0 ? z2 : c2;
+        if (tt == NT - 1 && q == 0) {
+          const int64_t j = (int64_t)w + (int64_t)(i / NT) * W;
+          __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(Z1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(Z2), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      ALZ_LOOK_MARK(2)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ALZ_LOOK_MARK(3)
       __builtin_amdgcn_s_barrier();
@@ -534,13 +611,12 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
       sr = sn;
       tic = (tic + 1 == NT) ? 0 : tic + 1;
       par ^= (tic == 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (kStoreLag < 2 || t == TOT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ALZ_LOOK_MARK(1)
       __builtin_amdgcn_s_barrier();
       ALZ_LOOK_MARK(2)
     }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < kStoreLag + 1; ++i) __builtin_amdgcn_s_barrier();
 #ifdef ALZ_ABLATE
     if (blockIdx.x == 5 && lane == 0 && (p.dbg & 256))
       printf("k_look replay wave, cycles per tile: tile %.1f tail %.1f barrier %.1f (%d tiles)\n",

@@ -8,7 +8,7 @@
 #   bench[:ARGS]     python bench.py ARGS           (':' separates, '+' stands for a blank)
 #   tune:ENV:ARGS    the same through the -DALZ_TUNING library (tools/variants/libalzhip_tuning.so) with ENV set
 #   abl:ENV:ARGS     the same through the -DALZ_ABLATE library (timing ablations: WRONG output by design)
-#   lib:NAME:ARGS    python bench.py ARGS through tools/variants/libalzhip_NAME.so
+#   lib:NAME[,ENV]:ARGS  python bench.py ARGS through tools/variants/libalzhip_NAME.so (with ENV set)
 #   py:SCRIPT[:ENV]  python tools/SCRIPT
 #   stats[:ARGS]     rocprofv3 --kernel-trace --stats of python bench.py ARGS -> kernel_stats.csv / kernel_dispatches.csv
 #   pmc:CTR:ARGS     one rocprofv3 --pmc CTR pass (+ kernel trace only) of python bench.py ARGS, summarised per kernel
@@ -32,7 +32,8 @@ for step in "$@"; do
            echo "tune [$a] [$b] rc=$?"; python tools/show_line.py $O/tune_$i.json ;;
     abl)   env $a ALZ_LIBRARY=$R/tools/variants/libalzhip_ablate.so timeout 300 python bench.py $b > $O/abl_$i.json 2> $O/abl_$i.err
            echo "abl [$a] [$b] rc=$?"; python tools/show_line.py $O/abl_$i.json ;;
-    lib)   ALZ_LIBRARY=$R/tools/variants/libalzhip_$a.so timeout 900 python bench.py $b > $O/lib_$i.json 2> $O/lib_$i.err
+    lib)   IFS=',' read -r nm ev <<< "$a"
+           env $ev ALZ_LIBRARY=$R/tools/variants/libalzhip_$nm.so timeout 900 python bench.py $b > $O/lib_$i.json 2> $O/lib_$i.err
            echo "lib [$a] [$b] rc=$?"; python tools/show_line.py $O/lib_$i.json ;;
     py)    env $b timeout 900 python tools/$a > $O/py_$i.log 2>&1; echo "py [$a] rc=$?"; tail -30 $O/py_$i.log ;;
     stats) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$i -o s -- python $R/bench.py $a > $O/stats_$i.log 2>&1
