@@ -376,9 +376,10 @@ class FilterBank(object):
   def set_time_parallel(self, chunk=True):
     """Opt into the time-parallel mode for narrow banks (alz_bank_set_time_parallel): the time axis
     of every block is cut into chunks that run side by side (zero-state pass, propagation of the
-    chunk states, replay).  ``chunk``: True / -1 = chunk length chosen by the engine, False / 0 =
-    off, a positive int = samples per chunk, "one-pass" / -2 = the one-pass form (512-sample chunks
-    resident in LDS: the block is read once; single biquad-class sections on time-major blocks).
+    chunk states, replay).  ``chunk``: True / -1 = form and chunk length chosen by the engine (from
+    256 channels up on time-major blocks the ONE-PASS form: 512-sample chunks resident in LDS, the
+    block read once), False / 0 = off, a positive int = samples per chunk (three launches),
+    "one-pass" / -2 = the one-pass form wherever it applies (single biquad-class sections).
     Not bit-identical to the reference (the contract's 1e-6 with orders of magnitude to spare); off
     by default."""
     n = -2 if chunk == "one-pass" else -1 if chunk is True else 0 if not chunk else int(chunk)

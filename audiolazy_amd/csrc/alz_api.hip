@@ -530,7 +530,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       if (h->time_parallel != 0 && whole && !generic) {
         // opt-in time-parallel mode: whole chunks of the whole bank; the ragged rest continues
         // serially from the state the replay pass left
-        rc = alz::launch_scan(sec, s, io, st, h->time_parallel == ALZ_TP_AUTO ? 0 : h->time_parallel, &h->scan[(size_t)s],
+        rc = alz::launch_scan(sec, s, io, st, h->time_parallel, &h->scan[(size_t)s],
                               &done_n, &name);
         if (rc) return rc;
         if (done_n > 0) done_c = c_count;

@@ -5,27 +5,34 @@
 // writes the result) -- 24 bytes of HBM traffic per sample for 16 algorithmic.  Here a chunk is small enough to stay
 // in LDS between the two uses (512 samples x 16 channels = 64 KiB), so the block is read ONCE:
 //
-//   * a workgroup owns 16 channels and every W-th chunk of them (W workgroups per channel group, all resident);
-//     two waves pipeline over 64-sample tiles with one barrier per tile, as k_duo does:
-//       AUX  queues the tile DMA (global_load_lds) into a ring of 16 tile slots, turns a landed tile into
-//            feed-forward sums p[n] IN PLACE, and stores finished tiles;
-//       the recurrence wave runs BOTH passes in its 64 lanes -- 16 channels x 2 roles x 2 skewed copies:
-//            ZS lanes  the recurrence over p from a ZERO state, a chunk and three tiles ahead, only for the chunk's
-//                      end state z_j, which they publish in global memory (64-bit agent-scope atomic stores into an
-//                      array pre-filled with a NaN pattern no computation produces: no flags, no fences);
-//            REC lanes the recurrence from the TRUE state, overwriting p with y.
+//   * a workgroup owns 16 channels and every W-th chunk of them (W workgroups per channel group, all resident, one per
+//     CU); its three waves (on three SIMDs) each loop over the workgroup's 64-sample tiles at their own pace and meet
+//     only through progress counters in LDS:
+//       LOAD    queues the tile DMA (global_load_lds) into a ring of 17 tile slots and turns a landed tile into
+//               feed-forward sums p[n] IN PLACE;
+//       REPLAY  runs only the serial part y[n] = (p[n] - a1 y[n-1]) - a2 y[n-2] from the chunk's TRUE start state,
+//               k_duo's way (16 channels x 4 skewed copies, one LDS write per four rows), overwriting p with y; its
+//               register ring of p rows runs on across tile boundaries (p is prepared many tiles ahead);
+//       HELP    stores finished tiles, and forms every chunk's zero-state end state z_j WITHOUT a second recurrence:
+//               the end state of a tile is a dot product of its p rows with the impulse response of 1/A(z) (32 FMAs
+//               per lane and tile, weights computed once per launch), carried from tile to tile through A^64 and
+//               published in global memory with the chunk's last tile (64-bit agent-scope atomic stores into an array
+//               pre-filled with a NaN pattern no computation produces: no flags, no fences).
 //   * the true state of chunk j needs no other workgroup's replay: it is chained in zero-state space,
-//     S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}   (M = A^L per channel, the matrix alz_scan.hip
-//     caches), from the workgroup's own previous start state and the z of the W chunks in between, fetched by four
-//     1 KiB global -> LDS transfers two tiles before the replay needs them.  Waits only ever point to smaller
-//     chunk indices and earlier intervals, and every workgroup of the launch is resident (one per CU): no deadlock;
-//     a bounded spin guards against the impossible.
+//     S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}   (M = A^512 per channel, the matrix alz_scan.hip
+//     caches), by HELP, from the workgroup's own previous start state and the z of the W chunks in between; LOAD
+//     fetches those with four 1 KiB global -> LDS transfers three tiles before HELP needs them (its transfer queue has
+//     no stores in it, so the wait for its next tile covers them).  Waits only ever point to smaller chunk indices
+//     and earlier tiles, and every workgroup of the launch is resident: no deadlock; bounded spins guard against the
+//     impossible.
 //
-// What was measured on the way (profiles/NOTES_r03.md 7): a third wave for the zero-state pass slowed the replay wave
-// by 15 %; run-time role / chunk-start tests inside the 64 steps made it 52 cycles per step; chunk states loaded into
-// registers made the compiler wait for them on the spot.  This form: 214 Gsamples/s at 512 channels x 2^20 with
-// 16 B/sample of HBM traffic, against 228 with 24 B/sample for the three-launch form -- hence an option
-// (ALZ_TP_ONE_PASS), not the default.
+// What was measured on the way (profiles/NOTES_r03.md 7, profiles/r03_look_ablations.log): the zero-state pass as a
+// second recurrence -- in a third wave, or in half the replay wave's lanes -- cost the replay wave 15 .. 40 % (its
+// dependent chain of 3 FP64 operations per step is the budget: 28.3 cycles per step, 64 steps per tile); as a dot
+// product it is free.  One barrier per tile made every wave wait for the slowest of each interval (memory stalls
+// included): counters instead.  260 Gsamples/s at 512 channels x 2^20 (267 at 2048) with 16.5 B/sample of HBM
+// traffic, against 237 with 24 B/sample for the three-launch form: ALZ_TP_AUTO takes it from 256 channels up.  The
+// replay wave alone runs at 276; the chain itself would allow ~305 at the clock the chip holds under this load.
 //
 // Every output sample is still the reference's DF-I statement (lazy_filters.py:197-257) in the kernels' own order;
 // only the chunk-start states carry a different rounding -- the same numerics as the three-launch mode (1e-10 ..
@@ -54,6 +61,9 @@ constexpr int kNT = 8;                       // tiles per chunk (L = 512)
 #endif
 #ifndef ALZ_LOOK_STORE_LAG
 #define ALZ_LOOK_STORE_LAG 2
+#endif
+#ifndef ALZ_LOOK_POLL_SLEEP
+#define ALZ_LOOK_POLL_SLEEP 1
 #endif
 #ifndef ALZ_LOOK_LAG
 #define ALZ_LOOK_LAG 11
@@ -85,7 +95,7 @@ struct LArgs {
   int *err;                    // set when a spin ran into its cap
   int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no replay arithmetic,
                                // 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain,
-                               // 64 no zero-state sums; 256 / 512 print the replay / the other waves' cycle counts
+                               // 64 no zero-state sums; with -DALZ_LOOK_TIMING 256 / 512 print the replay / the other waves' cycle counts
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -229,10 +239,28 @@ __device__ __forceinline__ double sum_rows(double x) {
   return __hiloint2double((int)b1[0], (int)b0[0]) + __hiloint2double((int)b1[1], (int)b0[1]);
 }
 
+// Progress counters in LDS, one writer each.  The LDS executes a wave's operations in the order it issued them, so a
+// counter written after the data (or after the reads that free a slot) needs no wait in between, and a reader that has
+// seen the counter sees the data; the compiler is held to the same order by the empty asm statements.
+enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_REQUEST, F_COUNT = 8 };
+__device__ __forceinline__ void publish(int *flag, int value, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void await(const int *flag, int need, int &cap, int *err) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+    __builtin_amdgcn_s_sleep(ALZ_LOOK_POLL_SLEEP);
+    if (++spins > cap) { *err = 1; cap = 0; break; }      // (cannot happen: every wait points to earlier work; a wave
+  }                                                        //  that gave up once no longer waits at all)
+  asm volatile("" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-#ifdef ALZ_ABLATE
+#if defined(ALZ_ABLATE) && defined(ALZ_LOOK_TIMING)     // (its own switch: a clock read also waits for the wave's LDS operations)
 #define ALZ_LOOK_CLOCK(n) long long cyc[n] = {}, c_prev = __builtin_readcyclecounter();
 #define ALZ_LOOK_MARK(k) { const long long c_now = __builtin_readcyclecounter(); cyc[k] += c_now - c_prev; c_prev = c_now; }
 #else
@@ -245,20 +273,19 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64, NT = kNT;
   constexpr int kStep = G * 8;
-  // pipeline offsets, in tiles of this workgroup's own tile sequence (see the header): in interval i
-  //   LOAD   queues the DMA of tile i + kDmaLead and prepares tile i + 1;
-  //   HELP   stores tile i - kRecLag - kStoreLag, forms tile i's part of its chunk's zero-state end state (published with the
-  //          chunk's last tile), asks for the neighbours' states three intervals before the replay opens a chunk and
-  //          chains the chunk's start state from them one interval before;
-  //   REPLAY works on tile i - kRecLag.
-  constexpr int kRecLag = ALZ_LOOK_LAG, kDmaLead = ALZ_LOOK_LEAD;
-  // the store follows the replay by kStoreLag intervals: with 2, the replay wave need not wait for its last LDS write
-  // before the barrier (the next tile's counted waits retire it)
-  constexpr int kStoreLag = ALZ_LOOK_STORE_LAG;
+  // The three waves each run their own loop over this workgroup's tile sequence and meet only through progress
+  // counters (no barrier after the first: a barrier per tile made every wave wait for the slowest of each interval,
+  // memory stalls included).  In its iteration i
+  //   LOAD    queues the DMA of tile i + kDmaLead (its slot must have been stored) and prepares tile i + 1; three
+  //           iterations before the replay opens a chunk it also asks for the neighbours' chunk states;
+  //   HELP    chains the start state of the chunk the replay opens at tile i + 1 - kRecLag, forms tile i's part of its
+  //           chunk's zero-state end state (published with the chunk's last tile) and stores tile
+  //           i - kRecLag - kStoreLag (the replay must be done with it);
+  //   REPLAY  works on tile i, waiting only at a chunk's first tile for the chunk's start state -- which implies that
+  //           the chunk's tiles are prepared and that HELP has read them (it overwrites p with y).
+  constexpr int kRecLag = ALZ_LOOK_LAG, kDmaLead = ALZ_LOOK_LEAD, kStoreLag = ALZ_LOOK_STORE_LAG;
   static_assert(kSlots >= kRecLag + kStoreLag + kDmaLead + 1, "a slot is stored before it is refilled");
   static_assert(kRecLag >= NT + 3, "a chunk's state is asked for after the neighbour has published its own");
-  static_assert((kRecLag - 2) % NT != NT - 1 && (kRecLag - 3) % NT != NT - 1,
-                "no chunk ends (two state stores) between a request and its use");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -274,6 +301,8 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
   char *zlds = hist + kSlots * kHist;                         // [kMaxW][2][16] doubles: the requested chunk end states
   char *sbuf = zlds + kMaxW * 256;                            // [2][2][16] doubles: chunk start states, by chunk parity
+  int *flags = reinterpret_cast<int *>(sbuf + 512);           // [F_COUNT] progress counters
+  int cap = 1 << 22;                                          // (~0.3 s of polling)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int lane_off = cl * 8;
 #define ALZ_EOFF(u) ((u) * G * 8 + (((u) * G) >> 7) * 16)
@@ -283,6 +312,8 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   double na1 = 0, na2 = 0;
   if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
   if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
+  if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0;
+  __syncthreads();
 
   if (wave == 1) {
     // ------------------------------ LOAD ------------------------------
@@ -358,34 +389,64 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     for (int t = 0; t < kDmaLead && t < TOT; ++t) queue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     prepare_tile(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ALZ_LOOK_CLOCK(4)                                          // queue / wait / prepare / barrier
+    publish(flags + F_PREPARED, 1, lane);
+    int req_seq = -1;                                          // a request whose transfers are in flight
+    ALZ_LOOK_CLOCK(4)                                          // slot wait / queue / transfer wait / prepare
     for (int i = 0; i < n_iv; ++i) {
-      if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
+      // the slot of tile i + kDmaLead must have been stored (this also paces the idle iterations of the tail)
+      {
+        int need = i + kDmaLead - kSlots + 1;
+        need = need > TOT ? TOT : need;
+        if (need > 0) await(flags + F_STORED, need, cap, p.err);
+      }
       ALZ_LOOK_MARK(0)
+      // three iterations before HELP chains a chunk's start state: ask for the states it is chained from, ALL AT ONCE,
+      // as four 1 KiB global -> LDS transfers.  They sit in this wave's transfer queue between two tiles, so the next
+      // iteration's wait for its tile covers them too (this wave has no stores to wait for; HELP does)
+      int asked = -1;
+      {
+        const int t_q = i + 3 - kRecLag;
+        if (t_q >= 0 && t_q < TOT && (t_q % NT) == 0 && (t_q > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+          const int64_t seq = t_q / NT, cj = (int64_t)w + seq * W;
+          const int64_t req_first = seq > 0 ? cj - W : 0;    // z_first .. z_{cj-1}
+#pragma unroll
+          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
+            int64_t ch = req_first + 4 * o + (lane >> 4);
+            if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
+            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
+          }
+          asked = (int)seq;
+        }
+      }
+      if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
+      ALZ_LOOK_MARK(1)
+      // issued after tile i + 1's transfers: those of kDmaLead - 1 more tiles, and this iteration's request if any
+      // (the last tiles of the sequence simply wait for everything)
+      static_assert((kDmaLead - 1) * (kChunks + 1) + kMaxW / 4 <= 63, "vmcnt is a 6-bit count");
+      if (i + kDmaLead < TOT) {
+        if (asked >= 0) wait_vm<(kDmaLead - 1) * (kChunks + 1) + kMaxW / 4>();
+        else wait_vm<(kDmaLead - 1) * (kChunks + 1)>();
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (asked >= 0) { publish(flags + F_REQUEST, asked + 1, lane); asked = -1; }
+      }
+      if (req_seq >= 0) publish(flags + F_REQUEST, req_seq + 1, lane);   // (older than everything just waited for)
+      req_seq = asked;
       if (i + 1 < TOT) {
-        // issued after tile i + 1's transfers: those of kDmaLead - 1 more tiles (the last tiles of the sequence simply
-        // wait for everything)
-        static_assert((kDmaLead - 1) * (kChunks + 1) <= 63, "vmcnt is a 6-bit count");
-        if (i + kDmaLead < TOT) wait_vm<(kDmaLead - 1) * (kChunks + 1)>();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
           const char *xs = smem + ((i + 1) % kSlots) * kSlot + lane_off;
           if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
           if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
         }
-        ALZ_LOOK_MARK(1)
+        ALZ_LOOK_MARK(2)
         if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
+        publish(flags + F_PREPARED, i + 2, lane);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ALZ_LOOK_MARK(2)
-      __builtin_amdgcn_s_barrier();
       ALZ_LOOK_MARK(3)
     }
-#ifdef ALZ_ABLATE
+#if defined(ALZ_ABLATE) && defined(ALZ_LOOK_TIMING)
     if (blockIdx.x == 5 && lane == 0 && (p.dbg & 512))
-      printf("k_look LOAD wave, cycles per interval: queue %.1f wait %.1f prepare %.1f barrier %.1f\n",
+      printf("k_look LOAD wave, cycles per iteration: slot wait %.1f queue %.1f transfer wait %.1f prepare %.1f\n",
              (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,116 +488,94 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     }
     double Z1 = 0.0, Z2 = 0.0;
     bool gave_up = false;
-    int64_t req_first = 0;
-    int req_cnt = 0;
-    if (w == 0 && q == 0) {                                   // chunk 0 starts from the bank's state
-      *reinterpret_cast<double *>(sbuf + cl * 8) = S1;
-      *reinterpret_cast<double *>(sbuf + 128 + cl * 8) = S2;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ALZ_LOOK_CLOCK(5)                                          // chain / store / zero-state / request / barrier
+    ALZ_LOOK_CLOCK(4)                                          // chain / waits / store / zero-state
     for (int i = 0; i < n_iv; ++i) {
-      // (1) three intervals before the replay opens a chunk, first thing: ask for the states its start state is chained
-      // from, ALL AT ONCE, as four 1 KiB global -> LDS transfers the compiler does not know about (loads into registers
-      // made it wait for them on the spot); they have two intervals to land
+      // (1) the start state of the chunk the replay opens at tile i + 1 - kRecLag
       {
-        const int t_q = i + 3 - kRecLag;
-        if (t_q >= 0 && t_q < TOT && (t_q % NT) == 0 && (t_q > 0 || w > 0) && !ALZ_DBG(p, 32)) {
-          const int64_t seq = t_q / NT, cj = (int64_t)w + seq * W;
-          req_first = seq > 0 ? cj - W : 0;                  // z_first .. z_{cj-1}
-          req_cnt = (int)(cj - req_first);
-#pragma unroll
-          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
-            int64_t ch = req_first + 4 * o + (lane >> 4);
-            if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
-            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
-          }
-        }
-      }
-      ALZ_LOOK_MARK(3)
-      // (2) one interval before the replay opens chunk number seq of this workgroup: its start state
-      {
-        const int t_c = i + 1 - kRecLag;                       // the replay's tile in the NEXT interval
-        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0 && (t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+        const int t_c = i + 1 - kRecLag;
+        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0) {
           const int seq = t_c / NT;
-          // the transfers asked for two intervals ago; the only vector-memory operations of this wave since then are
-          // the tile stores (eight each) of those two intervals, where they had a tile to store -- no chunk ends
-          // between a request and its use
-          const int ts1 = i - 1 - kRecLag - kStoreLag, ts2 = i - 2 - kRecLag - kStoreLag;
-          const int n_st = ALZ_DBG(p, 8) ? 0 : (ts1 >= 0 && ts1 < TOT ? 1 : 0) + (ts2 >= 0 && ts2 < TOT ? 1 : 0);
-          if (n_st == 2) wait_vm<2 * kChunks>();
-          else if (n_st == 1) wait_vm<kChunks>();
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          // all the landed states at once (one LDS round trip), then the chain; a state that was not yet published when
-          // the transfer read it (rare) is polled for
-          unsigned long long a1[kMaxW], a2[kMaxW];
-          bool missing = false;
-#pragma unroll
-          for (int e = 0; e < kMaxW; ++e) {
-            const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
-            a1[e] = zl[0];
-            a2[e] = zl[16];
-            missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
-          }
-          if (__builtin_amdgcn_ballot_w64(missing) != 0) {
+          if ((t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+            const int64_t cj = (int64_t)w + (int64_t)seq * W;
+            const int64_t req_first = seq > 0 ? cj - W : 0;  // z_first .. z_{cj-1} (LOAD asked for them)
+            const int req_cnt = (int)(cj - req_first);
+            await(flags + F_REQUEST, seq + 1, cap, p.err);
+            // all the landed states at once (one LDS round trip), then the chain; a state that was not yet published
+            // when the transfer read it (rare) is polled for
+            unsigned long long a1[kMaxW], a2[kMaxW];
+            bool missing = false;
 #pragma unroll
             for (int e = 0; e < kMaxW; ++e) {
-              if (e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel)) {
-                const unsigned long long *src = zg + (req_first + e) * 32 + cl;
-                unsigned long long b1, b2;
-                int spins = gave_up ? kSpinCap : 0;
-                do {
-                  b1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  b2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if (b1 != kSentinel && b2 != kSentinel) break;
-                  __builtin_amdgcn_s_sleep(8);
-                } while (++spins < ALZ_LOOK_CAP(p));
-                if (b1 == kSentinel || b2 == kSentinel) { *p.err = 1; b1 = 0; b2 = 0; gave_up = true; }
-                a1[e] = b1;
-                a2[e] = b2;
+              const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
+              a1[e] = zl[0];
+              a2[e] = zl[16];
+              missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
+            }
+            if (__builtin_amdgcn_ballot_w64(missing) != 0) {
+#pragma unroll
+              for (int e = 0; e < kMaxW; ++e) {
+                if (e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel)) {
+                  const unsigned long long *src = zg + (req_first + e) * 32 + cl;
+                  unsigned long long b1, b2;
+                  int spins = gave_up ? kSpinCap : 0;
+                  do {
+                    b1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (b1 != kSentinel && b2 != kSentinel) break;
+                    __builtin_amdgcn_s_sleep(8);
+                  } while (++spins < ALZ_LOOK_CAP(p));
+                  if (b1 == kSentinel || b2 == kSentinel) { *p.err = 1; b1 = 0; b2 = 0; gave_up = true; }
+                  a1[e] = b1;
+                  a2[e] = b2;
+                }
               }
             }
-          }
 #pragma unroll
-          for (int e = 0; e < kMaxW; ++e) {
-            if (e < req_cnt) {
-              const double z1 = __longlong_as_double((long long)a1[e]), z2 = __longlong_as_double((long long)a2[e]);
-              const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
-              const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
-              S1 = n1; S2 = n2;
+            for (int e = 0; e < kMaxW; ++e) {
+              if (e < req_cnt) {
+                const double z1 = __longlong_as_double((long long)a1[e]), z2 = __longlong_as_double((long long)a2[e]);
+                const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
+                const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
+                S1 = n1; S2 = n2;
+              }
             }
           }
           if (q == 0) {
             *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
             *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
           }
+          publish(flags + F_CHUNK, seq + 1, lane);
         }
       }
       ALZ_LOOK_MARK(0)
-      // (3) tile i's rows for (4), read first: they arrive while the finished tile is being stored
+      // (2) tile i's rows for (4), read first: they arrive while the finished tile is being stored
       const bool zs_on = i < TOT && !ALZ_DBG(p, 64);
+      const int ts = i - kRecLag - kStoreLag;
+      const bool st_on = ts >= 0 && ts < TOT;
+      if (i < TOT) await(flags + F_PREPARED, i + 1, cap, p.err);
+      if (st_on) await(flags + F_REPLAYED, ts + 1, cap, p.err);
+      ALZ_LOOK_MARK(1)
       double zp[16];
       if (zs_on) {
         const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
 #pragma unroll
         for (int j = 0; j < 16; ++j) zp[j] = *reinterpret_cast<const double *>(zsrc + j * 512);
       }
-      // the tile the replay finished in the last interval
-      {
-        const int ts = i - kRecLag - kStoreLag;
-        if (ts >= 0 && ts < TOT && !ALZ_DBG(p, 8)) {
-          const char *ys = smem + (ts % kSlots) * kSlot;
-          double *yt = yg + tile_row(ts) * p.ldy;
-          dbl2 v[kChunks];
+      // (3) the tile the replay has finished
+      if (st_on) {
+        const char *ys = smem + (ts % kSlots) * kSlot;
+        double *yt = yg + tile_row(ts) * p.ldy;
+        dbl2 v[kChunks];
 #pragma unroll
-          for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+        for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+        publish(flags + F_STORED, ts + 1, lane);             // (behind the reads in the LDS's order: the slot is free)
+        if (!ALZ_DBG(p, 8)) {
 #pragma unroll
           for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
         }
       }
-      ALZ_LOOK_MARK(1)
-      // (4) tile i's part of its chunk's zero-state end state (the tile was prepared in the last interval)
+      ALZ_LOOK_MARK(2)
+      // (4) tile i's part of its chunk's zero-state end state
       if (zs_on) {
         double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
 #pragma unroll
@@ -561,16 +600,12 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
                              __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      ALZ_LOOK_MARK(2)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ALZ_LOOK_MARK(3)
-      __builtin_amdgcn_s_barrier();
-      ALZ_LOOK_MARK(4)
     }
-#ifdef ALZ_ABLATE
+#if defined(ALZ_ABLATE) && defined(ALZ_LOOK_TIMING)
     if (blockIdx.x == 5 && lane == 0 && (p.dbg & 512))
-      printf("k_look HELP wave, cycles per interval: chain %.1f store %.1f zero-state %.1f request %.1f barrier %.1f\n",
-             (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv, (double)cyc[4] / n_iv);
+      printf("k_look HELP wave, cycles per iteration: chain %.1f waits %.1f store %.1f zero-state %.1f\n",
+             (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
@@ -578,9 +613,8 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     asm volatile("" : "+v"(na1), "+v"(na2));
     LookState st = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double pr[4][8];
-    __builtin_amdgcn_s_barrier();                            // (the prologue's)
-    for (int i = 0; i < kRecLag; ++i) __builtin_amdgcn_s_barrier();
-    ALZ_LOOK_CLOCK(3)                                          // tile / tail / barrier
+    ALZ_LOOK_CLOCK(3)                                          // tile / tail / chunk wait
+    await(flags + F_CHUNK, 1, cap, p.err);
     {
       const char *cur = smem + lane_off - q * kStep;         // tile 0: groups 0 and 1 of the register ring
 #pragma unroll
@@ -588,21 +622,25 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) pr[1][u] = *reinterpret_cast<const double *>(cur + (8 + u) * kStep);
     }
-    int sr = 0, tic = 0, par = 0;                            // slot, tile of the chunk, chunk parity: rotated by hand
+    int sr = 0, tic = 0, seq = 0;                            // slot, tile of the chunk, chunk number: counted by hand
+    ALZ_LOOK_MARK(2)
     for (int t = 0; t < TOT; ++t) {
       char *cur = smem + sr * kSlot + lane_off - q * kStep;
       const int sn = (sr + 1 == kSlots) ? 0 : sr + 1;
       const char *nxt = (t + 1 < TOT) ? smem + sn * kSlot + lane_off - q * kStep : cur;
-      if (!ALZ_DBG(p, 2)) {
-        if (tic == 0) {
-          const double s1 = *reinterpret_cast<const double *>(sbuf + par * 256 + cl * 8);
-          const double s2 = *reinterpret_cast<const double *>(sbuf + par * 256 + 128 + cl * 8);
+      if (tic == 0) {
+        if (t > 0) await(flags + F_CHUNK, seq + 1, cap, p.err);
+        ALZ_LOOK_MARK(2)
+        if (!ALZ_DBG(p, 2)) {
+          const double s1 = *reinterpret_cast<const double *>(sbuf + (seq & 1) * 256 + cl * 8);
+          const double s2 = *reinterpret_cast<const double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8);
           look_tile<PA, true>(cur, nxt, q, s1, s2, na1, na2, st, pr);
-        } else {
-          look_tile<PA, false>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
         }
+      } else if (!ALZ_DBG(p, 2)) {
+        look_tile<PA, false>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
       }
       ALZ_LOOK_MARK(0)
+      publish(flags + F_REPLAYED, t + 1, lane);              // (behind the tile's writes in the LDS's order)
       // copy 0 has just finished the tile: after the last one its (m1, m2) is the bank's state after the block
       if (t == TOT - 1 && q == 0 && ((K - 1) % W) == w) {
         if (p.na > 1) p.yh[0 * p.channels + c] = st.m1;
@@ -610,16 +648,12 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
       }
       sr = sn;
       tic = (tic + 1 == NT) ? 0 : tic + 1;
-      par ^= (tic == 0);
-      if (kStoreLag < 2 || t == TOT - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      seq += (tic == 0);
       ALZ_LOOK_MARK(1)
-      __builtin_amdgcn_s_barrier();
-      ALZ_LOOK_MARK(2)
     }
-    for (int i = 0; i < kStoreLag + 1; ++i) __builtin_amdgcn_s_barrier();
-#ifdef ALZ_ABLATE
+#if defined(ALZ_ABLATE) && defined(ALZ_LOOK_TIMING)
     if (blockIdx.x == 5 && lane == 0 && (p.dbg & 256))
-      printf("k_look replay wave, cycles per tile: tile %.1f tail %.1f barrier %.1f (%d tiles)\n",
+      printf("k_look replay wave, cycles per tile: tile %.1f tail %.1f chunk wait %.1f (%d tiles)\n",
              (double)cyc[0] / TOT, (double)cyc[1] / TOT, (double)cyc[2] / TOT, TOT);
 #endif
   }
@@ -668,7 +702,7 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
-  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512;
+  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(192), lds, stream, p);

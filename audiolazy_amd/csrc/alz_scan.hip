@@ -134,11 +134,22 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (io.c_first != 0 || io.c_count != io.channels) return ALZ_OK;
   const int64_t C = io.channels;
   if (C % 16) return ALZ_OK;
-  // chunk_len == ALZ_TP_ONE_PASS: one pass where the shape allows it (time-major block): 512-sample chunks resident
-  // in LDS, the block read once (alz_look.hip); the three-launch form below takes everything else.  Measured at 512
-  // channels x 2^20: 214 Gsamples/s with 16 B/sample of traffic against 228 with 24 (profiles/NOTES_r03.md): a
-  // choice for the caller (HBM shared with other work), not the default.
-  const bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
+  // One pass where the shape allows it (time-major block, a recursive section): 512-sample chunks resident in LDS, the
+  // block read once (alz_look.hip) -- 260 Gsamples/s with 16 B/sample of traffic at 512 channels x 2^20 against 228
+  // with 24 for the three-launch form below (profiles/NOTES_r03.md).  ALZ_TP_ONE_PASS asks for it; ALZ_TP_AUTO takes
+  // it when its workgroups (one per CU: 16 channels x up to 16 chunks in flight) fill most of the chip, i.e. from
+  // about 200 channels up; narrower banks fill the chip better as chunks x channels lanes of the three-launch form.
+  bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
+  if (chunk_len == ALZ_TP_AUTO && sec.na > 1 && io.sxc == 1 && io.syc == 1) {
+    int dev = 0, cus = 0;
+    ALZ_HIP_CHECK(hipGetDevice(&dev));
+    ALZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t groups = C / 16, Kl = io.n / kLookChunk;
+    int64_t wk = groups > 0 ? cus / groups : 0;
+    wk = wk > 16 ? 16 : wk;
+    wk = wk > Kl ? Kl : wk;
+    one_pass = wk >= 2 && 4 * groups * wk >= 3 * (int64_t)cus;
+  }
   if (chunk_len < 0) chunk_len = 0;
   if (one_pass && sec.na > 1 && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
     const int64_t groups = C / 16, Kl = io.n / kLookChunk;

@@ -122,9 +122,11 @@ int alz_bank_set_fused(alz_bank_t *h, int on);
  * the DF-I statement, but the chunk states carry a different rounding: results are NOT
  * bit-identical (<= 1e-6 normalised by contract, ~1e-12 typical, ~1e-9 for poles at radius
  * 0.9999).  Sections the mode does not cover run as usual.
- * chunk_len = ALZ_TP_ONE_PASS (-2): the one-pass form for a single biquad-class section on time-major blocks --
- * 512-sample chunks stay in LDS between the zero-state pass and the replay, so the block is read ONCE (16 bytes of
- * HBM traffic per sample instead of 24; same numerics); shapes it does not cover run in the three-launch form.   */
+ * The engine's choice (ALZ_TP_AUTO) includes the ONE-PASS form for a biquad-class section on time-major blocks:
+ * 512-sample chunks stay in LDS between the zero-state sums and the replay, so the block is read once (16 bytes of
+ * HBM traffic per sample instead of 24; same numerics).  It is taken when its workgroups fill most of the chip (from
+ * about 200 channels up to 2048); ALZ_TP_ONE_PASS (-2) asks for it on any shape it covers, a positive chunk_len
+ * always means the three-launch form.                                                                            */
 #define ALZ_TP_AUTO (-1)
 #define ALZ_TP_ONE_PASS (-2)
 int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len);

@@ -129,12 +129,30 @@ def test_cascade_sections_one_after_the_other(alz, oracle):
   assert norm_err(y, ref, 0) <= 1e-8
 
 
+def test_engine_choice_of_form(alz, oracle):
+  """ALZ_TP_AUTO takes the one-pass form where its workgroups fill the chip (>= 256 channels on time-major blocks), the
+  three-launch form for narrower banks, channel-major blocks and explicit chunk lengths."""
+  import torch
+  for C, layout, chunk, one_pass in ((512, "time", True, True), (64, "time", True, False), (512, "chan", True, False),
+                                     (512, "time", 2048, False), (64, "time", "one-pass", True)):
+    b, a = resonators(C)
+    n = 1 << 14
+    x = np.random.default_rng(C).uniform(-1, 1, (n, C) if layout == "time" else (C, n))
+    bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(chunk)
+    y = bank.process(torch.from_numpy(x).cuda(), layout=layout).cpu().numpy()
+    assert "k_scan" in bank.last_kernel and ("k_look" in bank.last_kernel) == one_pass, (C, layout, chunk, bank.last_kernel)
+    ref = oracle.bank([3], [3], b, a, x, layout=layout)
+    assert norm_err(y, ref, 0 if layout == "time" else 1) <= 1e-8
+
+
 @pytest.mark.parametrize("C,n,pattern", [(512, 1 << 16, "resonator"), (64, 8 * 512, "resonator"), (48, 5 * 512 + 100, "lowpass2"),
-                                          (1024, 1 << 14, "biquad"), (16, 1 << 15, "onepole")])
+                                          (1024, 1 << 14, "biquad"), (16, 1 << 15, "onepole"), (512, 13 * 512 + 7, "biquad"),
+                                          (2048, 8 * 512, "resonator"), (256, 37 * 512, "lowpass2")])
 def test_one_pass_mode(alz, oracle, C, n, pattern):
-  """The one-pass form of the time-parallel mode (k_look: 512-sample chunks resident in LDS, the zero-state pass in the
-  recurrence wave's spare lanes, chunk states through global memory): every chunk boundary, worker counts from 2 to
-  16 per channel group, a ragged tail, the state left for the next block."""
+  """The one-pass form of the time-parallel mode (k_look: 512-sample chunks resident in LDS, three waves paced by LDS
+  counters, zero-state end states as dot products, chunk states through global memory): every chunk boundary, worker
+  counts from 2 to 16 per channel group (even and uneven shares of the chunks), a ragged tail, the state left for the
+  next block."""
   import torch
   rng = np.random.default_rng(C + n)
   if pattern == "resonator":

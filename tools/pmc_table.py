@@ -1,6 +1,7 @@
 """Merge the per-workload counter sums of tools/pmc_workloads.sh into profiles/r03_pmc_traffic_table.json, the table
 bench.py fills every ``roofline.traffic`` from (labelled "not measured in this run").
-usage: python tools/pmc_table.py gpurun_out/<tag> > profiles/r03_pmc_traffic_table.json"""
+usage: python tools/pmc_table.py gpurun_out/<tag> [previous table] > profiles/r03_pmc_traffic_table.json
+(a previous table supplies the workloads this pass did not measure again)"""
 import glob, json, os, sys
 d = sys.argv[1]
 ALG = {  # algorithmic bytes per step, as bench.py defines them
@@ -9,7 +10,7 @@ ALG = {  # algorithmic bytes per step, as bench.py defines them
   "gammatone_one_stream_time_parallel": (8 + 8 / 256.) * 256 * 2 ** 20, "lpc": 3984.0 * 65536, "lpc_bit_identical": 3984.0 * 65536,
   "lpc_fma": 3984.0 * 65536, "lpc_1m": 3984.0 * 2 ** 20, "envelope_abs": 16.0 * 4096 * 2 ** 20, "timevar_shared": 16.0 * 4096 * 2 ** 18,
   "timevar_per_channel": 40.0 * 4096 * 2 ** 18, "narrow512_bit_exact": 16.0 * 512 * 2 ** 20, "narrow512_time_parallel": 16.0 * 512 * 2 ** 20,
-  "narrow512_time_parallel_one_pass": 16.0 * 512 * 2 ** 20}
+  "narrow512_time_parallel_three_launch": 16.0 * 512 * 2 ** 20}
 # kernels whose reads are 16 B / lane streams (tile DMA, wide loads): FETCH_SIZE x 2 per the guide's gfx950 note;
 # 8 B / lane readers (FIR buffer loads) are reported raw and marked uncalibrated
 WIDE = lambda key: not key.startswith("fir256")
@@ -17,6 +18,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes + kerne
                "`python bench.py --no-secondary --no-parity-check --steps 3 --warmup 1 <workload>` and divided by the 4 steps; "
                "FETCH_SIZE doubled for the 16 B/lane streaming kernels (guide: gfx950 counts half of such a stream; calibrated here on "
                "k_duo: 1.00001 x algorithmic), raw for the 8 B/lane FIR reads (uncalibrated); WRITE_SIZE as reported", "workloads": {}}
+if len(sys.argv) > 2:
+  out["workloads"] = {k: v for k, v in json.load(open(sys.argv[2]))["workloads"].items() if k in ALG}
 for key, alg in ALG.items():
   try:
     f = json.load(open(os.path.join(d, "pmc_%s_FETCH_SIZE.json" % key)))

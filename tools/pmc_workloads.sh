@@ -3,14 +3,16 @@
 # kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes): one run per workload and counter, the
 # counter summed over this library's kernels and divided by the number of steps.  Output: gpurun_out/<tag>/pmc_*.json,
 # merged by tools/pmc_table.py into profiles/r03_pmc_traffic_table.json.
-#   usage: tools/pmc_workloads.sh <tag>
+#   usage: tools/pmc_workloads.sh <tag> [regex: only the workloads whose key matches]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
 mkdir -p $O
 export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-secondary --no-parity-check --steps 3 --warmup 1"
+ONLY=${2:-.}
 run() {  # key, bench args
   key=$1; shift
+  [[ $key =~ $ONLY ]] || return 0
   for ctr in FETCH_SIZE WRITE_SIZE; do
     cd /tmp
     timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/raw_${key}_$ctr -o p -- python $R/bench.py $COMMON "$@" > $O/raw_${key}_$ctr.log 2>&1
@@ -34,4 +36,4 @@ run timevar_shared --workload timevar
 run timevar_per_channel --workload timevar --streams 0
 run narrow512_bit_exact --channels 512 --time-parallel 0
 run narrow512_time_parallel --channels 512 --time-parallel 1
-run narrow512_time_parallel_one_pass --channels 512 --time-parallel -2
+run narrow512_time_parallel_three_launch --channels 512 --time-parallel 8192
