@@ -165,4 +165,24 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
                 int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name);
 
+#ifdef __HIPCC__
+// Progress counters in LDS, one writer each.  The LDS executes a wave's operations in the order it issued them, so a
+// counter written after the data (or after the reads that free a slot) needs no wait in between, and a reader that has
+// seen the counter sees the data; the compiler is held to the same order by the empty asm statements.
+__device__ __forceinline__ void publish(int *flag, int value, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void await(const int *flag, int need, int &cap, int *err) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > cap) { if (err) *err = 1; cap = 0; break; }      // (cannot happen: every wait points to earlier work; a wave
+  }                                                        //  that gave up once no longer waits at all)
+  asm volatile("" ::: "memory");
+}
+
+#endif
+
 }  // namespace alz

@@ -62,9 +62,6 @@ constexpr int kNT = 8;                       // tiles per chunk (L = 512)
 #ifndef ALZ_LOOK_STORE_LAG
 #define ALZ_LOOK_STORE_LAG 2
 #endif
-#ifndef ALZ_LOOK_POLL_SLEEP
-#define ALZ_LOOK_POLL_SLEEP 1
-#endif
 #ifndef ALZ_LOOK_LAG
 #define ALZ_LOOK_LAG 11
 #endif
@@ -239,23 +236,7 @@ __device__ __forceinline__ double sum_rows(double x) {
   return __hiloint2double((int)b1[0], (int)b0[0]) + __hiloint2double((int)b1[1], (int)b0[1]);
 }
 
-// Progress counters in LDS, one writer each.  The LDS executes a wave's operations in the order it issued them, so a
-// counter written after the data (or after the reads that free a slot) needs no wait in between, and a reader that has
-// seen the counter sees the data; the compiler is held to the same order by the empty asm statements.
 enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_REQUEST, F_COUNT = 8 };
-__device__ __forceinline__ void publish(int *flag, int value, int lane) {
-  asm volatile("" ::: "memory");
-  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void await(const int *flag, int need, int &cap, int *err) {
-  int spins = 0;
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-    __builtin_amdgcn_s_sleep(ALZ_LOOK_POLL_SLEEP);
-    if (++spins > cap) { *err = 1; cap = 0; break; }      // (cannot happen: every wait points to earlier work; a wave
-  }                                                        //  that gave up once no longer waits at all)
-  asm volatile("" ::: "memory");
-}
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
