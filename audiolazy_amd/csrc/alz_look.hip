@@ -6,7 +6,7 @@
 // in LDS between the two uses (512 samples x 16 channels = 64 KiB), so the block is read ONCE:
 //
 //   * a workgroup owns 16 channels and every W-th chunk of them (W workgroups per channel group, all resident, one per
-//     CU); its three waves (on three SIMDs) each loop over the workgroup's 64-sample tiles at their own pace and meet
+//     CU); its four waves (one per SIMD) each loop over the workgroup's 64-sample tiles at their own pace and meet
 //     only through progress counters in LDS:
 //       LOAD    queues the tile DMA (global_load_lds) into a ring of 17 tile slots and turns a landed tile into
 //               feed-forward sums p[n] IN PLACE;
@@ -17,20 +17,21 @@
 //               the end state of a tile is a dot product of its p rows with the impulse response of 1/A(z) (32 FMAs
 //               per lane and tile, weights computed once per launch), carried from tile to tile through A^64 and
 //               published in global memory with the chunk's last tile (64-bit agent-scope atomic stores into an array
-//               pre-filled with a NaN pattern no computation produces: no flags, no fences).
-//   * the true state of chunk j needs no other workgroup's replay: it is chained in zero-state space,
-//     S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}   (M = A^512 per channel, the matrix alz_scan.hip
-//     caches), by HELP, from the workgroup's own previous start state and the z of the W chunks in between; LOAD
-//     fetches those with four 1 KiB global -> LDS transfers three tiles before HELP needs them (its transfer queue has
-//     no stores in it, so the wait for its next tile covers them).  Waits only ever point to smaller chunk indices
-//     and earlier tiles, and every workgroup of the launch is resident: no deadlock; bounded spins guard against the
-//     impossible.
+//               pre-filled with a NaN pattern no computation produces: no flags, no fences);
+//       CHAIN   hands REPLAY the true start state of every chunk, which needs no other workgroup's replay: it is
+//               chained in zero-state space, S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}
+//               (M = A^512 per channel, the matrix alz_scan.hip caches), from the workgroup's own previous start state
+//               and the z of the W chunks in between, fetched (four 1 KiB global -> LDS transfers, repeated until none
+//               shows the NaN pattern) as soon as the neighbours publish them.
+//     Waits only ever point to smaller chunk indices and earlier tiles, and every workgroup of the launch is resident:
+//     no deadlock; bounded spins guard against the impossible.
 //
 // What was measured on the way (profiles/NOTES_r03.md 7, profiles/r03_look_ablations.log): the zero-state pass as a
 // second recurrence -- in a third wave, or in half the replay wave's lanes -- cost the replay wave 15 .. 40 % (its
 // dependent chain of 3 FP64 operations per step is the budget: 28.3 cycles per step, 64 steps per tile); as a dot
 // product it is free.  One barrier per tile made every wave wait for the slowest of each interval (memory stalls
-// included): counters instead.  260 Gsamples/s at 512 channels x 2^20 (267 at 2048) with 16.5 B/sample of HBM
+// included): counters instead; the chain of the start states in a wave of its own (it took 3000 - 4000 cycles once
+// per chunk out of HELP's or LOAD's tile budget).  260 Gsamples/s at 512 channels x 2^20 (267 at 2048) with 16.5 B/sample of HBM
 // traffic, against 237 with 24 B/sample for the three-launch form: ALZ_TP_AUTO takes it from 256 channels up.  The
 // replay wave alone runs at 276; the chain itself would allow ~305 at the clock the chip holds under this load.
 //
@@ -236,7 +237,7 @@ __device__ __forceinline__ double sum_rows(double x) {
   return __hiloint2double((int)b1[0], (int)b0[0]) + __hiloint2double((int)b1[1], (int)b0[1]);
 }
 
-enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_REQUEST, F_COUNT = 8 };
+enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_ZDONE, F_COUNT = 8 };
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -250,23 +251,23 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 #endif
 
 template <unsigned PB, unsigned PA>
-__global__ __launch_bounds__(192) void k_look(LArgs p) {
+__global__ __launch_bounds__(256) void k_look(LArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64, NT = kNT;
   constexpr int kStep = G * 8;
-  // The three waves each run their own loop over this workgroup's tile sequence and meet only through progress
+  // The four waves each run their own loop over this workgroup's tile sequence and meet only through progress
   // counters (no barrier after the first: a barrier per tile made every wave wait for the slowest of each interval,
   // memory stalls included).  In its iteration i
-  //   LOAD    queues the DMA of tile i + kDmaLead (its slot must have been stored) and prepares tile i + 1; three
-  //           iterations before the replay opens a chunk it also asks for the neighbours' chunk states;
-  //   HELP    chains the start state of the chunk the replay opens at tile i + 1 - kRecLag, forms tile i's part of its
-  //           chunk's zero-state end state (published with the chunk's last tile) and stores tile
-  //           i - kRecLag - kStoreLag (the replay must be done with it);
-  //   REPLAY  works on tile i, waiting only at a chunk's first tile for the chunk's start state -- which implies that
-  //           the chunk's tiles are prepared and that HELP has read them (it overwrites p with y).
-  constexpr int kRecLag = ALZ_LOOK_LAG, kDmaLead = ALZ_LOOK_LEAD, kStoreLag = ALZ_LOOK_STORE_LAG;
-  static_assert(kSlots >= kRecLag + kStoreLag + kDmaLead + 1, "a slot is stored before it is refilled");
-  static_assert(kRecLag >= NT + 3, "a chunk's state is asked for after the neighbour has published its own");
+  //   LOAD    queues the DMA of tile i + kDmaLead (its slot must have been stored) and prepares tile i + 1;
+  //   HELP    forms tile i's part of its chunk's zero-state end state (published with the chunk's last tile) and stores
+  //           tile i - kStoreBehind (the replay must be done with it);
+  //   REPLAY  works on tile i, waiting only at a chunk's first tile for the chunk's start state;
+  //   CHAIN   (one iteration per chunk) fetches the states the chunk's start state is chained from, as soon as they
+  //           are published, chains it, and hands it to REPLAY once the chunk's tiles are prepared and HELP has read
+  //           them (the replay overwrites p with y).
+  constexpr int kDmaLead = ALZ_LOOK_LEAD, kStoreBehind = ALZ_LOOK_LAG + ALZ_LOOK_STORE_LAG;
+  static_assert(kSlots >= kStoreBehind + kDmaLead + 1, "a slot is stored before it is refilled");
+  static_assert(kStoreBehind >= NT + 3, "HELP must be able to finish a chunk's sums before the replay needs its state");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int cl = lane & 15, q = lane >> 4;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
   const int64_t K = p.n_chunks;
   const int my_chunks = (int)((K - w + W - 1) / W);           // chunks w, w + W, ...
   const int TOT = my_chunks * NT;
-  const int n_iv = TOT + kRecLag + kStoreLag + 1;
+  const int n_iv = TOT + kStoreBehind + 1;
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
   char *zlds = hist + kSlots * kHist;                         // [kMaxW][2][16] doubles: the requested chunk end states
@@ -371,7 +372,6 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     prepare_tile(0);
     publish(flags + F_PREPARED, 1, lane);
-    int req_seq = -1;                                          // a request whose transfers are in flight
     ALZ_LOOK_CLOCK(4)                                          // slot wait / queue / transfer wait / prepare
     for (int i = 0; i < n_iv; ++i) {
       // the slot of tile i + kDmaLead must have been stored (this also paces the idle iterations of the tail)
@@ -381,38 +381,13 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
         if (need > 0) await(flags + F_STORED, need, cap, p.err);
       }
       ALZ_LOOK_MARK(0)
-      // three iterations before HELP chains a chunk's start state: ask for the states it is chained from, ALL AT ONCE,
-      // as four 1 KiB global -> LDS transfers.  They sit in this wave's transfer queue between two tiles, so the next
-      // iteration's wait for its tile covers them too (this wave has no stores to wait for; HELP does)
-      int asked = -1;
-      {
-        const int t_q = i + 3 - kRecLag;
-        if (t_q >= 0 && t_q < TOT && (t_q % NT) == 0 && (t_q > 0 || w > 0) && !ALZ_DBG(p, 32)) {
-          const int64_t seq = t_q / NT, cj = (int64_t)w + seq * W;
-          const int64_t req_first = seq > 0 ? cj - W : 0;    // z_first .. z_{cj-1}
-#pragma unroll
-          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
-            int64_t ch = req_first + 4 * o + (lane >> 4);
-            if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
-            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
-          }
-          asked = (int)seq;
-        }
-      }
       if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
       ALZ_LOOK_MARK(1)
-      // issued after tile i + 1's transfers: those of kDmaLead - 1 more tiles, and this iteration's request if any
-      // (the last tiles of the sequence simply wait for everything)
-      static_assert((kDmaLead - 1) * (kChunks + 1) + kMaxW / 4 <= 63, "vmcnt is a 6-bit count");
-      if (i + kDmaLead < TOT) {
-        if (asked >= 0) wait_vm<(kDmaLead - 1) * (kChunks + 1) + kMaxW / 4>();
-        else wait_vm<(kDmaLead - 1) * (kChunks + 1)>();
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (asked >= 0) { publish(flags + F_REQUEST, asked + 1, lane); asked = -1; }
-      }
-      if (req_seq >= 0) publish(flags + F_REQUEST, req_seq + 1, lane);   // (older than everything just waited for)
-      req_seq = asked;
+      // issued after tile i + 1's transfers: those of kDmaLead - 1 more tiles (the last tiles of the sequence simply
+      // wait for everything)
+      static_assert((kDmaLead - 1) * (kChunks + 1) <= 63, "vmcnt is a 6-bit count");
+      if (i + kDmaLead < TOT) wait_vm<(kDmaLead - 1) * (kChunks + 1)>();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (i + 1 < TOT) {
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
           const char *xs = smem + ((i + 1) % kSlots) * kSlot + lane_off;
@@ -436,14 +411,6 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     const int row = lane / 8, cp = lane % 8;
     double *yg = p.y + (int64_t)row * p.ldy + c0 + 2 * cp;
     const int64_t y_chunk = 8 * p.ldy;
-    const double m11 = p.power[0 * p.channels + c], m12 = p.power[1 * p.channels + c];
-    const double m21 = p.power[2 * p.channels + c], m22 = p.power[3 * p.channels + c];
-    // S: the true state at the start of this workgroup's chunks, advanced in zero-state space --
-    // S_c = M ( ... M (M S_{c-W} + z_{c-W}) + z_{c-W+1} ... ) + z_{c-1} -- from the states every workgroup publishes;
-    // the first chunk starts the chain from the bank's state
-    double S1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
-    double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
-    asm volatile("" : "+v"(S1), "+v"(S2));
     // The zero-state end state of a tile is a dot product, not a recurrence: with h the impulse response of 1/A(z),
     // (y[63], y[62]) = sum_r (h[63-r], h[62-r]) p[r].  This lane takes rows 4 j + q: its 2 x 16 weights, and
     // A^64 = [[h64, -a2 h63], [h63, -a2 h62]] to carry the sum from tile to tile, come from 65 steps of h's own
@@ -468,81 +435,24 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
       M11 = h64; M12 = na2 * h63; M21 = h63; M22 = na2 * h62;
     }
     double Z1 = 0.0, Z2 = 0.0;
-    bool gave_up = false;
-    ALZ_LOOK_CLOCK(4)                                          // chain / waits / store / zero-state
+    ALZ_LOOK_CLOCK(7)                                          // - / prepared wait / store / zero-state / - / replayed wait / -
     for (int i = 0; i < n_iv; ++i) {
-      // (1) the start state of the chunk the replay opens at tile i + 1 - kRecLag
-      {
-        const int t_c = i + 1 - kRecLag;
-        if (t_c >= 0 && t_c < TOT && (t_c % NT) == 0) {
-          const int seq = t_c / NT;
-          if ((t_c > 0 || w > 0) && !ALZ_DBG(p, 32)) {
-            const int64_t cj = (int64_t)w + (int64_t)seq * W;
-            const int64_t req_first = seq > 0 ? cj - W : 0;  // z_first .. z_{cj-1} (LOAD asked for them)
-            const int req_cnt = (int)(cj - req_first);
-            await(flags + F_REQUEST, seq + 1, cap, p.err);
-            // all the landed states at once (one LDS round trip), then the chain; a state that was not yet published
-            // when the transfer read it (rare) is polled for
-            unsigned long long a1[kMaxW], a2[kMaxW];
-            bool missing = false;
-#pragma unroll
-            for (int e = 0; e < kMaxW; ++e) {
-              const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
-              a1[e] = zl[0];
-              a2[e] = zl[16];
-              missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
-            }
-            if (__builtin_amdgcn_ballot_w64(missing) != 0) {
-#pragma unroll
-              for (int e = 0; e < kMaxW; ++e) {
-                if (e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel)) {
-                  const unsigned long long *src = zg + (req_first + e) * 32 + cl;
-                  unsigned long long b1, b2;
-                  int spins = gave_up ? kSpinCap : 0;
-                  do {
-                    b1 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b2 = __hip_atomic_load(src + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (b1 != kSentinel && b2 != kSentinel) break;
-                    __builtin_amdgcn_s_sleep(8);
-                  } while (++spins < ALZ_LOOK_CAP(p));
-                  if (b1 == kSentinel || b2 == kSentinel) { *p.err = 1; b1 = 0; b2 = 0; gave_up = true; }
-                  a1[e] = b1;
-                  a2[e] = b2;
-                }
-              }
-            }
-#pragma unroll
-            for (int e = 0; e < kMaxW; ++e) {
-              if (e < req_cnt) {
-                const double z1 = __longlong_as_double((long long)a1[e]), z2 = __longlong_as_double((long long)a2[e]);
-                const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
-                const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
-                S1 = n1; S2 = n2;
-              }
-            }
-          }
-          if (q == 0) {
-            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
-            *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
-          }
-          publish(flags + F_CHUNK, seq + 1, lane);
-        }
-      }
-      ALZ_LOOK_MARK(0)
-      // (2) tile i's rows for (4), read first: they arrive while the finished tile is being stored
+      // tile i's rows for the zero-state sums, read first: they arrive while the finished tile is being stored
       const bool zs_on = i < TOT && !ALZ_DBG(p, 64);
-      const int ts = i - kRecLag - kStoreLag;
+      const int ts = i - kStoreBehind;
       const bool st_on = ts >= 0 && ts < TOT;
       if (i < TOT) await(flags + F_PREPARED, i + 1, cap, p.err);
-      if (st_on) await(flags + F_REPLAYED, ts + 1, cap, p.err);
       ALZ_LOOK_MARK(1)
+      if (st_on) await(flags + F_REPLAYED, ts + 1, cap, p.err);
+      ALZ_LOOK_MARK(5)
       double zp[16];
       if (zs_on) {
         const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
 #pragma unroll
         for (int j = 0; j < 16; ++j) zp[j] = *reinterpret_cast<const double *>(zsrc + j * 512);
       }
-      // (3) the tile the replay has finished
+      if (i < TOT) publish(flags + F_ZDONE, i + 1, lane);    // (behind the reads in the LDS's order: the replay may overwrite)
+      // the tile the replay has finished
       if (st_on) {
         const char *ys = smem + (ts % kSlots) * kSlot;
         double *yt = yg + tile_row(ts) * p.ldy;
@@ -556,7 +466,7 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
         }
       }
       ALZ_LOOK_MARK(2)
-      // (4) tile i's part of its chunk's zero-state end state
+      // tile i's part of its chunk's zero-state end state
       if (zs_on) {
         double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
 #pragma unroll
@@ -585,10 +495,83 @@ __global__ __launch_bounds__(192) void k_look(LArgs p) {
     }
 #if defined(ALZ_ABLATE) && defined(ALZ_LOOK_TIMING)
     if (blockIdx.x == 5 && lane == 0 && (p.dbg & 512))
-      printf("k_look HELP wave, cycles per iteration: chain %.1f waits %.1f store %.1f zero-state %.1f\n",
-             (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
+      printf("k_look HELP wave, cycles per iteration: prepared wait %.1f replayed wait %.1f store %.1f zero-state %.1f\n",
+             (double)cyc[1] / n_iv, (double)cyc[5] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (wave == 3) {
+    // ------------------------------ CHAIN ------------------------------
+    const double m11 = p.power[0 * p.channels + c], m12 = p.power[1 * p.channels + c];
+    const double m21 = p.power[2 * p.channels + c], m22 = p.power[3 * p.channels + c];
+    // S: the true state at the start of this workgroup's chunks, advanced in zero-state space --
+    // S_c = M ( ... M (M S_{c-W} + z_{c-W}) + z_{c-W+1} ... ) + z_{c-1} -- from the states every workgroup publishes;
+    // the first chunk starts the chain from the bank's state
+    double S1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
+    double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
+    asm volatile("" : "+v"(S1), "+v"(S2));
+    for (int seq = 0; seq < my_chunks; ++seq) {
+      if ((seq > 0 || w > 0) && !ALZ_DBG(p, 32)) {
+        const int64_t cj = (int64_t)w + (int64_t)seq * W;
+        const int64_t req_first = seq > 0 ? cj - W : 0;      // z_first .. z_{cj-1}
+        const int req_cnt = (int)(cj - req_first);
+        // all of them at once, as four 1 KiB global -> LDS transfers, again until none shows the "not yet published"
+        // pattern (this wave has nothing else to do; the last of them appears when the neighbour's HELP wave has
+        // summed its chunk)
+        unsigned long long a1[kMaxW], a2[kMaxW];
+        int tries = 0;
+        while (true) {
+#pragma unroll
+          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
+            int64_t ch = req_first + 4 * o + (lane >> 4);
+            if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
+            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bool missing = false;
+#pragma unroll
+          for (int e = 0; e < kMaxW; ++e) {
+            const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
+            a1[e] = zl[0];
+            a2[e] = zl[16];
+            missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
+          }
+          if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
+          if (++tries > ALZ_LOOK_CAP(p)) {                   // (cannot happen: the states come from earlier chunks)
+            *p.err = 1;
+#pragma unroll
+            for (int e = 0; e < kMaxW; ++e) {
+              if (a1[e] == kSentinel) a1[e] = 0;
+              if (a2[e] == kSentinel) a2[e] = 0;
+            }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(16);
+        }
+#pragma unroll
+        for (int e = 0; e < kMaxW; ++e) {
+          if (e < req_cnt) {
+            const double z1 = __longlong_as_double((long long)a1[e]), z2 = __longlong_as_double((long long)a2[e]);
+            const double n1 = __builtin_fma(m11, S1, __builtin_fma(m12, S2, z1));
+            const double n2 = __builtin_fma(m21, S1, __builtin_fma(m22, S2, z2));
+            S1 = n1; S2 = n2;
+          }
+        }
+      }
+      // the buffer of this parity held the state of chunk number seq - 2: the replay has read it
+      if (seq >= 2) await(flags + F_REPLAYED, NT * (seq - 2) + 1, cap, p.err);
+      if (q == 0) {
+        *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
+        *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
+      }
+      // the replay overwrites the chunk's tiles and reads two rows groups into the next one: HELP must have read the
+      // former, LOAD prepared the latter
+      {
+        const int zneed = NT * seq + NT, pneed = NT * seq + NT + 2;
+        await(flags + F_ZDONE, zneed > TOT ? TOT : zneed, cap, p.err);
+        await(flags + F_PREPARED, pneed > TOT ? TOT : pneed, cap, p.err);
+      }
+      publish(flags + F_CHUNK, seq + 1, lane);
+    }
   } else {
     // ------------------------------ REPLAY ------------------------------
     asm volatile("" : "+v"(na1), "+v"(na2));
@@ -686,7 +669,7 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(192), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = K * L;
   *kernel_name = "k_look";
