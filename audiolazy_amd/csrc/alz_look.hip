@@ -48,23 +48,21 @@ namespace {
 
 constexpr int kChunks = 8;                   // 1 KiB DMA transfers per tile
 constexpr int kNT = 8;                       // tiles per chunk (L = 512)
+// (the #ifndef values can be overridden in tools/variants builds: profiles/NOTES_r03.md 7 has what was tried)
 #ifndef ALZ_LOOK_SLOTS
 #define ALZ_LOOK_SLOTS 17
 #endif
 #ifndef ALZ_LOOK_LEAD
-#define ALZ_LOOK_LEAD 3
+#define ALZ_LOOK_LEAD 3      // tiles of DMA in flight ahead of the one being prepared
+#endif
+#ifndef ALZ_LOOK_BEHIND
+#define ALZ_LOOK_BEHIND 13   // HELP stores tile i - 13 in the iteration in which it sums tile i
 #endif
 #ifndef ALZ_LOOK_CHUNKWAIT
 #define ALZ_LOOK_CHUNKWAIT 1
 #endif
 #ifndef ALZ_LOOK_VAR
-#define ALZ_LOOK_VAR 0       // experiments (tools/variants only): 1 no LDS writes, 2 no LDS reads in the replay's tile
-#endif
-#ifndef ALZ_LOOK_STORE_LAG
-#define ALZ_LOOK_STORE_LAG 2
-#endif
-#ifndef ALZ_LOOK_LAG
-#define ALZ_LOOK_LAG 11
+#define ALZ_LOOK_VAR 0       // experiments: 1 no LDS writes, 2 no LDS reads in the replay's tile (WRONG output)
 #endif
 constexpr int kSlots = ALZ_LOOK_SLOTS;       // tile slots in LDS
 constexpr int kSlot = 8192 + kChunks * 16;   // a tile in the DMA layout (16 bytes of pad per 1 KiB chunk)
@@ -133,7 +131,7 @@ __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
 // One 64-sample tile of the replay wave: 16 channels x 4 skewed copies (copy q runs q steps behind, so one
 // ds_write_b64 of the wave stores four finished rows -- k_duo's scheme), over p in the tile slot, overwriting it with y.
 //   cur     the lane's column in the tile slot, minus its skew (the lane's step u is row u - q = cur + u * 128)
-//   nxt     the same for the NEXT tile of the workgroup's sequence: p is prepared many intervals ahead here, so the
+//   nxt     the same for the NEXT tile of the workgroup's sequence: p is prepared many tiles ahead here, so the
 //           register ring of 8-row groups (pr, four deep so that a tile's eight groups keep their places) simply runs
 //           on across the tile boundary and no tile starts by waiting for its first rows
 //   CS      instantiation for a tile that opens a chunk: copy q switches to the chunk's start state (s1, s2) at its
@@ -265,7 +263,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   //   CHAIN   (one iteration per chunk) fetches the states the chunk's start state is chained from, as soon as they
   //           are published, chains it, and hands it to REPLAY once the chunk's tiles are prepared and HELP has read
   //           them (the replay overwrites p with y).
-  constexpr int kDmaLead = ALZ_LOOK_LEAD, kStoreBehind = ALZ_LOOK_LAG + ALZ_LOOK_STORE_LAG;
+  constexpr int kDmaLead = ALZ_LOOK_LEAD, kStoreBehind = ALZ_LOOK_BEHIND;
   static_assert(kSlots >= kStoreBehind + kDmaLead + 1, "a slot is stored before it is refilled");
   static_assert(kStoreBehind >= NT + 3, "HELP must be able to finish a chunk's sums before the replay needs its state");
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
