@@ -179,3 +179,28 @@ def test_one_pass_mode(alz, oracle, C, n, pattern):
   assert norm_err(y, ref[:n], 0) <= 1e-8
   y2 = bank.process(torch.from_numpy(x2).cuda(), layout="time").cpu().numpy()
   assert norm_err(y2, ref[n:], 0) <= 1e-8
+
+
+def test_one_pass_is_deterministic_and_agrees_with_three_launches(alz):
+  """The one-pass form synchronises its waves and workgroups through counters and published states only: the same block
+  twelve times over must give the same BITS every time (the chain order is fixed), and agree with the three-launch form
+  of the same mode to its tolerance -- on shapes with 2 to 16 workgroups per channel group and uneven chunk shares."""
+  import torch
+  for C, n in ((256, 50 * 512), (512, 1 << 17), (1024, 23 * 512 + 64), (2048, 16 * 512)):
+    b, a = resonators(C)
+    x = torch.from_numpy(np.random.default_rng(C).uniform(-1, 1, (n, C))).cuda()
+    one = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
+    first = None
+    for _ in range(12):
+      one.reset()
+      y = one.process(x, layout="time").clone()
+      assert "k_look" in one.last_kernel
+      if first is None:
+        first = y
+      else:
+        assert torch.equal(first, y), (C, n)
+    three = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(2048)
+    y3 = three.process(x, layout="time")
+    assert "k_look" not in three.last_kernel
+    scale = y3.abs().max(dim=0).values.clamp_min(1e-300)
+    assert float(((first - y3).abs().max(dim=0).values / scale).max()) <= 1e-8
