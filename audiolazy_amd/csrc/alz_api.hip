@@ -310,6 +310,7 @@ int alz_bank_destroy(alz_bank_t *h) {
     if (sc.vyh) (void)hipFree(sc.vyh);
     if (sc.power) (void)hipFree(sc.power);
     if (sc.zbuf) (void)hipFree(sc.zbuf);
+    if (sc.look_err) (void)hipHostFree(sc.look_err);
   }
   delete h;
   return ALZ_OK;

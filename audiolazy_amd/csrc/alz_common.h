@@ -135,8 +135,9 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   uint64_t power_bytes = 0;
   int64_t power_len = 0;             // chunk length the cached matrix belongs to (0: none)
   int power_section = -1;
-  double *zbuf = nullptr;            // k_look: published chunk end states (+ an error word at the end)
+  double *zbuf = nullptr;            // k_look: published chunk end states
   uint64_t zbuf_bytes = 0;
+  int *look_err = nullptr;           // k_look: one word of pinned host memory the kernel sets if a bounded wait ran out
 };
 // alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, two-wave streaming kernel
 int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,

@@ -153,7 +153,18 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (chunk_len < 0) chunk_len = 0;
   if (one_pass && sec.na > 1 && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
     const int64_t groups = C / 16, Kl = io.n / kLookChunk;
-    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) + 64;
+    // a bounded wait of an EARLIER launch on this handle ran out (it cannot: every wait points to earlier work of
+    // workgroups that are resident): the kernel said so in a word of pinned host memory, read here without a sync
+    if (scratch->look_err && *(volatile int *)scratch->look_err != 0) {
+      *scratch->look_err = 0;
+      return fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel gave up waiting in an earlier call (its output is invalid)");
+    }
+    if (!scratch->look_err) {
+      if (hipHostMalloc((void **)&scratch->look_err, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(ALZ_E_NOMEM, "hipHostMalloc failed (time-parallel scratch)");
+      *scratch->look_err = 0;
+    }
+    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double);
     uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;
     int rc2 = grow_scratch(&scratch->zbuf, &have_z, zneed);
     if (rc2) return rc2;
@@ -169,8 +180,7 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
     const bool fresh = scratch->power_len != kLookChunk || scratch->power_section != section_index;
     if (fresh) hipLaunchKernelGGL(k_scan_power, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, stream, pw);
     int64_t done = 0;
-    int *err = (int *)((char *)scratch->zbuf + (zneed - 64));
-    rc2 = launch_look(sec, io, stream, scratch->power, scratch->zbuf, zneed - 64, err, &done, kernel_name);
+    rc2 = launch_look(sec, io, stream, scratch->power, scratch->zbuf, zneed, scratch->look_err, &done, kernel_name);
     if (rc2) return rc2;
     if (fresh) {                      // (the matrix is valid whether or not the kernel took the block)
       scratch->power_len = kLookChunk;
