@@ -328,17 +328,22 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// k_duo: the same streaming scheme with the work split over the two waves of a workgroup.
+// k_duo: the same streaming scheme with the work split over the waves of a workgroup.
 //
 //   AUX wave  queues the tile DMA, waits for it, computes the feed-forward sums
 //             p[n] = b0*x[n] (+ b1*x[n-1]) (+ b2*x[n-2]) for a whole tile with all 64 lanes
-//             (time-parallel: lane group q owns samples 4j + q), and stores finished y tiles;
+//             (time-parallel: lane group q owns samples 4j + q);
 //   REC wave  runs only the serial part  y[n] = (p[n] + (-a1)*y[n-1]) + (-a2)*y[n-2]
-//             (4 f64 ops and one LDS read per step, one row-select LDS write per 4 steps).
+//             (4 f64 ops and one LDS read per step, one row-select LDS write per 4 steps);
+//   STORE wave (round 3; the AUX wave's job before) reads the finished y tile from LDS and stores it: the LDS round
+//             trip and the eight store issues came out of the AUX wave's interval, which every tile's barrier waits
+//             for -- +3 % at 4096 channels, +5 % at 512 .. 2048 and channel-major, +4 % for the one-pole envelope bank
+//             (profiles/NOTES_r03.md 11).  Not in the FMA mode, which runs at the data path's limit: a separate
+//             storing wave interleaves its writes with the reads instead of batching them, 9 % slower there.
 //
 // p and the recurrence term order are exactly the reference's left-to-right sum (numerator
 // terms first, lazy_filters.py:198-224), so the split changes nothing numerically.  The waves
-// meet at one s_barrier per tile: while REC works on tile i, AUX stores tile i-1, queues tile
+// meet at one s_barrier per tile: while REC works on tile i, STORE stores tile i-1, AUX queues tile
 // i+3 and prepares p for tile i+1.  LDS: a 4-slot x ring (DMA target) + a 3-slot p/y ring.
 // G = 16 channels per workgroup (the REC wave's other 48 lanes are ghosts as in k_wave).
 // ---------------------------------------------------------------------------
@@ -348,6 +353,9 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
 static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_CHUNKWAIT
 #define ALZ_DUO_CHUNKWAIT 1
+#endif
+#ifndef ALZ_DUO_STORER
+#define ALZ_DUO_STORER 1     // a third wave stores the finished tiles (not in the FMA mode; profiles/NOTES_r03.md 11)
 #endif
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
@@ -370,7 +378,8 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
 template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0>
-__global__ __launch_bounds__(128) void k_duo(WArgs p) {
+__global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
+  constexpr bool STORER = ALZ_DUO_STORER && !FMA && !NOSTORE;    // a third wave stores the finished tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -405,8 +414,8 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
   constexpr int kOutChunk = CM ? kChunkLds : 1024;         // bytes per 1 KiB store chunk in the y ring
   const int lane_off_p = CM ? cl * kChanPitch : cl * 8;
 
-  if (wave == 1) {
-    // ------------------------------ AUX ------------------------------
+  if (wave >= 1) {
+    // ------------------------------ AUX (and, with ALZ_DUO_STORER, the storing wave) ------------------------------
     int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
     if (!CM) {
       const int row = lane / 8, cp = lane % 8;
@@ -508,13 +517,25 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
 
+    if (STORER && wave == 2) {
+      // the storing wave: tile i - 1 while REC works on tile i
+      __builtin_amdgcn_s_barrier();
+      for (int64_t i = 0; i < nt; ++i) {
+        if (!NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
+      }
+      if (!NOSTORE) store_tile(nt - 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     for (int t = 0; t < kXRing - 1 && t < nt && !ALZ_DBG(p, 1); ++t) queue_tile(t);
     wait_vm((int)((nt < kXRing - 1 ? nt : kXRing - 1) - 1) * kChunks);   // tile 0 has landed
     feed_forward(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < nt; ++i) {
-      if (!NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+      if (!STORER && !NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
@@ -522,14 +543,14 @@ __global__ __launch_bounds__(128) void k_duo(WArgs p) {
         // wait_vm: waiting for a few more of the oldest operations is always safe)
         const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
         const int64_t dma_after = last - (i + 1);
-        const int64_t stores_after = NOSTORE ? 0 : (i < kXRing - 2 ? i : kXRing - 2);
+        const int64_t stores_after = (NOSTORE || STORER) ? 0 : (i < kXRing - 2 ? i : kXRing - 2);
         wait_vm(ALZ_DBG(p, 5) ? 0 : (int)(dma_after + stores_after) * kChunks);
         if (!ALZ_DBG(p, 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
     }
-    if (!NOSTORE) store_tile(nt - 1);
+    if (!STORER && !NOSTORE) store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
     if (!NOSTORE && q == 3) {
       const char *xs = xring + (int)((nt - 1) % kXRing) * kDuoSlot + lane_off;
@@ -736,6 +757,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
   const bool prefer_single = g == 16 && lanes >= 8192 && !ch;
   wave_fn duo = nullptr;
+  bool duo_fma = false;
   if (g == 16 && sec.any_div) {
     duo = cm ? pick_duo_pattern<true, false, true>(sec.present_b, sec.present_a)
              : pick_duo_pattern<false, false, true>(sec.present_b, sec.present_a);
@@ -749,8 +771,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
              : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a);
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
     if (io.fused)
-      duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
-               : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
+      duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
+                               : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
     else
       duo = cm ? pick_duo_pattern<true, false>(sec.present_b, sec.present_a)
                : pick_duo_pattern<false, false>(sec.present_b, sec.present_a);
@@ -792,7 +814,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
     if (rc) return rc;
   }
   if (ch && ch->n_chunks > 65535) return ALZ_OK;
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? 128 : 64), lds,
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? ((ALZ_DUO_STORER && !duo_fma && !nostore) ? 192 : 128) : 64), lds,
                      stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
