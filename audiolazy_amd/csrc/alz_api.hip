@@ -433,6 +433,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
   io.mode = h->mode;
   io.zero = h->zero;
   io.fused = h->fused;
+  io.stream_once = (h->n_sections == 1 && x_dev != y_dev && (uint64_t)n * (uint64_t)h->channels * 8u >= (256ull << 20)) ? 1 : 0;
   int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
   std::string last_noted;

@@ -83,6 +83,8 @@ struct BlockIO {
   int fused;          // opt-in FMA contraction in the streaming kernels (not bit-exact)
   int pre_op;         // elementwise stage fused into this section's input reads (ALZ_MAP_ABS) or 0;
                       // honoured by launch_wave and the k_small path of launch_section only
+  int stream_once = 0;  // the block is large, read once and its result not read again by this call (single-section
+                      // bank): k_duo then moves it with non-temporal loads and stores
 };
 
 // alz_iir.hip: any section shape, channels [c_first, c_first + c_count)

@@ -46,6 +46,7 @@ struct WArgs {
   int map_input;          // OUTER, first section: x is indexed by input, not by channel
   int64_t n_sets;
   int nb, na;
+  int nt;                 // non-temporal tile loads and stores (k_duo; BlockIO::stream_once)
   const double *b, *a;
   double *xh, *yh;
   int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores, 8 no tile barriers (wrong output!)
@@ -58,34 +59,42 @@ struct WArgs {
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
 // at lds_dst + lane*16.  M0 is saved/restored inside the same statement (hipcc reserves it).
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst, bool nt = false) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-#ifdef ALZ_NT_LOADS
-      "global_load_lds_dwordx4 %1, off nt\n\t"
-#else
-      "global_load_lds_dwordx4 %1, off\n\t"
-#endif
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+  if (nt) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+  }
 }
 
 // one 1 KiB store, 16 B per lane.  Inline asm on purpose: a store hipcc knows about makes it
 // insert its own s_waitcnt vmcnt(7) in front of the next tile's stores, which (with the DMA
 // loads it cannot see in the queue) drains the whole prefetch ring every tile.  The trailing
 // s_nop covers the "VMEM store of more than 8 bytes, then overwrite of its data VGPRs" hazard.
+// nt (wave-uniform): non-temporal policy for blocks that are read once and not read back by the same call --
+// with the STORE wave at its side configs[1] gains 3 - 4 % from both hints together (profiles/NOTES_r03.md 11);
+// cascades and small blocks, whose next section or next pass finds the data in the Infinity Cache, keep the default.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store16(double *gdst, dbl2 v) {
-#ifdef ALZ_NT_STORES
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
-#else
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
-#endif
+__device__ __forceinline__ void store16(double *gdst, dbl2 v, bool nt = false) {
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
 
 // wait until at most `n` vector-memory operations of this wave are outstanding.
@@ -391,6 +400,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
   const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
+  const bool stream_once = p.nt != 0;                         // non-temporal tile loads and stores
   char *xring = smem;
   // p and y rings are written and read only by this kernel's own lanes, so their layout is free:
   // channel-major keeps 16 bytes after EVERY channel (a half-wave -- 16 channels x 2 lane groups --
@@ -444,7 +454,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
       const int s = (int)(t % kXRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
-        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kDuoSlot + j * kChunkLds);
+        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kDuoSlot + j * kChunkLds, stream_once);
     };
     // feed-forward of tile t: lane (q, cl) owns samples 4j + q (j = 0..15) of channel cl, so the
     // four lane groups of one ds_write_b64 fill four consecutive rows of the p ring (512
@@ -514,7 +524,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
         v[j] = *reinterpret_cast<const dbl2 *>(ys + (CM ? (2 * j + lane / 32) * kChanPitch + (lane % 32) * 16
                                                           : j * kOutChunk + lane * 16));
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
+      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j], stream_once);
     };
 
     if (STORER && wave == 2) {
@@ -788,6 +798,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
 
   WArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy;
+  p.nt = (io.stream_once && !ch && !io.fused) ? ALZ_TUNE("ALZ_DUO_NT", 1) : 0;
   p.n_tiles = tiles; p.channels = io.channels; p.c_first = 0;
   p.n_inputs = outer ? io.n_inputs : 0;
   p.map_input = io.map_input;
