@@ -141,7 +141,7 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   uint64_t zbuf_bytes = 0;
   int *look_err = nullptr;           // k_look: one word of pinned host memory the kernel sets if a bounded wait ran out
 };
-// alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, two-wave streaming kernel
+// alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, streaming kernel (recurrence, feed-forward and store waves)
 int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
                  const int *kind, const double *value, const double *const *series, const int *negated,
                  double *xh, double *yh, hipStream_t stream, int64_t *done_samples);

@@ -15,7 +15,8 @@
 //   AUX wave  queues the x tile DMA and, with it, the tile's 64 coefficient values of every series
 //             tap (global_load_lds, two taps per 1 KiB transfer); when a tile has landed it forms the
 //             feed-forward sums p[n] with the per-row b_k[n] (time-parallel, all 64 lanes), writes
-//             the pairs (-a1[n], -a2[n]) of the tile to a small LDS ring, and stores finished y tiles;
+//             the pairs (-a1[n], -a2[n]) of the tile to a small LDS ring;
+//   STORE wave stores finished y tiles (round 3: out of the AUX wave's interval, as in k_duo);
 //   REC wave  runs y[n] = (p[n] + na1[n] y[n-1]) + na2[n] y[n-2]: one 16-byte LDS read for the step's
 //             coefficient pair on top of k_duo's recurrence (ghost lanes, skewed lane groups, one
 //             ds_write_b64 per four rows).
@@ -94,7 +95,7 @@ __device__ __forceinline__ void wait_vm_literal() {
 // CM: channel-major blocks ([C, N], one Stream per row), k_duo's layout: a 1 KiB DMA chunk is two channels
 // of 512 B with a 16-byte pad, the p / y rings keep 16 bytes after every channel.
 template <unsigned PB, unsigned PA, int ND, bool CM>
-__global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
+__global__ __launch_bounds__(192) void k_tvduo(TDArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
   constexpr int kChanPitch = 64 * 8 + 16;                  // bytes per channel row of the p / y rings (CM)
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
   constexpr int kStep = CM ? 8 : G * 8;
 
-  if (wave == 1) {
-    // ------------------------------ AUX ------------------------------
+  if (wave >= 1) {
+    // ------------------------------ AUX (wave 1) and the storing wave (wave 2, as in k_duo) ------------------------------
     int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
     if (!CM) {
       const int row = lane / 8, cp = lane % 8;
@@ -245,33 +246,42 @@ __global__ __launch_bounds__(128) void k_tvduo(TDArgs p) {
       for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
     };
 
+    if (wave == 2) {
+      // the storing wave: tile i - 1 while REC works on tile i (in the AUX wave the LDS round trip and the store issues
+      // lengthened the interval every barrier waits for)
+      __builtin_amdgcn_s_barrier();
+      for (int64_t i = 0; i < nt; ++i) {
+        if (i >= 1) store_tile(i - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      store_tile(nt - 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     for (int t = 0; t < kXRing - 1 && t < nt; ++t) queue_tile(t);
     wait_vm((int)((nt < kXRing - 1 ? nt : kXRing - 1) - 1) * per_tile);   // tile 0 has landed
     prepare_tile(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int64_t i = 0; i < nt; ++i) {
-      if (i >= 1) store_tile(i - 1);
       if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
-        // operations issued after tile i+1's loads: the loads of tiles i+2 .. i+kXRing-1 and the stores of
-        // the kXRing-2 tiles finished since
-        if (i >= kXRing - 2 && i + kXRing - 1 < nt) {        // steady state: two tiles of loads, two of stores
-          constexpr int kSteady = (kXRing - 2) * per_tile + (kXRing - 2) * kChunks;
+        // operations issued after tile i+1's loads: the loads of tiles i+2 .. i+kXRing-1
+        if (i + kXRing - 1 < nt) {                              // steady state: two tiles of loads
+          constexpr int kSteady = (kXRing - 2) * per_tile;
           static_assert(kSteady <= 48, "vmcnt range");
           wait_vm_literal<kSteady>();
         } else {
-          const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
+          const int64_t last = nt - 1;
           const int64_t loads_after = last - (i + 1);
-          const int64_t stores_after = i < kXRing - 2 ? i : kXRing - 2;
-          wait_vm((int)(loads_after * per_tile + stores_after * kChunks));
+          wait_vm((int)(loads_after * per_tile));
         }
         prepare_tile(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    store_tile(nt - 1);
     if (q == 3) {      // input history for the next block: the last two x samples
       const char *xs = xring + (int)((nt - 1) % kXRing) * kSlot + lane_off;
       if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
@@ -408,7 +418,7 @@ int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy
                      (size_t)kPRing * kPairSlot;
   const int rc = ensure_dynamic_lds((const void *)fn, 96 * 1024);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(channels / 16)), dim3(128), channels / 16 <= 256 ? (size_t)96 * 1024 : lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(channels / 16)), dim3(192), channels / 16 <= 256 ? (size_t)96 * 1024 : lds, stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = p.n_tiles * 64;
   return ALZ_OK;

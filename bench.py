@@ -664,7 +664,7 @@ def wl_timevar(ctx, args, alz, C, N, steps, warmup, per_channel=False):
   if per_channel:    # x + three series read, y written: 40 algorithmic bytes per channel-sample
     return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvpc (three-wave streaming kernel, per-channel coefficient series)",
             "parity": parity, "roofline": hbm_roof(40.0 * C * N, k_ms)}
-  return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvduo (two-wave streaming kernel, shared coefficient series)",
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvduo (streaming kernel: recurrence / feed-forward / store waves, shared coefficient series)",
           "parity": parity, "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
