@@ -765,7 +765,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   if (io.pre_op && (!pre_abs || ch || io.fused || sec.any_div)) return ALZ_OK;   // the caller maps the input first
   // the single-wave kernel overtakes the two-wave one once a CU holds more than two workgroups' worth
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
-  const bool prefer_single = g == 16 && lanes >= 8192 && !ch;
+  static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
+  const bool prefer_single = g == 16 && lanes >= single_from && !ch;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
