@@ -46,7 +46,6 @@ struct WArgs {
   int map_input;          // OUTER, first section: x is indexed by input, not by channel
   int64_t n_sets;
   int nb, na;
-  int nt;                 // non-temporal tile loads and stores (k_duo; BlockIO::stream_once)
   const double *b, *a;
   double *xh, *yh;
   int dbg;  // ALZ_WAVE_DEBUG ablation bits: 1 no DMA, 2 no recurrence, 4 no stores, 8 no tile barriers (wrong output!)
@@ -59,9 +58,10 @@ struct WArgs {
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
 // at lds_dst + lane*16.  M0 is saved/restored inside the same statement (hipcc reserves it).
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst, bool nt = false) {
+template <bool NT = false>
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
   unsigned keep;
-  if (nt) {
+  if constexpr (NT) {
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
@@ -88,12 +88,15 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst, bool n
 // insert its own s_waitcnt vmcnt(7) in front of the next tile's stores, which (with the DMA
 // loads it cannot see in the queue) drains the whole prefetch ring every tile.  The trailing
 // s_nop covers the "VMEM store of more than 8 bytes, then overwrite of its data VGPRs" hazard.
-// nt (wave-uniform): non-temporal policy for blocks that are read once and not read back by the same call --
-// with the STORE wave at its side configs[1] gains 3 - 4 % from both hints together (profiles/NOTES_r03.md 11);
-// cascades and small blocks, whose next section or next pass finds the data in the Infinity Cache, keep the default.
+// NT: non-temporal policy for blocks that are read once and not read back by the same call -- with the STORE wave
+// at its side configs[1] gains 3 - 5 % from both hints together (profiles/NOTES_r03.md 11); cascades and small
+// blocks, whose next section or next pass finds the data in the Infinity Cache, keep the default.  A COMPILE-TIME
+// choice: as a wave-uniform run-time branch around the two statements it cost the two-wave instantiations 25 %
+// (the tile loop was no longer one basic block).
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store16(double *gdst, dbl2 v, bool nt = false) {
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+template <bool NT = false>
+__device__ __forceinline__ void store16(double *gdst, dbl2 v) {
+  if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
 
@@ -386,7 +389,7 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // DIV = true divides the finished sum by a0 (``(...) / gain``, lazy_filters.py:236-240): the banks
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
-template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0>
+template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0, bool NT = false>
 __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
   constexpr bool STORER = ALZ_DUO_STORER && !FMA && !NOSTORE;    // a third wave stores the finished tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,7 +403,6 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
   const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
-  const bool stream_once = p.nt != 0;                         // non-temporal tile loads and stores
   char *xring = smem;
   // p and y rings are written and read only by this kernel's own lanes, so their layout is free:
   // channel-major keeps 16 bytes after EVERY channel (a half-wave -- 16 channels x 2 lane groups --
@@ -454,7 +456,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
       const int s = (int)(t % kXRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
-        dma16(xg + t * x_tile + j * x_chunk, lds0 + s * kDuoSlot + j * kChunkLds, stream_once);
+        dma16<NT>(xg + t * x_tile + j * x_chunk, lds0 + s * kDuoSlot + j * kChunkLds);
     };
     // feed-forward of tile t: lane (q, cl) owns samples 4j + q (j = 0..15) of channel cl, so the
     // four lane groups of one ds_write_b64 fill four consecutive rows of the p ring (512
@@ -524,7 +526,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
         v[j] = *reinterpret_cast<const dbl2 *>(ys + (CM ? (2 * j + lane / 32) * kChanPitch + (lane % 32) * 16
                                                           : j * kOutChunk + lane * 16));
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j], stream_once);
+      for (int j = 0; j < kChunks; ++j) store16<NT>(yt + j * y_chunk, v[j]);
     };
 
     if (STORER && wave == 2) {
@@ -693,10 +695,10 @@ static wave_fn pick_pattern(unsigned pb, unsigned pa) {
   return nullptr;
 }
 
-template <bool CM, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0>
+template <bool CM, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0, bool NT = false>
 static wave_fn pick_duo_pattern(unsigned pb, unsigned pa) {
 #define ALZ_PAT(PB_, PA_) \
-  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV, NOSTORE, PRE>;
+  if (pb == PB_ && pa == PA_) return (wave_fn)k_duo<CM, PB_, PA_, FMA, DIV, NOSTORE, PRE, NT>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
@@ -767,6 +769,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
   const bool prefer_single = g == 16 && lanes >= single_from && !ch;
+  // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
+  const bool nt_tiles = io.stream_once && !ch && !io.fused && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
@@ -778,15 +782,19 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
              : pick_duo_pattern<false, false, false, true>(sec.present_b, sec.present_a);
     if (!duo) return ALZ_OK;
   } else if (g == 16 && pre_abs && duo_env && !prefer_single) {
-    duo = cm ? pick_duo_pattern<true, false, false, false, 1>(sec.present_b, sec.present_a)
-             : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a);
+    duo = nt_tiles ? (cm ? pick_duo_pattern<true, false, false, false, 1, true>(sec.present_b, sec.present_a)
+                         : pick_duo_pattern<false, false, false, false, 1, true>(sec.present_b, sec.present_a))
+                   : (cm ? pick_duo_pattern<true, false, false, false, 1>(sec.present_b, sec.present_a)
+                         : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a));
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
     if (io.fused)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
     else
-      duo = cm ? pick_duo_pattern<true, false>(sec.present_b, sec.present_a)
-               : pick_duo_pattern<false, false>(sec.present_b, sec.present_a);
+      duo = nt_tiles ? (cm ? pick_duo_pattern<true, false, false, false, 0, true>(sec.present_b, sec.present_a)
+                           : pick_duo_pattern<false, false, false, false, 0, true>(sec.present_b, sec.present_a))
+                     : (cm ? pick_duo_pattern<true, false>(sec.present_b, sec.present_a)
+                           : pick_duo_pattern<false, false>(sec.present_b, sec.present_a));
   }
   wave_fn fn = duo;
   if (!fn && nostore)
@@ -799,7 +807,6 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
 
   WArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy;
-  p.nt = (io.stream_once && !ch && !io.fused) ? ALZ_TUNE("ALZ_DUO_NT", 1) : 0;
   p.n_tiles = tiles; p.channels = io.channels; p.c_first = 0;
   p.n_inputs = outer ? io.n_inputs : 0;
   p.map_input = io.map_input;
