@@ -568,8 +568,10 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
              (int64_t)(sec.nb + (kRingPF + 3) * kRingK + 2 * kRingR) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge runs: 32-bit row offsets
              (int64_t)(sec.nb - 1) * io.channels * 8 < ((int64_t)1 << 31)) {
     // Run-to-wave mapping.  A run (kRingR output rows of 64 channels) reads a window of kRingR + nb - 1 input rows,
-    // so neighbouring runs share most of their input.  Interleaved (default): the grid is just large enough to
-    // fill the chip (two waves per SIMD) and block y takes runs y, y + GY, y + 2 GY, ...: at any moment the GY
+    // so neighbouring runs share most of their input.  Interleaved (default): the grid is 64 times what fills the
+    // chip (two waves per SIMD are resident; a grid of exactly that size left 7 - 10 % on the table: waves that finish
+    // early leave their SIMD half empty, profiles/NOTES_r03.md 5) and block y takes runs y, y + GY, y + 2 GY, ...:
+    // blocks are dispatched in order, so at any moment the resident
     // waves of a channel group -- same XCD, since the XCD follows blockIdx.x -- work on ADJACENT runs, and a row
     // fetched by the leading wave is found in that XCD's L2 by the others a few microseconds later (reuse distance
     // ~1.5 MB per XCD against 4 MB of L2).  Blocked (round 1/2): block y takes 8 consecutive runs, so concurrent
@@ -578,7 +580,8 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     const int map_sel = ALZ_TUNE("ALZ_FIR_MAP", 1);
     unsigned gyr;
     if (map_sel == 1) {
-      int64_t gy_fill = (2 * 1024 + gx - 1) / gx;             // waves that fill 1024 SIMDs twice
+      static const int fill = ALZ_TUNE("ALZ_FIR_FILL", 64);
+      int64_t gy_fill = ((int64_t)fill * 1024 + gx - 1) / gx;  // waves that fill 1024 SIMDs `fill` times
       if (gy_fill < 1) gy_fill = 1;
       gyr = (unsigned)(runs_total < gy_fill ? runs_total : gy_fill);
       p.run_first_mul = 1; p.run_stride = gyr; p.run_count = (runs_total + gyr - 1) / gyr;
