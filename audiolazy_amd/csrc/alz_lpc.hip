@@ -238,6 +238,10 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 #ifndef ALZ_LPC_FULL
 #define ALZ_LPC_FULL 1
 #endif
+#ifndef ALZ_LPC_RING
+#define ALZ_LPC_RING 2        // chunk slots in LDS (2: +5..7 % over 3, and deeper is slower still: profiles/NOTES_r03.md 10): ALZ_LPC_RING - 1 chunks of DMA ahead of the one being summed
+#endif
+constexpr int kLpcRing = ALZ_LPC_RING;
 template <int P, int LEV, bool FMA = false>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
     return sig + fr * hop + s0;
   };
   auto queue = [&](int c) {
-    const unsigned slot = lds0 + (unsigned)(c % 3) * 8192u;
+    const unsigned slot = lds0 + (unsigned)(c % kLpcRing) * 8192u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) lpc_dma16(src_of(j, c), slot + j * 1024);
   };
@@ -274,16 +278,23 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
 #pragma unroll
   for (int k = 0; k < H * 16; ++k) hist[k] = 0.0;
 
-  queue(0);
-  if (nchunks > 1) queue(1);
+  for (int c0 = 0; c0 < kLpcRing - 1 && c0 < nchunks; ++c0) queue(c0);
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 2 < nchunks) queue(c + 2);
-    // transfers issued after chunk c's: chunks c+1, c+2 (those that exist)
-    const int after = (nchunks - 1 - c < 2) ? (nchunks - 1 - c) : 2;
-    if (after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char *slot = smem + (c % 3) * 8192 + lane * 128;
+    if (c + kLpcRing - 1 < nchunks) queue(c + kLpcRing - 1);
+    // transfers issued after chunk c's: chunks c+1 .. c+kLpcRing-1 (those that exist)
+    const int after = (nchunks - 1 - c < kLpcRing - 1) ? (nchunks - 1 - c) : kLpcRing - 1;
+    static_assert(kLpcRing >= 2 && (kLpcRing - 1) * 8 <= 56, "vmcnt is a 6-bit count");
+    switch (after) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    }
+    const char *slot = smem + (c % kLpcRing) * 8192 + lane * 128;
     double cur[16];
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {
@@ -469,7 +480,7 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
   if (acorr_stage_fn st_fn = stage_ok(sig, n_frames, frame_len, hop) ? pick_acorr_stage<0>(P) : nullptr) {
-    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, st, sig, n_frames,
+    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), kLpcRing * 8192, st, sig, n_frames,
                        frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
     return true;
@@ -544,7 +555,7 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
     alz::acorr_stage_fn fn = dense ? (fused ? nullptr : alz::pick_acorr_stage_dense(order + 1))
                                    : (fused ? alz::pick_acorr_stage<1, true>(order + 1) : alz::pick_acorr_stage<1>(order + 1));
     if (fn) {
-      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 3 * 8192, (hipStream_t)stream,
+      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), alz::kLpcRing * 8192, (hipStream_t)stream,
                          sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
       if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
       done = true;
