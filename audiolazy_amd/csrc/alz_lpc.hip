@@ -238,11 +238,10 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 #ifndef ALZ_LPC_FULL
 #define ALZ_LPC_FULL 1
 #endif
-#ifndef ALZ_LPC_RING
-#define ALZ_LPC_RING 2        // chunk slots in LDS (2: +5..7 % over 3, and deeper is slower still: profiles/NOTES_r03.md 10): ALZ_LPC_RING - 1 chunks of DMA ahead of the one being summed
-#endif
-constexpr int kLpcRing = ALZ_LPC_RING;
-template <int P, int LEV, bool FMA = false>
+// RING: chunk slots in LDS (RING - 1 chunks of DMA ahead of the one being summed).  Two: 16 KiB instead of 24 put ten
+// one-wave workgroups on a CU instead of six (+7 .. 23 % at 2^20 frames, +3 % at configs[4]'s 65 536; deeper rings are
+// slower still: NOTES_r03.md 10).
+template <int P, int LEV, bool FMA = false, int kLpcRing = 3>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
                                                      double *__restrict__ coefs, double *__restrict__ err,
@@ -389,30 +388,38 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
 
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
-template <int LEV, bool FMA = false>
+template <int LEV, bool FMA = false, int RING = 3>
 static acorr_stage_fn pick_acorr_stage(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9, LEV, FMA>;
-    case 11: return k_acorr_stage<11, LEV, FMA>;
-    case 13: return k_acorr_stage<13, LEV, FMA>;
-    case 17: return k_acorr_stage<17, LEV, FMA>;
-    case 21: return k_acorr_stage<21, LEV, FMA>;
-    case 25: return k_acorr_stage<25, LEV, FMA>;
-    case 33: return k_acorr_stage<33, LEV, FMA>;
+    case 9: return k_acorr_stage<9, LEV, FMA, RING>;
+    case 11: return k_acorr_stage<11, LEV, FMA, RING>;
+    case 13: return k_acorr_stage<13, LEV, FMA, RING>;
+    case 17: return k_acorr_stage<17, LEV, FMA, RING>;
+    case 21: return k_acorr_stage<21, LEV, FMA, RING>;
+    case 25: return k_acorr_stage<25, LEV, FMA, RING>;
+    case 33: return k_acorr_stage<33, LEV, FMA, RING>;
     default: return nullptr;
   }
 }
 
 // the bit-identical one-launch form for the orders the dense Levinson-Durbin is unrolled for (alz_lev.hip has
 // the same list); other orders run the two-launch form
+template <int RING = 3>
 static acorr_stage_fn pick_acorr_stage_dense(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9, 2>;
-    case 11: return k_acorr_stage<11, 2>;
-    case 13: return k_acorr_stage<13, 2>;
-    case 17: return k_acorr_stage<17, 2>;
+    case 9: return k_acorr_stage<9, 2, false, RING>;
+    case 11: return k_acorr_stage<11, 2, false, RING>;
+    case 13: return k_acorr_stage<13, 2, false, RING>;
+    case 17: return k_acorr_stage<17, 2, false, RING>;
     default: return nullptr;
   }
+}
+
+// two chunk slots (one chunk of DMA ahead): same-box pairs 1.04 / 1.06 against 1.01 / 1.02 Gframes/s at 65 536 frames,
+// 1.01 against 0.94 at 2^20 (profiles/r03_lpc_ring.log); the three-slot instantiations stay selectable in tuning builds
+static bool stage_ring2(int64_t) {
+  static const int force = ALZ_TUNE("ALZ_LPC_RING2", 1);
+  return force != 0;
 }
 
 static bool stage_ok(const double *sig, int64_t n_frames, int frame_len, int64_t hop) {
@@ -479,8 +486,10 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   *rc = ALZ_OK;
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
-  if (acorr_stage_fn st_fn = stage_ok(sig, n_frames, frame_len, hop) ? pick_acorr_stage<0>(P) : nullptr) {
-    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), kLpcRing * 8192, st, sig, n_frames,
+  const bool ring2 = stage_ring2(n_frames);
+  if (acorr_stage_fn st_fn = !stage_ok(sig, n_frames, frame_len, hop) ? nullptr
+                             : ring2 ? pick_acorr_stage<0, false, 2>(P) : pick_acorr_stage<0>(P)) {
+    hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, st, sig, n_frames,
                        frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
     return true;
@@ -552,10 +561,14 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
   if (n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
     // one launch: autocorrelation and Levinson-Durbin in the same lane
     const bool fused = (flags & ALZ_LPC_FUSED) != 0;
-    alz::acorr_stage_fn fn = dense ? (fused ? nullptr : alz::pick_acorr_stage_dense(order + 1))
-                                   : (fused ? alz::pick_acorr_stage<1, true>(order + 1) : alz::pick_acorr_stage<1>(order + 1));
+    const bool ring2 = alz::stage_ring2(n_frames);
+    const int P = order + 1;
+    alz::acorr_stage_fn fn =
+        dense ? (fused ? nullptr : ring2 ? alz::pick_acorr_stage_dense<2>(P) : alz::pick_acorr_stage_dense<3>(P))
+        : fused ? (ring2 ? alz::pick_acorr_stage<1, true, 2>(P) : alz::pick_acorr_stage<1, true, 3>(P))
+                : (ring2 ? alz::pick_acorr_stage<1, false, 2>(P) : alz::pick_acorr_stage<1, false, 3>(P));
     if (fn) {
-      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), alz::kLpcRing * 8192, (hipStream_t)stream,
+      hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, (hipStream_t)stream,
                          sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
       if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
       done = true;
