@@ -583,6 +583,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
       static const int fill = ALZ_TUNE("ALZ_FIR_FILL", 64);
       int64_t gy_fill = ((int64_t)fill * 1024 + gx - 1) / gx;  // waves that fill 1024 SIMDs `fill` times
       if (gy_fill < 1) gy_fill = 1;
+      if (gy_fill > 65535) gy_fill = 65535;                      // (the grid's y range)
       gyr = (unsigned)(runs_total < gy_fill ? runs_total : gy_fill);
       p.run_first_mul = 1; p.run_stride = gyr; p.run_count = (runs_total + gyr - 1) / gyr;
     } else {

@@ -553,3 +553,22 @@ def test_streaming_with_gain_division(alz, oracle, layout):
   got = np.concatenate(parts, axis=0 if layout == "time" else 1)
   ref = oracle.bank([3], [3], b, a, x, layout=layout, zero=.125)
   assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_fir_narrow_and_long(alz, oracle):
+  """Shared-tap FIR on 16 channels x 3.4 M samples: more runs than the grid's y range allows blocks (the launcher
+  clamps the grid and lets every block take several runs)."""
+  import torch
+  rng = np.random.default_rng(5)
+  C, n, nb = 16, 3_400_000, 24
+  b = np.tile(rng.uniform(-1, 1, nb), (C, 1))
+  a = np.ones((C, 1))
+  x = rng.uniform(-1, 1, (n, C))
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  y = bank.process(torch.from_numpy(x).cuda(), layout="time").cpu().numpy()
+  pick = np.r_[0:2000, n // 2:n // 2 + 2000, n - 2000:n]
+  ref = oracle.bank([nb], [1], b, a, x[:n // 2 + 2000], layout="time")
+  assert np.array_equal(y[:2000], ref[:2000])
+  assert np.array_equal(y[n // 2:n // 2 + 2000], ref[n // 2:n // 2 + 2000])
+  assert np.isfinite(y[pick]).all() and "k_fir" in bank.last_kernel, bank.last_kernel
