@@ -109,13 +109,14 @@ def stage_memories(memory, nas, zero=0.0):
   return [memory_to_hist(items, na - 1, zero) for na in nas]
 
 
-def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=None):
+def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=None, _hists=None):
   """The filter call protocol for one cascade of LTI sections [(b, a), ...]: ``memory`` is read
   now, the input is not touched until the result is iterated (the reference's generator pulls
   its first sample at the first ``next``); the first item then tells whether samples are scalars
   or rows of C values (C parallel streams, reference tests/test_filters_extdep.py:49-89)."""
   from .stream import Stream
-  hists = stage_memories(memory, [len(a) for _, a in sections], zero)
+  hists = stage_memories(memory, [len(a) for _, a in sections], zero) if _hists is None else \
+      [memory_to_hist(h, len(a) - 1, zero) for h, (_, a) in zip(_hists, sections)]
 
   def blocks_out():
     it = iter(seq)

@@ -57,7 +57,8 @@ Rccl *rccl() {
       for (const char *n : names)
         if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
     if (!r.lib) {
-      r.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+      const char *e = dlerror();   // (the call clears the error: read it once)
+      r.why = std::string("librccl.so not found: ") + (e ? e : "");
       return;
     }
 #define ALZ_SYM(field, name)                                             \

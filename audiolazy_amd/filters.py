@@ -39,10 +39,11 @@ class LinearFilter(object):
     else:
       self.numpoly = Poly(numerator)
       self.denpoly = Poly({0: 1} if denominator is None else denominator)
-    # the denominator starts at z ** 0: a common delay / advance factor is cancelled (:126-132)
-    powers = [k for k, _ in self.denpoly.terms()]
-    if powers and min(powers) != 0:
-      shift = Poly({-min(powers): 1})
+    # the denominator starts at z ** 0: a common delay / advance factor is cancelled (:126-132); a
+    # denominator with no terms (division by the zero filter) is the reference's ``min()`` of nothing
+    power = min(k for k, _ in self.denpoly.terms())   # ValueError when there is no term, like the reference
+    if power != 0:
+      shift = Poly([0, 1]) ** -power
       self.numpoly = self.numpoly * shift
       self.denpoly = self.denpoly * shift
 
@@ -149,6 +150,10 @@ class LinearFilter(object):
     series = any(timevar.is_series(v) for v in numlist) or any(timevar.is_series(v) for v in denlist)
     if not series and self.denpoly[0] == 0:
       raise ZeroDivisionError("Invalid filter gain")
+    # ``memory`` is read NOW, once, like the reference reads it before it builds its generator (:185-195): a
+    # one-shot iterator is drawn from exactly once, and the staged list serves the gate, the engine and the
+    # per-sample path alike
+    memory = generic.read_memory(memory, len(denlist) - 1, zero)
     # The accept gate: the engine computes in float64 on real scalars and rows of them.  What it
     # cannot represent -- an all-integer configuration (ints stay ints, reference :735-742), complex / matrix /
     # symbolic coefficients or items -- runs on the per-sample path with the reference's semantics.
@@ -167,20 +172,40 @@ class LinearFilter(object):
                          lambda s, cs: generic.df1(numlist, denlist, s, memory=memory, zero=zero), seq, numlist, denlist))
 
 
-def _members_fit_engine(members, args, kwargs):
-  """Every member an LTI LinearFilter whose call would pass the engine's coefficient / zero / memory gate."""
+def _call_arguments(args, kwargs):
+  """(memory, zero, other keyword arguments) of a container call ``filt(seq, *args[1:], **kwargs)``."""
+  rest = dict(kwargs)
+  memory = args[1] if len(args) > 1 else rest.pop("memory", None)
+  zero = args[2] if len(args) > 2 else rest.pop("zero", 0.)
+  return memory, zero, rest
+
+
+def _stage_member_memories(members, memory, zero):
+  """``memory`` as the members of a container read it, one after the other AT CALL TIME (the reference's
+  ``reduce`` calls every member before anything is iterated, :988-990, :1052-1054): a list serves every member
+  from its start, a one-shot iterator is drawn from member by member, a callable is called once per member."""
   from . import generic
-  memory = args[1] if len(args) > 1 else kwargs.get("memory")
-  zero = args[2] if len(args) > 2 else kwargs.get("zero", 0.)
+  if memory is None:
+    return [None] * len(members)
+  return [generic.read_memory(memory, len(f.denlist) - 1, zero) for f in members]
+
+
+def _members_fit_engine(members, memories, zero):
+  """Every member an LTI LinearFilter whose call would pass the engine's coefficient / zero / memory gate
+  (``memories``: the staged memory of every member)."""
+  from . import generic
   if not generic.is_engine_item(zero):
     return False
-  for f in members:
-    if not (isinstance(f, LinearFilter) and f.is_lti()):
-      return False
+  for f, memory in zip(members, memories):
     if not generic.coefficients_fit_engine(f.numlist, f.denlist) or \
        generic.all_int_configuration(f.numlist, f.denlist, memory, zero):
       return False
   return True
+
+
+def _members_are_lti(members):
+  return all(isinstance(f, LinearFilter) and f.is_lti() and f.is_causal() and
+             all(k >= 0 for k, _ in f.denpoly.terms()) for f in members)
 
 
 def _zero_fits_engine(zero):
@@ -189,34 +214,38 @@ def _zero_fits_engine(zero):
 
 
 def _gated(engine, fallback, seq, numlist, denlist):
-  """Generator behind a filter call: nothing is pulled until the result is iterated (like the reference's
+  """Iterator behind a filter call: nothing is pulled until the result is iterated (like the reference's
   generator); then the FIRST input item and the first value of every coefficient series decide between the
   GPU engine (real scalars / rows of them) and the per-sample path (everything else).  The peeked values are
-  chained back in front of their iterators."""
+  chained back in front of their iterators.  The choice is made inside a one-item generator under
+  ``chain.from_iterable``: once made, the items come straight from the chosen iterator (for the engine a chain
+  over the lists of whole blocks) -- no Python frame is resumed per sample."""
   import itertools
   from . import generic
-  it = iter(seq)
-  for first in it:
-    break
-  else:
-    return
-  fits = generic.is_engine_item(first)
-  sides = []
-  for coefs in (numlist, denlist):
-    out = []
-    for c in coefs:
-      if generic.is_series(c):
-        ci = iter(c)
-        for head in ci:
-          fits = fits and generic.is_engine_item(head)
-          c = itertools.chain([head], ci)
-          break
-        else:
-          c = iter(())
-      out.append(c)
-    sides.append(out)
-  for item in (engine if fits else fallback)(itertools.chain([first], it), sides):
-    yield item
+
+  def decide():
+    it = iter(seq)
+    for first in it:
+      break
+    else:
+      return
+    fits = generic.is_engine_item(first)
+    sides = []
+    for coefs in (numlist, denlist):
+      out = []
+      for c in coefs:
+        if generic.is_series(c):
+          ci = iter(c)
+          for head in ci:
+            fits = fits and generic.is_engine_item(head)
+            c = itertools.chain([head], ci)
+            break
+          else:
+            c = iter(())
+        out.append(c)
+      sides.append(out)
+    yield iter((engine if fits else fallback)(itertools.chain([first], it), sides))
+  return itertools.chain.from_iterable(decide())
 
 
 class ZFilter(LinearFilter):
@@ -304,8 +333,9 @@ class ZFilter(LinearFilter):
     """Filter an iterable -- or, given a ZFilter, substitute it for z
     (reference :840-889), e.g. ``filt(1 / z)`` reverses the coefficients."""
     if isinstance(seq, ZFilter):
-      inv = 1 / seq
-      return self.numpoly(inv) / self.denpoly(inv)
+      # the reference's own expression, term by term (its roundings, its int / float types, its a0)
+      return sum(v * seq ** -k for k, v in self.numpoly.terms()) / \
+             sum(v * seq ** -k for k, v in self.denpoly.terms())
     return super(ZFilter, self).__call__(seq, memory=memory, zero=zero)
 
   def __repr__(self):
@@ -404,21 +434,32 @@ class CascadeFilter(FilterList):
   def __call__(self, *args, **kwargs):
     seq = args[0]
     members = self.callables
-    def one_by_one(data, _coefs=None):
-      for f in members:
-        data = f(data, *args[1:], **kwargs)
-      return data
-    if members and _members_fit_engine(members, args, kwargs):
-      from .bank import call_sections, sections_of
-      from .stream import Stream
-      # one fused engine call for items the engine takes; anything else goes through the members' own gates
-      return Stream(_gated(lambda s, cs: call_sections(sections_of(members), s, *args[1:], **kwargs), one_by_one, seq, [], []))
-    data = seq
-    for f in members:
-      data = f(data, *args[1:], **kwargs)
     if not members:
       from .stream import Stream
       return Stream(seq)
+    if _members_are_lti(members) and not any(f.denpoly[0] == 0 for f in members):
+      memory, zero, rest = _call_arguments(args, kwargs)
+      if set(rest) <= {"block"}:
+        # every stage's memory is read now, in stage order, like the reference's reduce does it (:988-990)
+        memories = _stage_member_memories(members, memory, zero)
+        if _members_fit_engine(members, memories, zero):
+          from .bank import call_sections, sections_of
+          from .stream import Stream
+
+          def one_by_one(data, _coefs=None):   # items the engine does not take: the members' own gates
+            for f, mem in zip(members, memories):
+              data = f(data, memory=mem, zero=zero)
+            return data
+          hists = None if memory is None else memories
+          return Stream(_gated(lambda s, cs: call_sections(sections_of(members), s, zero=zero, _hists=hists, **rest),
+                               one_by_one, seq, [], []))
+        data = seq
+        for f, mem in zip(members, memories):
+          data = f(data, memory=mem, zero=zero)
+        return data
+    data = seq
+    for f in members:
+      data = f(data, *args[1:], **kwargs)
     return data
 
   @property
@@ -461,21 +502,27 @@ class ParallelFilter(FilterList):
       return Stream(zero for _ in seq)
     import itertools
 
-    def one_by_one(src, _coefs=None):
+    def one_by_one(src, _coefs=None, memories=None):
       copies = itertools.tee(src, len(members))
       total = None
-      for f, part in zip(members, copies):
-        out = f(part, *args[1:], **kwargs)
+      for i, (f, part) in enumerate(zip(members, copies)):
+        out = f(part, *args[1:], **kwargs) if memories is None else f(part, memory=memories[i], zero=zero)
         out = out if isinstance(out, Stream) else Stream(out)
         total = out if total is None else total + out
       return total
-    if _members_fit_engine(members, args, kwargs) and len(args) == 1 and set(kwargs) <= {"memory", "zero", "block"}:
-      def bank(src, _coefs=None):
-        try:
-          return self._call_bank(src, kwargs.get("memory"), kwargs.get("zero", 0.), kwargs.get("block"))
-        except NotImplementedError:   # coefficients outside the engine's gate
-          return one_by_one(src)
-      return Stream(_gated(bank, one_by_one, seq, [], []))
+    if _members_are_lti(members) and not any(f.denpoly[0] == 0 for f in members):
+      memory, zero, rest = _call_arguments(args, kwargs)
+      if set(rest) <= {"block"}:
+        # every member's memory is read now, in member order (the reference's reduce, :1052-1054)
+        memories = _stage_member_memories(members, memory, zero)
+        if _members_fit_engine(members, memories, zero):
+          def bank(src, _coefs=None):
+            try:
+              return self._call_bank(src, memories, zero, rest.get("block"))
+            except NotImplementedError:   # coefficients outside the engine's gate
+              return one_by_one(src, memories=memories)
+          return Stream(_gated(bank, lambda src, _c=None: one_by_one(src, memories=memories), seq, [], []))
+        return one_by_one(seq, memories=memories)
     return one_by_one(seq)
 
   @property
@@ -504,7 +551,7 @@ class ParallelFilter(FilterList):
       out = r if out is None else out + r
     return out
 
-  def _call_bank(self, seq, memory, zero, block):
+  def _call_bank(self, seq, memories, zero, block):
     """All filters as the coefficient sets of one OUTER bank over the single input, then the
     ordered sum over the sets on the device (alz_mix_dev)."""
     import itertools
@@ -527,18 +574,14 @@ class ParallelFilter(FilterList):
       b[i, :len(bi)] = bi
       a[i, :len(ai)] = ai
     bank = FilterBank([(b, a)], n_inputs=1, mode="outer")
-    # every filter receives the same memory / zero (reference :1053) but applies the padding rule
-    # with its own order, so the histories are built per filter
-    if callable(memory) and not hasattr(memory, "__iter__"):
-      items = None
-    else:
-      items = None if memory is None else list(itertools.islice(iter(memory), na - 1))
+    # every filter received the same memory / zero (reference :1053) and applied the padding rule with its own
+    # order: ``memories`` holds the staged list of every filter (None: all ``zero``)
     xh = np.full((len(secs), max(nb - 1, 1)), float(zero))
     yh = np.full((len(secs), max(na - 1, 1)), float(zero))
     for i, (_, ai) in enumerate(secs):
       lm = len(ai) - 1
-      hist = memory_to_hist(memory if (memory is not None and items is None) else items, lm, zero)
-      yh[i, :lm] = hist
+      if memories[i] is not None:
+        yh[i, :lm] = memory_to_hist(memories[i], lm, zero)
     bank.reset(zero=float(zero))
     bank.set_state(xh, yh)
 

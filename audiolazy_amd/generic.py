@@ -63,16 +63,12 @@ def all_int_configuration(numlist, denlist, memory, zero):
   lm = len(a) - 1
   short_memory = lm > 0 and (memory is None or callable(memory))
   if not (memory is None or callable(memory)):
-    try:
-      mem = list(itertools.islice(memory, lm)) if not hasattr(memory, "__len__") else list(memory)[:lm]
-    except TypeError:
+    if not hasattr(memory, "__len__"):
+      return False       # a one-shot iterator is never pulled here: callers stage it first (read_memory)
+    mem = list(memory)[:lm]
+    if not all(is_int(v) for v in mem):
       return False
-    if hasattr(memory, "__len__"):
-      if not all(is_int(v) for v in mem):
-        return False
-      short_memory = len(mem) < lm
-    else:
-      return False       # (a one-shot iterator: leave it to the call to consume)
+    short_memory = len(mem) < lm
   # ``zero`` is read as a past input by numerator taps at delay >= 1 and fills a missing / short memory
   zero_read = any(present(c) for c in b[1:]) or short_memory
   return is_int(zero) or not zero_read
@@ -81,6 +77,20 @@ def all_int_configuration(numlist, denlist, memory, zero):
 def coefficients_fit_engine(numlist, denlist):
   """Constant coefficients must be real scalars for the engine (series are looked at when they are pulled)."""
   return all(is_series(c) or is_engine_scalar(c) for c in list(numlist) + list(denlist))
+
+
+def read_memory(memory, size, zero):
+  """The ``memory`` argument as the reference reads it AT CALL TIME (:185-195): None stays None (all ``zero``);
+  a callable is called with the size; from an iterable the first ``size`` items are taken -- by the reference's
+  own ``takewhile`` over ``enumerate``, which also draws the item that ends it from a one-shot iterator -- and a
+  short one is LEFT-padded with ``zero``.  Returns a list of exactly ``size`` items: staged once, it can be
+  handed to the gate, the engine and the per-sample path alike without anything being pulled twice."""
+  if memory is None:
+    return None
+  if not is_series(memory):
+    memory = memory(size)
+  got = [item for _unused, item in itertools.takewhile(lambda pair: pair[0] < size, enumerate(memory))]
+  return [zero] * (size - len(got)) + got
 
 
 def initial_memory(memory, size, zero):

@@ -327,7 +327,34 @@ def generic_item_cases():
           count(start=sqrt(2), step=pi / 3)]
   sig = Stream(mat(vect).reshape(2, 3) for vect in zip(*data))
   add("matrix_items_matrix_series", filt(sig, zero=mat([[0, 0, 0], [0, 0, 0]])).limit(12))
+  # ``memory`` given as a one-shot iterator / Stream / callable: read once, at call time (:185-195); containers
+  # hand the SAME object to every member in turn (:988-990, :1052-1054), so an iterator is drawn from member by
+  # member (the ``takewhile`` that reads it also draws the item that ends it)
+  acc = ZFilter([1, 1], [1, -1])
+  two = ZFilter([1], [1, 0, -1])
+  add("mem_iter_int", acc([1, 5, -4, -7, 9], memory=iter([3]), zero=0))
+  add("mem_stream_int", acc([1, 5, -4, -7, 9], memory=Stream([3, 8]), zero=0))
+  add("mem_iter_short_int", two([1, 5, -4, -7, 9], memory=iter([3]), zero=0))
+  add("mem_callable_int", two([1, 5, -4, -7, 9], memory=lambda n: [7] * n, zero=0))
+  add("mem_cascade_iter_int", CascadeFilter(acc, two, acc)([1, 5, -4, -7, 9], memory=iter([3, 4, 5, 6, 7, 8, 9]), zero=0))
+  add("mem_cascade_list_int", CascadeFilter(acc, two, acc)([1, 5, -4, -7, 9], memory=[3, 4, 5], zero=0))
+  add("mem_parallel_iter_int", ParallelFilter(acc, two, acc)([1, 5, -4, -7, 9], memory=iter([3, 4, 5, 6, 7, 8, 9]), zero=0))
+  # float memories on integer-coefficient filters: these calls are the float engine's (GPU tests read them)
+  add("mem_iter_float", acc([1., 5., -4., -7., 9.], memory=iter([5.0])))
+  add("mem_stream_float", two([1., 5., -4., -7., 9.], memory=Stream([.5, .25, 8.])))
+  add("mem_comb_iter_float", (1 / (1 - z ** -3))([1., 5., -4., -7., 9., 2.], memory=iter([.5, .25])))
+  add("mem_cascade_iter_float", CascadeFilter(acc, two, acc)([1., 5., -4., -7., 9.], memory=iter([3., 4., 5., 6., 7., 8., 9.])))
+  add("mem_parallel_iter_float", ParallelFilter(acc, two, acc)([1., 5., -4., -7., 9.], memory=iter([3., 4., 5., 6., 7., 8., 9.])))
+  add("mem_mutated_after_call", _mutated_memory_case())
   return out
+
+
+def _mutated_memory_case():
+  """The memory list is changed between the call and the iteration: the reference has already copied it."""
+  mem = [3.]
+  res = ZFilter([1, 1], [1, -1])([1., 5., -4.], memory=mem)
+  mem[0] = 100.
+  return res
 
 
 # --------------------------------------------------------------------------
@@ -579,6 +606,78 @@ def maps_cases():
   return out
 
 
+# --------------------------------------------------------------------------
+# 14. ``filt(other_zfilter)``: substitution of a ZFilter for z (lazy_filters.py:885-887,
+#     ``sum(v * seq ** -k ...) / sum(v * seq ** -k ...)``) and what the constructor makes of a zero
+#     denominator (lazy_filters.py:125-133: ``min()`` of no terms -> ValueError).  Seeded random rational
+#     pairs: constants, pure delays / advances, integer coefficients, zero numerators.
+# --------------------------------------------------------------------------
+def typed(v):
+  """A coefficient with its Python type: the reference keeps ints ints."""
+  if isinstance(v, bool) or not isinstance(v, (int, float)):
+    raise TypeError(type(v))
+  return ["i", int(v)] if isinstance(v, int) else ["f", float(v).hex()]
+
+
+def zfilter_outcome(fn):
+  """What an expression gives: the (power, typed value) terms of numpoly / denpoly, or the exception's name."""
+  try:
+    r = fn()
+  except Exception as exc:   # noqa: BLE001 -- the exception type IS the datum
+    return dict(raises=type(exc).__name__)
+  if not isinstance(r, ZFilter):
+    return dict(value=typed(r))
+  return dict(num=[[typed(k), typed(v)] for k, v in r.numpoly.terms()],
+              den=[[typed(k), typed(v)] for k, v in r.denpoly.terms()])
+
+
+def random_rational(rng, kind):
+  """(num terms, den terms) as {power: value} dicts in z ** -1; ``kind`` picks the family."""
+  def coef(integer):
+    if integer:
+      return rng.choice([-3, -2, -1, 1, 2, 3, 4])
+    return rng.choice([rng.uniform(-2., 2.), round(rng.uniform(-3., 3.), 1), .5, -.25, 1.5])
+  def poly(nterms, integer, lo, hi):
+    return {p: coef(integer) for p in rng.sample(range(lo, hi + 1), nterms)}
+  integer = rng.random() < .4
+  if kind == "const":
+    return {0: coef(integer)}, {0: 1}
+  if kind == "delay":
+    return {rng.choice([-3, -2, -1, 1, 2, 3]): rng.choice([1, 1, -1, coef(integer)])}, {0: 1}
+  if kind == "zero":
+    return {}, {0: 1} if rng.random() < .5 else poly(2, integer, 0, 2)
+  if kind == "fir":
+    return poly(rng.randint(1, 3), integer, -1, 3), {0: 1}
+  num = poly(rng.randint(1, 3), integer, -1, 3)
+  den = poly(rng.randint(1, 3), integer, 0, 3)
+  if rng.random() < .3:
+    den[0] = 1
+  return num, den
+
+
+def composition_cases():
+  rng = random.Random(20260925)
+  kinds = ["const", "delay", "zero", "fir", "rational", "rational", "rational", "fir"]
+  out = []
+  for idx in range(640):
+    fk, gk = rng.choice(kinds), rng.choice(kinds)
+    fnum, fden = random_rational(rng, fk)
+    gnum, gden = random_rational(rng, gk)
+    case = dict(f=[[[typed(k), typed(v)] for k, v in d.items()] for d in (fnum, fden)],
+                g=[[[typed(k), typed(v)] for k, v in d.items()] for d in (gnum, gden)])
+    def build(num, den):
+      return ZFilter(dict(num), dict(den))
+    case["f_built"] = zfilter_outcome(lambda: build(fnum, fden))
+    case["g_built"] = zfilter_outcome(lambda: build(gnum, gden))
+    case["f_of_g"] = zfilter_outcome(lambda: build(fnum, fden)(build(gnum, gden)))
+    # division by / negative power of a filter whose numerator may be zero (empty denominator -> ValueError)
+    case["g_over_f"] = zfilter_outcome(lambda: build(gnum, gden) / build(fnum, fden))
+    case["k_over_f"] = zfilter_outcome(lambda: 2.5 / build(fnum, fden))
+    case["f_inv"] = zfilter_outcome(lambda: build(fnum, fden) ** -1)
+    out.append(case)
+  return out
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-maps":
@@ -586,6 +685,9 @@ if __name__ == "__main__":
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-generic":
     dump("generic_items.json", generic_item_cases())
+    sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-composition":
+    dump("composition.json", composition_cases())
     sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-lpc-strategies":
     dump("lpc_strategies.json", lpc_strategy_cases())
@@ -605,3 +707,5 @@ if __name__ == "__main__":
   dump("timevar_algebra.json", timevar_algebra_cases())
   dump("maps.json", maps_cases())
   dump("lpc_strategies.json", lpc_strategy_cases())
+  dump("generic_items.json", generic_item_cases())
+  dump("composition.json", composition_cases())

@@ -72,3 +72,38 @@ def test_memory_to_hist_reference_rules():
   assert memory_to_hist([1, 2, 3], 2, 0.) == [1, 2]
   assert memory_to_hist(lambda n: [9.] * n, 3, 0.) == [9., 9., 9.]
   assert memory_to_hist(iter([4, 5, 6]), 1, 0.) == [4]
+
+
+def test_missing_rccl_is_unsupported_not_a_crash(tmp_path):
+  """include/alz.h promises ALZ_E_UNSUPPORTED from alz_comm_* when librccl cannot be loaded.  The loader is made
+  to refuse every "rccl" name WITHOUT setting dlerror (a preloaded dlopen): round 3 built its message from a
+  second dlerror() call, i.e. from NULL."""
+  import subprocess
+  import sys
+  stub = tmp_path / "norccl.c"
+  stub.write_text(r'''
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <string.h>
+void *dlopen(const char *name, int flags) {
+  static void *(*real)(const char *, int);
+  if (!real) real = (void *(*)(const char *, int))dlsym(RTLD_NEXT, "dlopen");
+  if (name && strstr(name, "rccl")) return 0;
+  return real(name, flags);
+}
+''')
+  so = tmp_path / "norccl.so"
+  subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(stub), "-ldl"])
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = (
+    "import ctypes, sys\n"
+    "L = ctypes.CDLL(%r)\n"
+    "L.alz_last_error.restype = ctypes.c_char_p\n"
+    "buf = ctypes.create_string_buffer(128)\n"
+    "rc = L.alz_comm_unique_id(buf)\n"
+    "print(rc, L.alz_last_error().decode())\n" % os.path.join(root, "audiolazy_amd", "libalzhip.so"))
+  env = dict(os.environ, LD_PRELOAD=str(so))
+  res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+  assert res.returncode == 0, res.stderr[-2000:]
+  rc, msg = res.stdout.strip().split(" ", 1)
+  assert int(rc) == -7 and "librccl.so not found" in msg, res.stdout

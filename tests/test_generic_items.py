@@ -99,3 +99,36 @@ def test_product_never_imports_the_oracle():
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   src = open(os.path.join(root, "audiolazy_amd", "generic.py")).read()
   assert "import oracle" not in src and "from oracle" not in src and "/root/reference" not in src
+
+
+def test_memory_is_read_once_at_call_time():
+  """``memory`` as a one-shot iterator, a Stream or a callable (reference lazy_filters.py:185-195): read once, when
+  the filter is CALLED; the gate never draws from it (round-3 advisor: it did, and an integer-coefficient filter
+  lost its initial state).  Containers hand the same object to every member in turn (:988-990, :1052-1054)."""
+  from audiolazy_amd import CascadeFilter, ParallelFilter, Stream, ZFilter, generic
+  from audiolazy_amd.bank import stage_memories
+  acc, two = ZFilter([1, 1], [1, -1]), ZFilter([1], [1, 0, -1])
+  data = [1, 5, -4, -7, 9]
+  check("mem_iter_int", acc(data, memory=iter([3]), zero=0))
+  check("mem_stream_int", acc(data, memory=Stream([3, 8]), zero=0))
+  check("mem_iter_short_int", two(data, memory=iter([3]), zero=0))
+  check("mem_callable_int", two(data, memory=lambda n: [7] * n, zero=0))
+  check("mem_cascade_iter_int", CascadeFilter(acc, two, acc)(data, memory=iter([3, 4, 5, 6, 7, 8, 9]), zero=0))
+  check("mem_cascade_list_int", CascadeFilter(acc, two, acc)(data, memory=[3, 4, 5], zero=0))
+  check("mem_parallel_iter_int", ParallelFilter(acc, two, acc)(data, memory=iter([3, 4, 5, 6, 7, 8, 9]), zero=0))
+  # the advisor's reproduction: the gate leaves a one-shot iterator alone
+  mem = iter([5.0])
+  assert generic.all_int_configuration([1, 1], [1, -1], mem, 0.) is False
+  assert stage_memories(mem, [2]) == [[5.0]]
+  # staged at call time: what happens to the caller's object afterwards does not matter
+  pulled = []
+
+  def memory_source():
+    for v in (3, 4):
+      pulled.append(v)
+      yield v
+  res = acc(data, memory=memory_source(), zero=0)
+  assert pulled == [3, 4]          # (the reference's takewhile draws the item that ends it too)
+  assert list(res) == [4, 10, 11, 0, 2]
+  assert generic.read_memory(None, 3, 0.) is None and generic.read_memory([.7], 2, 0.) == [0., .7]
+  assert generic.read_memory(iter(range(9)), 2, 0.) == [0, 1] and generic.read_memory(lambda n: [1.] * n, 2, 0) == [1., 1.]

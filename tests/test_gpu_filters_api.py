@@ -262,3 +262,29 @@ def test_calls_own_their_state_and_touch_their_input_lazily(al):
   got = np.array(list(casc(iter(rows), zero=np.zeros(3))))
   ref = oracle.bank([2, 2], [3, 1], np.array(b + [1., -1.]), np.array(a + [1.]), rows)
   assert same_bits(got, ref)
+
+
+def test_memory_iterables_on_the_engine(al):
+  """Float memories given as one-shot iterators / Streams to INTEGER-coefficient filters: the gate must not draw
+  from them (round-3 advisor); read once at call time, member by member in containers (reference
+  lazy_filters.py:185-195, :988-990, :1052-1054).  Golden values from the reference (generic_items.json)."""
+  gold = {c["tag"]: c for c in load_golden("generic_items.json")}
+  acc, two = al.ZFilter([1, 1], [1, -1]), al.ZFilter([1], [1, 0, -1])
+  data = [1., 5., -4., -7., 9.]
+
+  def check(tag, res):
+    got = list(res)
+    assert all(isinstance(v, float) for v in got), tag
+    assert [repr(v) for v in got] == gold[tag]["reprs"], tag
+  check("mem_iter_float", acc(data, memory=iter([5.0])))
+  check("mem_stream_float", two(data, memory=al.Stream([.5, .25, 8.])))
+  check("mem_comb_iter_float", (1 / (1 - al.z ** -3))(data + [2.], memory=iter([.5, .25])))
+  check("mem_cascade_iter_float", al.CascadeFilter(acc, two, acc)(data, memory=iter([3., 4., 5., 6., 7., 8., 9.])))
+  check("mem_parallel_iter_float", al.ParallelFilter(acc, two, acc)(data, memory=iter([3., 4., 5., 6., 7., 8., 9.])))
+  mem = [3.]
+  res = acc(data[:3], memory=mem)
+  mem[0] = 100.            # the call has already staged its memory
+  check("mem_mutated_after_call", res)
+  # a bad memory argument fails at the call, not at the first next()
+  with pytest.raises(TypeError):
+    acc(data, memory=5.0)
