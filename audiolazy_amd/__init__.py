@@ -8,7 +8,7 @@ of it (WavStream / chunks sample formats, Streamix mixing), executed by hand-wri
 for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design, the z**-1 algebra and the lazy
 Stream type stay on the host in float64 and follow the reference's semantics.
 """
-from ._ffi import ParCorError, load as load_library, device_count  # noqa: F401
+from ._ffi import ParCorError, load as load_library, device_count, last_kernel  # noqa: F401
 from .stream import Stream, ControlStream, Streamix, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
 from .bank import FilterBank, memory_to_hist, sections_of, block_size, mix_tracks, mix_sets  # noqa: F401
 from .poly import Poly, x  # noqa: F401

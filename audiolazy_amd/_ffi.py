@@ -35,6 +35,7 @@ _int = ctypes.c_int
 SIGNATURES = {
   "alz_version": (_int, []),
   "alz_last_error": (ctypes.c_char_p, []),
+  "alz_last_kernel": (ctypes.c_char_p, []),
   "alz_device_count": (_int, [_ip]),
   "alz_malloc": (_int, [_int, _u64, ctypes.POINTER(_vp)]),
   "alz_free": (_int, [_int, _vp]),
@@ -142,6 +143,13 @@ def load():
 def last_error():
   msg = load().alz_last_error()
   return msg.decode("utf-8", "replace") if msg else ""
+
+
+def last_kernel():
+  """Kernel(s) the last handle-less call of this thread launched (alz_last_kernel): lpc / acorr / levinson /
+  time-varying blocks.  Banks report theirs through ``FilterBank.last_kernel``."""
+  name = load().alz_last_kernel()
+  return name.decode("utf-8", "replace") if name else ""
 
 
 def check(rc):

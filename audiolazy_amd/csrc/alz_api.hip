@@ -15,7 +15,12 @@ namespace alz {
 
 static thread_local std::string g_err;
 
+static thread_local std::string g_kernel;
 void set_error(const std::string &msg) { g_err = msg; }
+void note_kernel(const std::string &name, bool append) {
+  if (append && !g_kernel.empty()) g_kernel += " + " + name;
+  else g_kernel = name;
+}
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
@@ -111,6 +116,8 @@ extern "C" {
 int alz_version(void) { return ALZ_VERSION; }
 
 const char *alz_last_error(void) { return alz::g_err.c_str(); }
+
+const char *alz_last_kernel(void) { return alz::g_kernel.c_str(); }
 
 int alz_device_count(int *count) {
   if (!count) return fail(ALZ_E_ARG, "count is NULL");
@@ -361,10 +368,26 @@ int alz_bank_set_state(alz_bank_t *h, const double *xh_host, const double *yh_ho
   return put_state(h, xh_host, yh_host);
 }
 
+// The one-pass time-parallel kernel (alz_look.hip) reports a wait that ran out in a word of pinned host memory per
+// section.  Every entry point that hands results to the caller looks at it -- after its synchronisation where it has
+// one -- so a bad block is never delivered silently (round-3 review: only the NEXT one-pass call used to look).
+static int take_look_error(alz_bank_t *h) {
+  bool bad = false;
+  for (alz::ScanScratch &sc : h->scan)
+    if (sc.look_err && *(volatile int *)sc.look_err != 0) {
+      *sc.look_err = 0;
+      bad = true;
+    }
+  return bad ? fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel gave up waiting for another workgroup "
+                               "(the block it wrote is invalid; process it again)")
+             : ALZ_OK;
+}
+
 int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host) {
   if (!h) return fail(ALZ_E_ARG, "NULL handle");
   DeviceGuard g(h->device);
   ALZ_HIP_CHECK(hipDeviceSynchronize());
+  if (const int lrc = take_look_error(h)) return lrc;
   const int64_t C = h->channels;
   std::vector<double> tmp;
   for (int s = 0; s < h->n_sections; ++s) {
@@ -398,6 +421,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     return fail(ALZ_E_ARG, "in-place processing needs DIAGONAL mode and ldx == ldy");
   h->last_kernels.clear();
   h->last_kernel = "";
+  if (const int lrc = take_look_error(h)) return lrc;      // (an EARLIER block of this handle: read without a sync)
   if (n == 0) return ALZ_OK;
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
@@ -605,14 +629,22 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     if (hipEventRecord(start, st) != hipSuccess) return -1000;         // everything queued on `st` so far (input map, expansion)
     for (int s = 0; s + 1 < ns; ++s)
       if (hipStreamWaitEvent(h->sec_streams[s], start, 0) != hipSuccess) return -1000;
+    // an error in the middle leaves work queued on the side streams: the caller's stream is made to wait for it
+    // before the error is returned, so that "everything this call queued is ordered before what the caller queues
+    // next on `st`" holds on the error paths too
+    auto bail = [&](int code) -> int {
+      for (int s = 0; s + 1 < ns; ++s)
+        if (hipEventRecord(ev_of(s, 0), h->sec_streams[s]) == hipSuccess) (void)hipStreamWaitEvent(st, ev_of(s, 0), 0);
+      return code;
+    };
     for (int64_t j = 0; j < n_chunks; ++j) {
       const int64_t t0 = j * chunk, tn = (t0 + chunk <= n) ? chunk : n - t0;
       for (int s = 0; s < ns; ++s) {
         hipStream_t ss = stream_of(s);
-        if (s > 0 && !ALZ_TUNE("ALZ_SECPIPE_NOWAIT", 0) && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return -1000;
+        if (s > 0 && !ALZ_TUNE("ALZ_SECPIPE_NOWAIT", 0) && hipStreamWaitEvent(ss, ev_of(s - 1, j), 0) != hipSuccess) return bail(-1000);
         const int rc = run_sections_on(0, h->channels, t0, tn, s, s + 1, ss);
-        if (rc) return rc;
-        if (hipEventRecord(ev_of(s, j), ss) != hipSuccess) return -1000;
+        if (rc) return bail(rc);
+        if (hipEventRecord(ev_of(s, j), ss) != hipSuccess) return bail(-1000);
       }
     }
     // (the caller's stream ends with the last section's last chunk; every earlier section finished before that
@@ -730,6 +762,7 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
       if (ry == hipSuccess) (void)hipHostUnregister((void *)y_host);
       if (rc == ALZ_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
         rc = fail(ALZ_E_HIP, "host pipeline: stream synchronisation failed");
+      if (rc == ALZ_OK) rc = take_look_error(h);
       return rc;
     }
     if (rx == hipSuccess) (void)hipHostUnregister((void *)x_host);     // y could not be pinned: plain path
@@ -739,6 +772,7 @@ int alz_bank_process_host(alz_bank_t *h, const double *x_host, double *y_host, i
   rc = alz_bank_process_dev(h, h->stage_x, h->stage_y, n, layout, lsx, lsy, nullptr);
   if (rc) return rc;
   ALZ_HIP_CHECK(hipStreamSynchronize(nullptr));
+  if (const int lrc = take_look_error(h)) return lrc;
   ALZ_HIP_CHECK(hipMemcpy2D(y_host, (size_t)ldy * 8, h->stage_y, (size_t)lsy * 8, (size_t)out_cols * 8,
                             (size_t)out_rows, hipMemcpyDeviceToHost));
   return ALZ_OK;
@@ -770,7 +804,7 @@ int alz_bank_sync(alz_bank_t *h) {
   if (!h) return fail(ALZ_E_ARG, "NULL handle");
   DeviceGuard g(h->device);
   ALZ_HIP_CHECK(hipDeviceSynchronize());
-  return ALZ_OK;
+  return take_look_error(h);
 }
 
 const char *alz_bank_last_kernel(const alz_bank_t *h) { return h ? h->last_kernels.c_str() : ""; }

@@ -33,6 +33,9 @@ namespace alz {
 // thread-local last-error message (alz_last_error)
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
+// thread-local name of what the last handle-less call (alz_lpc_*, alz_acorr_dev, alz_levinson_dev*, alz_tv_process_dev)
+// launched (alz_last_kernel): a diagnostic, like alz_bank_last_kernel for banks
+void note_kernel(const std::string &name, bool append = false);
 
 #define ALZ_HIP_CHECK(expr)                                                              \
   do {                                                                                   \

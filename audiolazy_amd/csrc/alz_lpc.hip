@@ -492,12 +492,14 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
     hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, st, sig, n_frames,
                        frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
+    note_kernel("k_acorr_stage<" + std::to_string(P) + ",lags," + (ring2 ? "2" : "3") + " slots>", true);
     return true;
   }
   if (acorr_lane_fn lane_fn = (n_frames >= 16384 && frame_len >= 2 * P) ? pick_acorr_lane(P) : nullptr) {
     hipLaunchKernelGGL(lane_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, sig, n_frames,
                        frame_len, hop, r_out);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_lane launch failed");
+    note_kernel("k_acorr_lane<" + std::to_string(P) + ">", true);
     return true;
   }
   const int nfr_max = 64 / P + 2;     // frames one wave's 64 (frame, lag) pairs can touch
@@ -507,11 +509,13 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
     hipLaunchKernelGGL(k_acorr_global, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, st, sig, n_frames,
                        frame_len, hop, P, r_out);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_global launch failed");
+    note_kernel("k_acorr_global", true);
     return true;
   }
   hipLaunchKernelGGL(k_acorr_dense, dim3((unsigned)((total + 63) / 64)), dim3(64), lds, st, sig, n_frames,
                      frame_len, hop, P, r_out);
   if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_dense launch failed");
+  note_kernel("k_acorr_dense", true);
   return true;
 }
 
@@ -541,6 +545,7 @@ static int launch_lpc(const double *sig, int64_t n_frames, int frame_len, int64_
                        err, status, r_out, from_r);
   }
   ALZ_HIP_CHECK(hipGetLastError());
+  note_kernel(std::string("k_lpc<") + (slot == 32 ? "32" : "64") + ">", true);
   return ALZ_OK;
 }
 
@@ -557,6 +562,7 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
   bool done = false;
+  alz::note_kernel("");
   const bool dense = (flags & ALZ_LPC_DENSE) != 0 || order > 63;     // (orders past the register kernels: dense form only)
   if (n_frames > 0 && alz::stage_ok(sig_dev, n_frames, frame_len, hop)) {
     // one launch: autocorrelation and Levinson-Durbin in the same lane
@@ -571,6 +577,8 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
       hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, (hipStream_t)stream,
                          sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
       if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
+      alz::note_kernel("k_acorr_stage<" + std::to_string(P) + (dense ? ",dense Levinson-Durbin" : fused ? ",lev,fma" : ",lev") +
+                       (ring2 ? ",2 slots>" : ",3 slots>"));
       done = true;
     }
   }
@@ -586,6 +594,7 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
       if (rc == ALZ_OK)
         rc = alz::launch_levinson_dense(r_tmp, n_frames, order + 1, order, coefs_dev, err_dev, status_dev,
                                         (hipStream_t)stream);
+      alz::note_kernel("k_levinson_dense", true);
       (void)hipFreeAsync(r_tmp, (hipStream_t)stream);
     }
     done = true;
@@ -601,6 +610,7 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
                              (hipStream_t)stream, r_tmp, n_frames, order + 1, order, coefs_dev, err_dev,
                              status_dev);
           if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_levinson_lane launch failed");
+          alz::note_kernel("k_levinson_lane", true);
         }
         done = true;
       }
@@ -632,13 +642,16 @@ int alz_levinson_dev_ex(const double *r_dev, int64_t n_frames, int n_lags, int o
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
+  alz::note_kernel("");
   if ((flags & ALZ_LPC_DENSE) != 0 || order > 63) {
     rc = alz::launch_levinson_dense(r_dev, n_frames, n_lags, order, coefs_dev, err_dev, status_dev, (hipStream_t)stream);
+    alz::note_kernel("k_levinson_dense", true);
   } else if (order <= alz::kLevMax) {
     if (n_frames > 0) {
       hipLaunchKernelGGL(alz::k_levinson_lane, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0,
                          (hipStream_t)stream, r_dev, n_frames, n_lags, order, coefs_dev, err_dev, status_dev);
       if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_levinson_lane launch failed");
+      alz::note_kernel("k_levinson_lane", true);
     }
   } else {
     rc = alz::launch_lpc(r_dev, n_frames, n_lags, n_lags, order, coefs_dev, err_dev, status_dev, nullptr, 1,
@@ -660,6 +673,7 @@ int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_
   ALZ_HIP_CHECK(hipGetDevice(&prev));
   if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
   int rc = ALZ_OK;
+  alz::note_kernel("");
   if (n_frames <= 0 || !alz::launch_acorr_dense(sig_dev, n_frames, frame_len, hop, max_lag, r_dev,
                                                 (hipStream_t)stream, &rc))
     rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, max_lag, nullptr, nullptr, nullptr, r_dev, 0,

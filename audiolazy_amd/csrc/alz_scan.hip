@@ -153,12 +153,7 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (chunk_len < 0) chunk_len = 0;
   if (one_pass && sec.na > 1 && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
     const int64_t groups = C / 16, Kl = io.n / kLookChunk;
-    // a bounded wait of an EARLIER launch on this handle ran out (it cannot: every wait points to earlier work of
-    // workgroups that are resident): the kernel said so in a word of pinned host memory, read here without a sync
-    if (scratch->look_err && *(volatile int *)scratch->look_err != 0) {
-      *scratch->look_err = 0;
-      return fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel gave up waiting in an earlier call (its output is invalid)");
-    }
+    // (a wait that ran out in an earlier launch is reported by alz_api.hip's take_look_error at every entry point)
     if (!scratch->look_err) {
       if (hipHostMalloc((void **)&scratch->look_err, 64, hipHostMallocDefault) != hipSuccess)
         return fail(ALZ_E_NOMEM, "hipHostMalloc failed (time-parallel scratch)");

@@ -485,6 +485,7 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
   }
   p.gain = a[0].value;
   p.gain_mode = p.gain == 1.0 ? 0 : p.gain == -1.0 ? 2 : 1;
+  alz::note_kernel("");
   if (n == 0) return ALZ_OK;
   int prev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&prev));
@@ -505,11 +506,12 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     }
     int64_t done = 0;
     if (ok) {
-      const int rc = alz::launch_tvduo(p.x, p.y, n, ldx, ldy, layout == ALZ_CHAN_MAJOR, channels, nb, na, kind, value,
+      const int rc = alz::launch_tvduo(p.x, p.y, p.n, ldx, ldy, layout == ALZ_CHAN_MAJOR, channels, nb, na, kind, value,
                                        series, negated, xh_dev, yh_dev, (hipStream_t)stream, &done);
       if (rc) { if (prev != device) (void)hipSetDevice(prev); return rc; }
     }
     if (done > 0) {
+      alz::note_kernel("k_tvduo", true);
       p.x += done * p.sxn; p.y += done * p.syn; p.n -= done;
       for (int k = 0; k < alz::kTvMax; ++k) {
         if (p.b.kind[k] == 2) p.b.series[k] += done * p.b.sn[k];
@@ -538,11 +540,12 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     }
     int64_t done = 0;
     if (ok && any) {
-      const int rc = alz::launch_tvpc(p.x, p.y, n, ldx, ldy, channels, nb, na, kind, value, series, sld, negated,
+      const int rc = alz::launch_tvpc(p.x, p.y, p.n, ldx, ldy, channels, nb, na, kind, value, series, sld, negated,
                                       xh_dev, yh_dev, (hipStream_t)stream, &done);
       if (rc) { if (prev != device) (void)hipSetDevice(prev); return rc; }
     }
     if (done > 0) {
+      alz::note_kernel("k_tvpc", true);
       p.x += done * p.sxn; p.y += done * p.syn; p.n -= done;
       for (int k = 0; k < alz::kTvMax; ++k) {
         if (p.b.kind[k] == 2) p.b.series[k] += done * p.b.sn[k];
@@ -562,9 +565,12 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
 #undef ALZ_TV_PAT
     hipLaunchKernelGGL(fn, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    alz::note_kernel("k_tv_one<3,3>", true);
   }
-  else if (channels == 1)
+  else if (channels == 1) {
     hipLaunchKernelGGL((alz::k_tv_one<alz::kTvMax, alz::kTvMax>), dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    alz::note_kernel("k_tv_one", true);
+  }
   else if (nb <= 3 && na <= 3) {
     unsigned pb = 0, pa = 0;
     for (int k = 0; k < 3; ++k) pb |= (p.b.kind[k] != 0) << k;
@@ -576,9 +582,12 @@ int alz_tv_process_dev(int nb, const alz_tv_tap_t *b, int na, const alz_tv_tap_t
     ALZ_TV_PAT(1, 2) ALZ_TV_PAT(1, 0) ALZ_TV_PAT(2, 0) ALZ_TV_PAT(3, 0) ALZ_TV_PAT(4, 0) ALZ_TV_PAT(7, 0)
 #undef ALZ_TV_PAT
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+    alz::note_kernel(fn == alz::k_tv<3, 3, 16> ? "k_tv<3,3>" : "k_tvp", true);
   }
-  else
+  else {
     hipLaunchKernelGGL((alz::k_tv<alz::kTvMax, alz::kTvMax, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
+    alz::note_kernel("k_tv", true);
+  }
   hipError_t e = hipGetLastError();
   if (prev != device) (void)hipSetDevice(prev);
   if (e != hipSuccess) return alz::fail(ALZ_E_HIP, std::string("k_tv launch: ") + hipGetErrorString(e));

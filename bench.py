@@ -307,6 +307,10 @@ class Ctx(object):
     self.local_elapsed = []                    # per ctx.timed() call; [0] is the headline workload
     if args.backend == "gloo":
       self.local %= max(torch.cuda.device_count(), 1)   # test mode: ranks may share a GPU
+    elif self.world > torch.cuda.device_count():
+      # RCCL refuses two ranks on one device: an N > device count run cannot produce a valid line
+      sys.exit("bench.py: %d ranks on the nccl (RCCL) backend need %d GPUs, this node shows %d -- refusing "
+               "(use --backend gloo for the shared-GPU test mode)" % (self.world, self.world, torch.cuda.device_count()))
     if self.world > 1 or args.init_dist:
       import torch.distributed as dist
       os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -470,6 +474,9 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
           "C": C, "N": N}
 
 
+_REF_CACHE = {}
+
+
 def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
   torch = ctx.torch
   taps = fir_taps()
@@ -498,6 +505,28 @@ def wl_fir(ctx, args, alz, C, N, steps, warmup, fused):
         parity = "MISMATCH: " + parity
     else:
       parity = "MISMATCH"
+    # ... and the benchmarked EXTENT: the whole block (every run and grid block of k_fir_ring) on 64 strided channels
+    if N > nchk and not parity.startswith("MISMATCH"):
+      bank.reset()
+      bank.process(x, layout="time", out=y)
+      pick = np.unique(np.linspace(0, C - 1, min(C, 64)).astype(int))
+      idx = torch.from_numpy(pick).to(ctx.dev)
+      got = y.index_select(1, idx).cpu().numpy()
+      key = ("fir", C, N)
+      if key not in _REF_CACHE:        # (both modes filter the same seeded block: one oracle run serves them)
+        _REF_CACHE.clear()
+        _REF_CACHE[key] = oracle.bank([256], [1], taps, np.ones(1), x.index_select(1, idx).cpu().numpy(), layout="time")
+      ref = _REF_CACHE[key]
+      if bits_equal(got, ref):
+        parity += "; full extent: %d strided channels x %d samples bit-exact" % (len(pick), N)
+      elif fused:
+        err = norm_err(got, ref, 0)
+        parity += "; full extent (%d strided channels x %d samples): max normalised error %.3g" % (len(pick), N, err)
+        if not err <= 1e-6:
+          parity = "MISMATCH: " + parity
+      else:
+        parity = "MISMATCH on the full extent: " + parity
+      del got
   del x, y, bank
   torch.cuda.empty_cache()
   flops = 511.0 * C * N   # 256 mul + 255 add per output sample (an FMA counts as its two operations)
@@ -568,26 +597,33 @@ def wl_lpc(ctx, args, alz, steps, warmup, fused=False, exact=False, frames=65536
   out = (torch.empty((F, order + 1), dtype=torch.float64, device=ctx.dev), torch.empty((F,), dtype=torch.float64, device=ctx.dev),
          torch.empty((F,), dtype=torch.int32, device=ctx.dev))          # results land in the same tensors every step
   elapsed, k_ms = ctx.timed(lambda: kautocor_frames(sig, L, order, fused=fused, exact=exact, out=out), steps, warmup)
+  kernel = alz.last_kernel()                       # read from the library (alz_last_kernel), not assumed
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
     from oracle import oracle
-    nf = 4096
-    nf = 65536 if (fused or exact) else nf          # (the fused kernel needs >= 16384 frames)
-    coefs, err, status = kautocor_frames(sig[:nf * L].contiguous(), L, order, fused=fused, exact=exact)
-    rc, re, rs = oracle.kautocor_frames(sig[:nf * L].cpu().numpy(), nf, L, L, order)
-    worst = float(np.max(np.abs(coefs.cpu().numpy() - rc) / np.maximum(1.0, np.abs(rc))))
-    ok = worst <= 1e-9 and np.array_equal(status.cpu().numpy(), rs)
-    if exact:
-      ok = bits_equal(coefs.cpu().numpy(), rc) and bits_equal(err.cpu().numpy(), re) and np.array_equal(status.cpu().numpy(), rs)
-      parity = "bit-exact vs oracle: coefficients and error of all %d frames" % nf if ok else "MISMATCH (%.3g)" % worst
+    # frames compared with the oracle: all of a 65 536-frame batch (4096 of them for the default recursion); of a
+    # larger batch every 16th frame ACROSS THE WHOLE BATCH plus the last 4096 (every workgroup range, the chunk
+    # ring's later rounds), taken from the results of the timed launches themselves
+    if F > 65536:
+      frames = np.unique(np.r_[0:F:16, F - 4096:F])
     else:
-      parity = ("%d frames: coefficients within %.1e of the oracle (Levinson is not bit-pinned; contract 1e-6)"
-                % (nf, worst)) if ok else "MISMATCH (%.3g)" % worst
+      frames = np.arange(F if (fused or exact) else min(F, 4096))
+    idx = torch.from_numpy(frames).to(ctx.dev)
+    coefs, err, status = (t.index_select(0, idx).cpu().numpy() for t in out)
+    blk = sig.reshape(F, L).index_select(0, idx).cpu().numpy()
+    rc, re, rs = oracle.kautocor_frames(blk.reshape(-1), len(frames), L, L, order)
+    worst = float(np.max(np.abs(coefs - rc) / np.maximum(1.0, np.abs(rc))))
+    what = "%d frames%s" % (len(frames), " (every 16th of %d + the last 4096)" % F if F > 65536 else "")
+    if exact:
+      ok = bits_equal(coefs, rc) and bits_equal(err, re) and np.array_equal(status, rs)
+      parity = "bit-exact vs oracle: coefficients and error of %s" % what if ok else "MISMATCH (%.3g)" % worst
+    else:
+      ok = worst <= 1e-9 and np.array_equal(status, rs)
+      parity = ("%s: coefficients within %.1e of the oracle (this recursion is not bit-pinned; contract 1e-6)"
+                % (what, worst)) if ok else "MISMATCH (%.3g)" % worst
   del sig
   ctx.torch.cuda.empty_cache()
-  return {"units": float(F), "elapsed": elapsed, "parity": parity,
-          "kernel": ("k_acorr_stage<17,dense> (autocorrelation + the reference's dense Levinson-Durbin in ONE launch)" if exact else
-                     "k_acorr_stage<17,lev%s> (autocorrelation + Levinson-Durbin in one launch)" % (",fma" if fused else "")),
+  return {"units": float(F), "elapsed": elapsed, "parity": parity, "kernel": kernel,
           "roofline": hbm_roof(3984.0 * F, k_ms), "F": F}
 
 
@@ -619,53 +655,56 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
           "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
-def wl_timevar(ctx, args, alz, C, N, steps, warmup, per_channel=False):
-  """A bank steered by control streams: every channel runs the same time-varying
-  resonator, b0[n] x[n] + b2[n] x[n-2] - a1[n] y[n-1] - a2[n] y[n-2], whose coefficient series sweep
-  the centre frequency from 200 Hz to 4 kHz at 48 kHz -- ``resonator.z_exp(Stream(freqs), bw)`` called
-  with vector-valued samples.  One value per tap and sample for the whole bank."""
-  torch = ctx.torch
-  from audiolazy_amd import timevar
+def timevar_bank(torch, dev, C, N, per_channel):
+  """Coefficients of the time-varying resonator bank: b0[n] x[n] + b2 x[n-2] - a1[n] y[n-1] - a2[n] y[n-2] whose series
+  sweep the centre frequency from 200 Hz to 4 kHz at 48 kHz (``resonator.z_exp(Stream(freqs), bw)`` with vector-valued
+  samples).  Shared form: one value per tap and sample for the whole bank ([N] tensors); per-channel form: [N, C] rows
+  (the reference's ``repeat(ndarray)``-style coefficient Streams), channel c detuned by a factor 1 + c / 4 C.
+  Returns (b, a, host copies of the shared series)."""
   n = np.arange(N)
   w = 2 * np.pi * np.geomspace(200., 4000., N) / 48000.
   r = np.exp(-(2 * np.pi * 100. / 48000.) / 2)
   g = (1 - r * r) / 2
   series = {"b0": np.full(N, g) * (1 + 1e-3 * np.sin(n / 997.)), "a1": -2 * r * np.cos(w), "a2": np.full(N, r * r)}
-  dev = {k: torch.from_numpy(v).to(ctx.dev) for k, v in series.items()}
+  d = {k: torch.from_numpy(v).to(dev) for k, v in series.items()}
   if per_channel:
-    # one series per channel and tap ([N, C] rows, the reference's ``repeat(ndarray)``-style coefficient Streams): every
-    # channel sweeps its own centre frequency (channel c is detuned by a factor 1 + c / 4 C)
-    det = 1.0 + torch.arange(C, dtype=torch.float64, device=ctx.dev) / (4.0 * C)
-    wd = dev_w = torch.from_numpy(w).to(ctx.dev)[:, None] * det[None, :]
-    dev = {"b0": dev["b0"][:, None].expand(N, C).contiguous(), "a1": (-2 * r) * torch.cos(wd),
-           "a2": dev["a2"][:, None].expand(N, C).contiguous()}
-    del wd, dev_w
-  b = [dev["b0"], 0., -g]
-  a = [1., dev["a1"], dev["a2"]]
+    det = 1.0 + torch.arange(C, dtype=torch.float64, device=dev) / (4.0 * C)
+    wd = torch.from_numpy(w).to(dev)[:, None] * det[None, :]
+    d = {"b0": d["b0"][:, None].expand(N, C).contiguous(), "a1": (-2 * r) * torch.cos(wd),
+         "a2": d["a2"][:, None].expand(N, C).contiguous()}
+    del wd
+  return [d["b0"], 0., -g], [1., d["a1"], d["a2"]], series
+
+
+def wl_timevar(ctx, args, alz, C, N, steps, warmup, per_channel=False):
+  """A bank steered by control streams: see timevar_bank."""
+  torch = ctx.torch
+  from audiolazy_amd import timevar
+  b, a, _series = timevar_bank(torch, ctx.dev, C, N, per_channel)
   x = ctx.noise((N, C), 5)
   xh = torch.zeros((2, C), dtype=torch.float64, device=ctx.dev)
   yh = torch.zeros((2, C), dtype=torch.float64, device=ctx.dev)
   elapsed, k_ms = ctx.timed(lambda: timevar.process_block(b, a, x, xh=xh, yh=yh), steps, warmup)
+  kernel = alz.last_kernel()                       # read from the library (alz_last_kernel), not assumed
   parity = "skipped (--no-parity-check)"
   if ctx.rank == 0 and not args.no_parity_check:
+    # the WHOLE benchmarked block from a zero state, 64 strided channels against the C restatement alzo_tv_df1
+    # (pinned on reference-generated vectors, tests/test_timevar_cpu.py)
     from oracle import oracle
-    nchk = 4096
-    xs = x[:nchk].contiguous()
-    got = timevar.process_block([dev["b0"][:nchk].contiguous(), 0., -g],
-                                [1., dev["a1"][:nchk].contiguous(), dev["a2"][:nchk].contiguous()], xs).cpu().numpy()
-    xs = xs.cpu().numpy()
-    pick = [0, 1, C // 2, C - 1]
-    col = lambda k, ch: (dev[k][:nchk, ch].cpu().numpy() if per_channel else series[k][:nchk])
-    ok = all(bits_equal(got[:, ch], np.array(oracle.tv_df1([col("b0", ch), 0., -g], [1., col("a1", ch), col("a2", ch)], xs[:, ch])))
-             for ch in pick)
-    parity = ("bit-exact vs the pure-Python restatement, channels %s x %d samples" % (pick, nchk)) if ok else "MISMATCH"
+    y = timevar.process_block(b, a, x)
+    pick = np.unique(np.linspace(0, C - 1, min(C, 64)).astype(int))
+    idx = torch.from_numpy(pick).to(ctx.dev)
+    got, xs = y.index_select(1, idx).cpu().numpy(), x.index_select(1, idx).cpu().numpy()
+    del y
+    host = lambda v: ((v.index_select(1, idx) if v.dim() == 2 else v).cpu().numpy() if hasattr(v, "dim") else v)
+    ref = oracle.tv_bank([host(v) for v in b], [host(v) for v in a], xs, layout="time")
+    parity = ("bit-exact vs oracle (alzo_tv_df1): %d strided channels x %d samples (the whole block)" % (len(pick), N)
+              if bits_equal(got, ref) else "MISMATCH")
   del x
   torch.cuda.empty_cache()
-  if per_channel:    # x + three series read, y written: 40 algorithmic bytes per channel-sample
-    return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvpc (three-wave streaming kernel, per-channel coefficient series)",
-            "parity": parity, "roofline": hbm_roof(40.0 * C * N, k_ms)}
-  return {"units": float(C) * N, "elapsed": elapsed, "kernel": "k_tvduo (streaming kernel: recurrence / feed-forward / store waves, shared coefficient series)",
-          "parity": parity, "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
+  # per-channel series: x + three series read, y written: 40 algorithmic bytes per channel-sample
+  return {"units": float(C) * N, "elapsed": elapsed, "kernel": kernel, "parity": parity,
+          "roofline": hbm_roof((40.0 if per_channel else ALG_BYTES_PER_SAMPLE) * C * N, k_ms)}
 
 
 def wl_collective(ctx, args, C, n):
@@ -711,10 +750,10 @@ def wl_collective(ctx, args, C, n):
       comm.close()
       out["c_abi_direct_rccl"] = {"check": "ok" if ok else "MISMATCH", "calls": "alz_comm_create / alz_comm_gather / alz_comm_sum"}
     except Exception as exc:        # (reported, not fatal: the torch.distributed path above is the one bench.py relies on)
-      out["c_abi_direct_rccl"] = {"check": "ok", "skipped": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+      out["c_abi_direct_rccl"] = {"check": "skipped", "why": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
   del y
   torch.cuda.empty_cache()
-  bad = [k for k, v in out.items() if v["check"] != "ok"]
+  bad = [k for k, v in out.items() if v["check"] not in ("ok", "skipped")]
   return {"workload": "downstream step, outside the filter path: channel mix over ranks as one all_reduce of the per-rank "
                       "sums, and the raw gather of every rank's [%d, %d] float64 shard to rank 0" % (n, C),
           "backend": "%s (%s)" % (args.backend, "RCCL" if args.backend == "nccl" else "CPU tensors, test mode"),
@@ -725,15 +764,22 @@ def wl_collective(ctx, args, C, n):
 _PMC = None
 
 
+PMC_TABLES = ("r04_pmc_traffic_table.json", "r03_pmc_traffic_table.json")     # newest first
+
+
 def fill_traffic(roof, key):
-  """roofline.traffic from the committed per-workload PMC table (profiles/r03_pmc_traffic_table.json), scaled to this
+  """roofline.traffic from the committed per-workload PMC table (profiles/r0N_pmc_traffic_table.json), scaled to this
   launch's algorithmic bytes; labelled as what it is: measured by rocprofv3 in separate runs, not inside this one."""
   global _PMC
   if _PMC is None:
-    try:
-      _PMC = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_table.json")))["workloads"]
-    except (OSError, KeyError, ValueError):
-      _PMC = {}
+    _PMC = {}
+    for name in PMC_TABLES:
+      try:
+        table = json.load(open(os.path.join(ROOT, "profiles", name)))["workloads"]
+      except (OSError, KeyError, ValueError):
+        continue
+      for k, row in table.items():
+        _PMC.setdefault(k, dict(row, table=name))
   row = _PMC.get(key)
   if not row:
     return
@@ -741,9 +787,10 @@ def fill_traffic(roof, key):
   if not alg:
     return
   roof["traffic"] = row["traffic_over_algorithmic"] * alg
+  roof["traffic_ratio"] = row["traffic_over_algorithmic"]
   roof["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
-                            "(profiles/r03_pmc_traffic_table.json, key %r): x%.4f of algorithmic%s"
-                            % (key, row["traffic_over_algorithmic"], "" if row.get("fetch_correction") == 2.0 else
+                            "(profiles/%s, key %r): x%.4f of algorithmic%s"
+                            % (row["table"], key, row["traffic_over_algorithmic"], "" if row.get("fetch_correction") == 2.0 else
                                " (8 B/lane reads: FETCH_SIZE uncalibrated)"))
 
 
@@ -757,6 +804,85 @@ def entry(res, world, steps, unit, workload, key=None):
   return {"workload": workload, "value": world * res["units"] * steps / res["elapsed"] / 1e9, "unit": unit,
           "steps": steps, "ms_per_step": res["elapsed"] / steps * 1e3, "kernel": res["kernel"],
           "parity": res["parity"], "roofline": roof}
+
+
+def short_parity(p):
+  """The parity verdict in a few dozen characters: status + the extents compared (the prose stays in the full record)."""
+  import re
+  p = str(p)
+  if p.startswith("MISMATCH") or p.startswith("skipped"):
+    return p[:100]
+  dims = re.findall(r"\d+(?: strided)? (?:channels|bands|frames)(?: x \d+ (?:input )?streams)?(?: x \d+ samples)?"
+                    r"(?: \(every 16th of \d+ \+ the last 4096\))?", p)
+  dims = [d.replace(" strided", "").replace(" channels", "ch").replace(" bands", "b").replace(" input streams", "s")
+           .replace(" streams", "s").replace(" samples", "").replace(" frames", "fr").replace("every 16th of ", "1/16 of ")
+           .replace(" + the last 4096", "+last 4096").replace(" x ", "x") for d in dims]
+  err = re.findall(r"(?:max normalised error|within) ([0-9.e+-]+)", p)
+  if p.startswith("bit-exact") and not err:
+    status = "bit-exact"
+  elif err:
+    status = "err<=%s (%s)" % (max(err, key=float), "mixed: see full record" if "bit-exact" in p.split(";")[0] and "not bit-exact" not in p
+                               else "opt-in mode" if "by design" in p else "contract 1e-6")
+  else:
+    status = p[:60]
+  return status + (" [" + "; ".join(dims) + "]" if dims else "")
+
+
+# The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
+# the tail of the line still holds configs[2..4].
+SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
+                   "narrow512_time_parallel_three_launch", "envelope_abs", "timevar_shared", "timevar_per_channel",
+                   "gammatone_one_stream", "gammatone_one_stream_time_parallel", "lpc_1m", "lpc_1m_bit_identical",
+                   "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
+
+
+def compact_line(full):
+  """The ONE line bench.py prints: the contract's fields, `roofline`, `cpu_baseline` and a slim `secondary`
+  ({value, unit, ms_per_step, frac, traffic_ratio, parity} per workload) -- under ~6 KB.  Workload prose, kernel names,
+  traffic provenance and the CPU legs' sampling notes are in the full record (--full-json, default
+  gpurun_out/bench_full.json) and in profiles/bench_legend.md."""
+  line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data")}
+  cfg = dict(full["config"])
+  cfg["workload"] = cfg["workload"][:160]
+  if "kernel" in cfg:
+    cfg["kernel"] = cfg["kernel"][:120]
+  line["config"] = cfg
+  roof = full["roofline"]
+  line["roofline"] = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_avg",
+                                           "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "traffic_ratio")
+                      if k in roof}
+  if roof.get("traffic") is not None:
+    line["roofline"]["traffic_source"] = "rocprofv3 --pmc table under profiles/ (separate runs of this workload)"
+  if "cpu_baseline" in full:
+    cpu = full["cpu_baseline"]
+    line["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                            "host_logical_cpus": cpu.get("host_logical_cpus"),
+                            "sample": cpu["sample"][:150],
+                            "legs": {k: round(v["value"], 6) for k, v in cpu.get("legs", {}).items()}}
+  for k in ("per_rank", "process_group"):
+    if k in full:
+      line[k] = full[k]
+  sec = full.get("secondary") or {}
+  if sec:
+    line["legend"] = "profiles/bench_legend.md"
+    keys = [k for k in SECONDARY_ORDER if k in sec] + [k for k in sec if k not in SECONDARY_ORDER]
+    keys.sort(key=lambda k: SECONDARY_ORDER.index(k) if k in SECONDARY_ORDER else -1)
+    slim = {}
+    for k in keys:
+      e = sec[k]
+      if "roofline" not in e:          # the downstream collective: its own small record
+        slim[k] = {"parity": e.get("parity", "")[:60], "ranks": e.get("ranks"), "backend": e.get("backend", "")[:40],
+                   "collectives": {n: {f: (round(v, 4) if isinstance(v, float) else v) for f, v in c.items() if f in ("ms", "GBps_per_rank", "check")}
+                                   for n, c in e.get("collectives", {}).items()}}
+        continue
+      r = e["roofline"]
+      slim[k] = {"value": round(e["value"], 4), "unit": e["unit"], "ms_per_step": round(e["ms_per_step"], 5),
+                 "frac": round(r["frac"], 4), "traffic_ratio": r.get("traffic_ratio"), "parity": short_parity(e["parity"])}
+      if "per_rank_frac" in e:
+        slim[k]["per_rank_frac"] = e["per_rank_frac"]
+    line["secondary"] = slim
+  return line
 
 
 def main():
@@ -790,6 +916,9 @@ def main():
                        "downstream gather / mixdown run on the chosen backend (RCCL on a one-GPU box)")
   ap.add_argument("--launch-check", action="store_true",
                   help="start the ranks, run the protocol's collectives, print one line and exit (no device work)")
+  ap.add_argument("--full-json", default=None,
+                  help="where rank 0 writes the full (verbose) record; default gpurun_out/bench_full.json when that "
+                       "directory can be made, '-' to skip")
   ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
@@ -897,6 +1026,8 @@ def main():
         e = entry(r, 1, 5, "Gsamples/s", "configs[1]'s 4096 channels divided over %d ranks (strong scaling), "
                   "%d channels per GPU" % (world, hi - lo))
         e["value"] = float(C) * N * 5 / r["elapsed"] / 1e9
+        # every rank's own roofline fraction on its shard, next to the whole-job figure
+        e["per_rank_frac"] = [round(row[0], 4) for row in ctx.all_ranks([r["roofline"]["frac"]])]
         secondary["strong_scaling"] = e
   elif args.workload == "fir":
     if (C, N) == (4096, 1 << 20):   # configs[2] defaults
@@ -971,11 +1102,21 @@ def main():
       out["per_rank"] = per_rank
       out["process_group"] = {"backend": args.backend, "ranks": world,
                               "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "none (--init-dist)"}
-    if secondary:
-      out["secondary"] = secondary
     if cpu is not None:
       out["cpu_baseline"] = cpu
-    print(json.dumps(out))
+    if secondary:
+      out["secondary"] = secondary
+    full_path = args.full_json
+    if full_path is None:
+      full_path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    if full_path != "-":
+      try:
+        os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+        with open(full_path, "w") as f:
+          json.dump(out, f, indent=1)
+      except OSError:
+        pass
+    print(json.dumps(compact_line(out)))
     checks = [config.get("parity_spot_check") or ""] + [e["parity"] for e in secondary.values()]
     bad = any(str(c).startswith("MISMATCH") for c in checks)
     if bad:

@@ -59,6 +59,10 @@ typedef struct alz_bank alz_bank_t;
 /* ---- library / device ---------------------------------------------------- */
 int alz_version(void);
 const char *alz_last_error(void);
+/* Name of the kernel(s) the last handle-less call of this thread launched (alz_lpc_kautocor_dev*, alz_acorr_dev,
+ * alz_levinson_dev*, alz_tv_process_dev): a diagnostic like alz_bank_last_kernel; bench.py and the tests read the
+ * kernel names from here instead of assuming them. */
+const char *alz_last_kernel(void);
 int alz_device_count(int *count);
 /* device memory helpers so a caller needs no other HIP binding */
 int alz_malloc(int device, uint64_t bytes, void **dev_ptr);

@@ -233,3 +233,57 @@ void alzo_kautocor_frames(const double *sig, int64_t F, int64_t len, int64_t hop
     status[f] = alzo_kautocor(sig + f * hop, len, order,
                               coefs + f * (order + 1), err + f);
 }
+
+/*
+ * Time-varying coefficients (lazy_filters.py:197-257 with iterable coefficients, :202-204, :214-216): one channel,
+ * Direct Form I, the same term order as alzo_df1.  Every tap is one of
+ *   kind 0  absent (a constant that equals 0: no term, :209, :223)
+ *   kind 1  a constant: value * d_k, or (-value) * m_k                      (:210, :224)
+ *   kind 2  a series: next(b_k) * d_k, or -next(a_k) * m_k -- WHATEVER its values (a series zero still makes a term);
+ *           the value for sample n is ser[n * stride]; neg != 0 says the series already holds -a_k
+ * a[0] is a constant (the reference divides a series gain out first, :166-174): gain.  xh / yh as in alzo_df1
+ * (updated in place).  float64 series only: the unary minus of an INTEGER 0 (+0) is not restated here
+ * (oracle.tv_df1, the pure-Python form, keeps that).  Returns 0, -1 for a zero gain.
+ */
+int alzo_tv_df1(int nb, int na, const int *bkind, const double *bval, const double *const *bser,
+                const int64_t *bstride, const int *akind, const double *aval, const double *const *aser,
+                const int64_t *astride, const int *aneg, double gain,
+                const double *x, int64_t sx, double *y, int64_t sy, int64_t n,
+                double *xh, double *yh, double zero)
+{
+  if (gain == 0.0) return -1;
+  int nterms = 0;
+  for (int k = 0; k < nb; ++k) nterms += (bkind[k] != 0);
+  for (int k = 1; k < na; ++k) nterms += (akind[k] != 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const double d0 = x[i * sx];
+    double acc = 0.0;
+    int first = 1;
+    for (int k = 0; k < nb; ++k) {
+      if (bkind[k] == 0) continue;
+      const double c = bkind[k] == 2 ? bser[k][i * bstride[k]] : bval[k];
+      const double d = (k == 0) ? d0 : xh[k - 1];
+      const double t = c * d;
+      if (first) { acc = t; first = 0; } else acc = acc + t;
+    }
+    for (int k = 1; k < na; ++k) {
+      if (akind[k] == 0) continue;
+      double c;
+      if (akind[k] == 2) { c = aser[k][i * astride[k]]; if (!aneg[k]) c = -c; }
+      else c = -aval[k];
+      const double t = c * yh[k - 1];
+      if (first) { acc = t; first = 0; } else acc = acc + t;
+    }
+    double m0;
+    if (nterms == 0) m0 = zero;
+    else if (gain == 1.0) m0 = acc;
+    else if (gain == -1.0) m0 = -acc;
+    else m0 = acc / gain;
+    y[i * sy] = m0;
+    for (int k = na - 2; k > 0; --k) yh[k] = yh[k - 1];
+    if (na > 1) yh[0] = m0;
+    for (int k = nb - 2; k > 0; --k) xh[k] = xh[k - 1];
+    if (nb > 1) xh[0] = d0;
+  }
+  return 0;
+}

@@ -95,3 +95,32 @@ def test_cpu_baseline_falls_back_to_the_port_without_the_reference(monkeypatch):
   cpu = bench.cpu_baseline(b, a, budget_s=0.2)
   assert cpu["kind"] == "port" and "restated" in cpu["sample"]
   monkeypatch.setattr(bench, "_REF", None)
+
+
+def test_compact_line_fits_a_truncating_record_and_ends_with_the_baseline_configs():
+  """The line bench.py prints must survive a driver that keeps ~6 KB of it (round-3 review: the 14 KB line lost
+  configs[2..4]).  Input: the committed full record of the round-3 driver command; checked: size, the contract's
+  keys, the slim secondary fields, and that the BASELINE configs are the LAST entries."""
+  import json
+  import bench
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  full = json.load(open(os.path.join(root, "profiles", "r03_bench_full.json")))
+  line = bench.compact_line(full)
+  text = json.dumps(line)
+  assert len(text) < 6144, len(text)
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "secondary"):
+    assert key in line, key
+  assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+  assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+  sec = line["secondary"]
+  assert set(sec) == set(full["secondary"])
+  for k, e in sec.items():
+    assert set(e) == {"value", "unit", "ms_per_step", "frac", "traffic_ratio", "parity"}, k
+    assert len(e["parity"]) <= 100 and e["parity"].split()[0] in ("bit-exact", "err<=1e-06", "MISMATCH") or e["parity"].startswith("err<="), e
+  assert list(sec)[-5:] == ["fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical"]
+  assert text.index('"secondary"') > text.index('"cpu_baseline"')      # the secondaries close the line
+  # statuses survive the shortening
+  assert bench.short_parity("MISMATCH on the full extent: x").startswith("MISMATCH")
+  assert bench.short_parity("bit-exact vs oracle, 8192 channels x 512 samples; full extent: 64 strided channels x 262144 "
+                            "samples bit-exact") == "bit-exact [8192chx512; 64chx262144]"

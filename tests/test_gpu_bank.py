@@ -567,8 +567,9 @@ def test_fir_narrow_and_long(alz, oracle):
   x = rng.uniform(-1, 1, (n, C))
   bank = alz.FilterBank([(b, a)], n_inputs=C)
   y = bank.process(torch.from_numpy(x).cuda(), layout="time").cpu().numpy()
-  pick = np.r_[0:2000, n // 2:n // 2 + 2000, n - 2000:n]
-  ref = oracle.bank([nb], [1], b, a, x[:n // 2 + 2000], layout="time")
-  assert np.array_equal(y[:2000], ref[:2000])
-  assert np.array_equal(y[n // 2:n // 2 + 2000], ref[n // 2:n // 2 + 2000])
-  assert np.isfinite(y[pick]).all() and "k_fir" in bank.last_kernel, bank.last_kernel
+  assert "k_fir" in bank.last_kernel, bank.last_kernel
+  # the WHOLE block, head to tail, bit for bit (round-3 review: the tail was only checked for finiteness)
+  ref = oracle.bank([nb], [1], b, a, x, layout="time")
+  assert y.shape == ref.shape
+  same = y.view(np.uint64) == ref.view(np.uint64)
+  assert same.all(), "first differing row %d of %d" % (int(np.argmin(same.all(axis=1))), n)

@@ -258,3 +258,77 @@ def test_cfg4_pipeline_full_block_length_on_strided_channels(alz, oracle):
     rows_x.append(xs[ch % S])
   ref = oracle.bank([2] * 4, [3] * 4, np.array(rows_b), np.array(rows_a), np.array(rows_x), layout="chan")
   assert same_bits(got, ref)
+
+
+# ---- the benchmarked EXTENTS of configs[2], configs[4] and the time-varying banks (round-3 verdict, weak #2) ----------
+@pytest.mark.parametrize("fused", [False, True])
+def test_cfg3_fir256_full_extent_on_strided_channels(alz, oracle, bench, fused):
+  """configs[2] at its real extent: 8192 channels x 2^18 samples through k_fir_ring (all 683 runs a block is cut into,
+  every y-grid block), 64 strided channels against the C oracle over the WHOLE block: bit for bit in the default
+  mode, <= 1e-12 normalised in the opt-in FMA mode."""
+  import torch
+  C, N = 8192, 1 << 18
+  taps = bench.fir_taps()
+  x = _gpu_noise((N, C), 12)
+  bank = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C)
+  if fused:
+    bank.set_fused(True)
+  bank.reset()
+  y = bank.process(x, layout="time")
+  assert "k_fir_ring" in bank.last_kernel and (("fma" in bank.last_kernel) == fused), bank.last_kernel
+  pick = np.linspace(0, C - 1, 64).astype(int)
+  idx = torch.from_numpy(pick).cuda()
+  got, xs = y.index_select(1, idx).cpu().numpy(), x.index_select(1, idx).cpu().numpy()
+  del x, y
+  torch.cuda.empty_cache()
+  ref = oracle.bank([256], [1], taps, np.ones(1), xs, layout="time")
+  if fused:
+    assert norm_err(got, ref, 0) <= 1e-12
+  else:
+    assert same_bits(got, ref)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_cfg5_lpc_two_to_the_twenty_frames(alz, oracle, exact):
+  """configs[4] as the 2^20-frame batch the bench reports (16 384 workgroups, the two-slot ring's later rounds): every
+  16th frame across the whole batch plus the last 4 096, against the oracle -- bit for bit for the dense form,
+  1e-9 for the default recursion; the autocorrelation-only path is covered by the 65 536-frame test."""
+  import torch
+  from audiolazy_amd.lpc import kautocor_frames
+  F, L, order = 1 << 20, 480, 16
+  sig = _gpu_noise((F * L,), 13)
+  coefs, err, status = kautocor_frames(sig, L, order, exact=exact)
+  assert "k_acorr_stage<17" in alz.last_kernel() and (("dense" in alz.last_kernel()) == exact), alz.last_kernel()
+  frames = np.unique(np.r_[0:F:16, F - 4096:F])
+  idx = torch.from_numpy(frames).cuda()
+  c, e, st = coefs.index_select(0, idx).cpu().numpy(), err.index_select(0, idx).cpu().numpy(), status.index_select(0, idx).cpu().numpy()
+  blk = sig.reshape(F, L).index_select(0, idx).cpu().numpy()
+  del sig
+  torch.cuda.empty_cache()
+  rc, re, rs = oracle.kautocor_frames(blk.reshape(-1), len(frames), L, L, order)
+  assert np.array_equal(st, rs) and not st.any()
+  if exact:
+    assert same_bits(c, rc) and same_bits(e, re)
+  else:
+    scale = np.abs(rc).max(axis=1, keepdims=True)
+    assert (np.abs(c - rc) / scale).max() <= 1e-9 and (np.abs(e - re) / np.abs(re)).max() <= 1e-9
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_timevar_bank_full_extent_on_strided_channels(alz, oracle, bench, per_channel):
+  """The time-varying resonator banks at the benchmarked shape, 4096 channels x 2^18 samples: k_tvduo (series shared by
+  the bank) and k_tvpc (a series per channel) against the C restatement alzo_tv_df1 (pinned on the reference's
+  vectors, tests/test_timevar_cpu.py) on 64 strided channels over the WHOLE block, bit for bit."""
+  import torch
+  from audiolazy_amd import timevar
+  C, N = 4096, 1 << 18
+  b, a, series = bench.timevar_bank(torch, torch.device("cuda"), C, N, per_channel)
+  x = _gpu_noise((N, C), 14)
+  y = timevar.process_block(b, a, x)
+  assert ("k_tvpc" if per_channel else "k_tvduo") in alz.last_kernel(), alz.last_kernel()
+  pick = np.linspace(0, C - 1, 64).astype(int)
+  idx = torch.from_numpy(pick).cuda()
+  got, xs = y.index_select(1, idx).cpu().numpy(), x.index_select(1, idx).cpu().numpy()
+  host = lambda v: (v.index_select(1, idx) if v.dim() == 2 else v).cpu().numpy() if hasattr(v, "dim") else v
+  ref = oracle.tv_bank([host(v) for v in b], [host(v) for v in a], xs, layout="time")
+  assert same_bits(got, ref)

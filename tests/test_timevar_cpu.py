@@ -74,3 +74,56 @@ def test_lti_filters_stay_lti():
   tv = al.ZFilter([al.Stream([.1, .2])], [1., .5])
   assert not tv.is_lti()
   assert not al.CascadeFilter(al.lowpass.pole(.1), tv).is_lti()
+
+
+def as_arrays(coefs_):
+  return [np.asarray(v, dtype=np.float64) if isinstance(v, list) else v for v in coefs_]
+
+
+@pytest.mark.parametrize("idx", range(8))
+def test_c_oracle_direct_stream_coefficients(idx):
+  """alzo_tv_df1 (oracle/alz_oracle.c, what the full-extent GPU comparisons use) pinned on the same
+  reference-generated vectors as the pure-Python form."""
+  g = load_golden("timevar.json")
+  c = g["direct"][idx]
+  b, a = normalised(coefs(c["b"]), coefs(c["a"]))
+  memory = None if c["memory"] is None else unhex(c["memory"])
+  y = oracle.tv_df1_c(as_arrays(b), as_arrays(a), unhex(g["x"]), memory=memory, zero=float.fromhex(c["zero"]))
+  assert same_bits(y, unhex(c["y"]))
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_c_oracle_designs_on_streams(idx):
+  g = load_golden("timevar.json")
+  c = g["designs"][idx]
+  assert same_bits(oracle.tv_df1_c(as_arrays(coefs(c["b"])), as_arrays(coefs(c["a"])), unhex(g["x"])), unhex(c["y"]))
+
+
+def test_c_oracle_equals_the_python_form_on_random_banks():
+  """Shared and per-channel series, every tap pattern of a biquad, gains, memory and zero: the C form against
+  oracle.tv_df1 (itself pinned on the reference's vectors) on every channel."""
+  rng = np.random.default_rng(77)
+  N, C = 300, 5
+  for trial in range(40):
+    x = rng.uniform(-1, 1, (N, C))
+    def tap(allow_zero=True):
+      r = rng.integers(0, 4)
+      if r == 0 and allow_zero:
+        return 0.
+      if r == 1:
+        return float(rng.uniform(-.9, .9))
+      if r == 2:
+        return rng.uniform(-.9, .9, N)
+      return rng.uniform(-.9, .9, (N, C))
+    b = [tap() for _ in range(rng.integers(1, 4))]
+    a = [float(rng.choice([1., -1., 2., .5]))] + [tap() for _ in range(rng.integers(0, 3))]
+    zero = float(rng.choice([0., .25]))
+    memory = None if rng.random() < .5 else rng.uniform(-1, 1, len(a) - 1).tolist()
+    layout = "time" if trial % 2 == 0 else "chan"
+    xin = x if layout == "time" else np.ascontiguousarray(x.T)
+    got = oracle.tv_bank(b, a, xin, layout=layout, memory=memory, zero=zero)
+    for c in range(C):
+      bc = [v[:, c] if isinstance(v, np.ndarray) and v.ndim == 2 else v for v in b]
+      ac = [v[:, c] if isinstance(v, np.ndarray) and v.ndim == 2 else v for v in a]
+      ref = oracle.tv_df1(bc, ac, x[:, c], memory=memory, zero=zero)
+      assert same_bits(got[:, c], ref), (trial, c)
