@@ -169,9 +169,212 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
 // them all (four waves x 8 KiB at ~64 B/clk) behind the last recurrence step.  Same operations in the
 // same order as section_chunk: identical doubles.
 // `pre(j)` runs at the head of group j (k_pipe: the LDS read of piece j of the NEXT tile).
-template <int NB, unsigned PB, unsigned PA, bool FMA, typename Emit, typename Pre>
+#ifndef ALZ_PIPE_ILV
+#define ALZ_PIPE_ILV 1
+#endif
+#ifndef ALZ_PIPE_PHASE
+#define ALZ_PIPE_PHASE 1
+#endif
+constexpr int c_popcount(unsigned v) { int n = 0; for (int k = 0; k < 8; ++k) n += (v >> k) & 1u; return n; }
+constexpr int c_kth_tap(unsigned pb, int n) {      // delay of the n-th present tap
+  for (int k = 0; k < 8; ++k)
+    if ((pb >> k) & 1u) { if (n == 0) return k; --n; }
+  return 0;
+}
+// The feed-forward sum of ONE sample as a sequence of single operations (ff_ops of them), so that they can be dealt
+// out one at a time between the operations of the recurrence:  op 0: acc = b_k0 x;  then per further tap
+// t = b_k x; acc = acc + t  (FMA: acc = fma(b_k, x, acc)) -- the same operations in the same order as section_chunk.
+template <unsigned PB, bool FMA>
+struct FfSeq {
+  static constexpr int terms = c_popcount(PB);
+  static constexpr int ops = terms == 0 ? 0 : (FMA ? terms : 2 * terms - 1);
+};
+template <unsigned PB, bool FMA, int I>
+__device__ __forceinline__ void ff_op(int u, const double (&v)[16], const double (&bc)[8], const double (&dx)[7],
+                                      double &acc, double &tmp) {
+  constexpr int term = FMA ? I : (I + 1) / 2;
+  constexpr int k = c_kth_tap(PB, term);
+  constexpr bool is_mul = FMA ? true : (I == 0 || (I & 1));
+  if constexpr (is_mul) {
+    const double xv = (u - k >= 0) ? v[u - k < 0 ? 0 : u - k] : dx[k - u - 1 < 0 ? 0 : (k - u - 1 > 6 ? 6 : k - u - 1)];
+    if constexpr (I == 0) acc = bc[k] * xv;
+    else if constexpr (FMA) acc = __builtin_fma(bc[k], xv, acc);
+    else tmp = bc[k] * xv;
+  } else {
+    acc = acc + tmp;
+  }
+}
+
+// The same section over a 16-sample tile, handing every finished pair of outputs (2j, 2j + 1) to
+// `emit` as soon as it exists.  Group j = {recurrence of pair j with the feed-forward operations of pair j + 1
+// dealt out BETWEEN its dependent operations, emit(j)}: a lone in-order wave issues an FP64 operation every ~4.5
+// cycles but can use a result only ~7.5 - 9 cycles after its producer, so a recurrence whose three dependent
+// operations per sample follow each other directly waits ~4 cycles at each of them while the six feed-forward
+// operations of the pair, all issued before it (what the compiler's scheduler does with the plain loop: round 3,
+// ~40 cycles per sample), fill nothing.  One independent operation after every dependent one and the pair costs its
+// issue time, 14 x 4.5 cycles.  The order is pinned with sched_barrier between the single operations.
+// k_pipe's stage waves use `emit` / `pre` to spread the LDS writes of the hand-over (and the reads of the NEXT tile,
+// `pre(j)` at the head of group j) through the arithmetic of the interval.  Same operations in the same order per
+// sample as section_chunk: identical doubles.
+//
+// PH (0..3, k_pipe passes the stage index): WHERE in a group the hand-over's two LDS operations are issued -- the
+// write of the pair finished in the previous group and the read of piece j of the next tile.  The four stage waves of
+// a workgroup leave every barrier together and run the same instruction mix, so with the LDS operations at the same
+// place in every wave all four requests (4 x (13 + 4) cycles of the CU's one LDS pipe) arrive at once, the waves
+// stand in its queue, and then the pipe idles while all four compute: the interval was the SUM of arithmetic and
+// hand-over (profiles/NOTES_r02.md 12).  Issued a quarter of a group apart, the requests of the four waves interleave.
+#if ALZ_PIPE_ILV
+// The core: `hook(j)` is called once in group j, at the place PH selects; o[0 .. 2j - 1] are final by then (the caller
+// owns o and decides what is written or read when).
+template <int NB, unsigned PB, unsigned PA, bool FMA, int PH, typename Hook>
+__device__ __forceinline__ void section_tile_hook(const double (&v)[16], const double (&bc)[8], double na1, double na2,
+                                                  double (&dx)[7], double &m1, double &m2, double (&o)[16], Hook hook) {
+  double p[16];
+  using Seq = FfSeq<PB, FMA>;
+  constexpr int NF = Seq::ops;                       // feed-forward operations per sample
+  double tmpa = 0.0, tmpb = 0.0;
+#define ALZ_PIN() __builtin_amdgcn_sched_barrier(0)
+  // feed-forward operation number F of the PAIR (u, u + 1): sample u's and sample u + 1's operations alternate
+  auto ffp = [&](auto FI, int u) {
+    constexpr int F = decltype(FI)::value;
+    if constexpr (F < 2 * NF) {
+      if constexpr ((F & 1) == 0) ff_op<PB, FMA, F / 2>(u, v, bc, dx, p[u], tmpa);
+      else ff_op<PB, FMA, F / 2>(u + 1, v, bc, dx, p[u + 1], tmpb);
+      ALZ_PIN();
+    }
+  };
+#define ALZ_FF(F, u) ffp(std::integral_constant<int, (F)>{}, (u))
+  // pair 0's feed-forward sums, before the first group
+  {
+    ALZ_FF(0, 0); ALZ_FF(1, 0); ALZ_FF(2, 0); ALZ_FF(3, 0); ALZ_FF(4, 0); ALZ_FF(5, 0); ALZ_FF(6, 0); ALZ_FF(7, 0);
+    ALZ_FF(8, 0); ALZ_FF(9, 0); ALZ_FF(10, 0); ALZ_FF(11, 0); ALZ_FF(12, 0); ALZ_FF(13, 0); ALZ_FF(14, 0); ALZ_FF(15, 0);
+    ALZ_FF(16, 0); ALZ_FF(17, 0); ALZ_FF(18, 0); ALZ_FF(19, 0); ALZ_FF(20, 0); ALZ_FF(21, 0); ALZ_FF(22, 0); ALZ_FF(23, 0);
+    ALZ_FF(24, 0); ALZ_FF(25, 0);
+  }
+  static_assert(2 * NF <= 26, "at most seven taps per section");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // the hand-over's LDS operations of this group, at the place PH selects
+    auto lds_ops = [&](int slot) {
+      if (slot == (ALZ_PIPE_PHASE ? PH : 0)) {
+        hook(j);
+        ALZ_PIN();
+      }
+    };
+    lds_ops(0);
+    const int un = 2 * j + 2;                        // the pair whose feed-forward sums ride in this group
+    const bool more = j + 1 < 8;
+    if constexpr (PB != 0u && PA == 3u && !FMA) {
+      // sample 2j:  t1 = na1 m1 | F | a = p + t1 | t2 = na2 m2 | F | o = a + t2      (| = pinned order)
+      double t1 = na1 * m1; ALZ_PIN();
+      if (more) ALZ_FF(0, un);
+      double a = p[2 * j] + t1; ALZ_PIN();
+      double t2 = na2 * m2; ALZ_PIN();
+      lds_ops(1);
+      if (more) ALZ_FF(1, un);
+      const double o0 = a + t2; ALZ_PIN();
+      if (more) ALZ_FF(2, un);
+      lds_ops(2);
+      // sample 2j + 1
+      t1 = na1 * o0; ALZ_PIN();
+      if (more) ALZ_FF(3, un);
+      a = p[2 * j + 1] + t1; ALZ_PIN();
+      t2 = na2 * m1; ALZ_PIN();
+      lds_ops(3);
+      if (more) ALZ_FF(4, un);
+      const double o1 = a + t2; ALZ_PIN();
+      if (more) ALZ_FF(5, un);
+      o[2 * j] = o0; o[2 * j + 1] = o1;
+      m2 = o0; m1 = o1;
+      if (more) {                                    // (sections with more than two taps: the rest of the pair's sums)
+        ALZ_FF(6, un); ALZ_FF(7, un); ALZ_FF(8, un); ALZ_FF(9, un); ALZ_FF(10, un); ALZ_FF(11, un); ALZ_FF(12, un);
+        ALZ_FF(13, un); ALZ_FF(14, un); ALZ_FF(15, un); ALZ_FF(16, un); ALZ_FF(17, un); ALZ_FF(18, un); ALZ_FF(19, un);
+        ALZ_FF(20, un); ALZ_FF(21, un); ALZ_FF(22, un); ALZ_FF(23, un); ALZ_FF(24, un); ALZ_FF(25, un);
+      }
+    } else if constexpr (PB != 0u && PA == 3u && FMA) {
+      // FMA mode: two dependent operations per sample, one of the next pair's sums after each
+      double a = __builtin_fma(na1, m1, p[2 * j]); ALZ_PIN();
+      lds_ops(1);
+      if (more) ALZ_FF(0, un);
+      const double o0 = __builtin_fma(na2, m2, a); ALZ_PIN();
+      if (more) ALZ_FF(1, un);
+      lds_ops(2);
+      a = __builtin_fma(na1, o0, p[2 * j + 1]); ALZ_PIN();
+      if (more) ALZ_FF(2, un);
+      lds_ops(3);
+      const double o1 = __builtin_fma(na2, m1, a); ALZ_PIN();
+      if (more) ALZ_FF(3, un);
+      o[2 * j] = o0; o[2 * j + 1] = o1;
+      m2 = o0; m1 = o1;
+      if (more) {
+        ALZ_FF(4, un); ALZ_FF(5, un); ALZ_FF(6, un); ALZ_FF(7, un); ALZ_FF(8, un); ALZ_FF(9, un); ALZ_FF(10, un);
+        ALZ_FF(11, un); ALZ_FF(12, un); ALZ_FF(13, un);
+      }
+    } else {
+      // other shapes (one-pole sections, sections without a numerator): the recurrence as written, the next pair's
+      // sums dealt between its two samples
+#pragma unroll
+      for (int u = 2 * j; u < 2 * j + 2; ++u) {
+        double acc = p[u];
+        if constexpr (PB != 0u) {
+          if constexpr (PA & 1u) acc = FMA ? __builtin_fma(na1, m1, acc) : acc + na1 * m1;
+          if constexpr (PA & 2u) acc = FMA ? __builtin_fma(na2, m2, acc) : acc + na2 * m2;
+        } else {
+          bool first = true;
+          if constexpr (PA & 1u) { acc = na1 * m1; first = false; }
+          if constexpr (PA & 2u) { const double t = na2 * m2; acc = first ? t : acc + t; }
+        }
+        o[u] = acc;
+        m2 = m1;
+        m1 = acc;
+        ALZ_PIN();
+        if (more && u == 2 * j) {
+          lds_ops(1);
+          ALZ_FF(0, un); ALZ_FF(1, un); ALZ_FF(2, un); ALZ_FF(3, un); ALZ_FF(4, un); ALZ_FF(5, un); ALZ_FF(6, un);
+          lds_ops(2);
+          ALZ_FF(7, un); ALZ_FF(8, un); ALZ_FF(9, un); ALZ_FF(10, un); ALZ_FF(11, un); ALZ_FF(12, un);
+        } else if (more) {
+          lds_ops(3);
+          ALZ_FF(13, un); ALZ_FF(14, un); ALZ_FF(15, un); ALZ_FF(16, un); ALZ_FF(17, un); ALZ_FF(18, un); ALZ_FF(19, un);
+          ALZ_FF(20, un); ALZ_FF(21, un); ALZ_FF(22, un); ALZ_FF(23, un); ALZ_FF(24, un); ALZ_FF(25, un);
+        } else if (u == 2 * j) {
+          lds_ops(1);
+          lds_ops(2);
+        } else {
+          lds_ops(3);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef ALZ_FF
+#undef ALZ_PIN
+  double ndx[7];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) ndx[k] = (15 - k >= 0) ? v[15 - k < 0 ? 0 : 15 - k] : dx[k - 16 < 0 ? 0 : k - 16];
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k) dx[k] = ndx[k];
+}
+#endif
+
+template <int NB, unsigned PB, unsigned PA, bool FMA, int PH = 0, typename Emit, typename Pre>
 __device__ __forceinline__ void section_tile_emit(const double (&v)[16], const double (&bc)[8], double na1, double na2,
                                                   double (&dx)[7], double &m1, double &m2, Emit emit, Pre pre) {
+#if ALZ_PIPE_ILV
+  // (the FMA mode keeps the compiler's own order inside a group: four operations per sample with two dependent ones
+  // leave it nothing to gain from the pinned order -- measured 511 - 516 pinned against 533 Gsamples/s, NOTES_r04.md 3)
+  if constexpr (!FMA) {
+    // group j: the write of the pair finished in group j - 1, the read of piece j of the next tile; the last pair after the loop
+    double o[16];
+    section_tile_hook<NB, PB, PA, FMA, PH>(v, bc, na1, na2, dx, m1, m2, o, [&](int j) {
+      if (j > 0) emit(j - 1, o[2 * j - 2], o[2 * j - 1]);
+      pre(j);
+    });
+    emit(7, o[14], o[15]);
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
+#endif
   double p[16], o[16];
   auto ff = [&](int u) {
     double acc = 0.0;
@@ -502,7 +705,20 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // only 256 workgroups wide at G = 64 (cfg4: 256 bands x 64 streams) then has two workgroups per CU
 // whose barrier intervals drift apart: one's section arithmetic runs while the other hands tiles over.
 // timing ablations (-DALZ_ABLATE builds only; wrong results): bit 8 = no barriers, bit 16 = no LDS drain before them
+#if defined(ALZ_ABLATE) && defined(ALZ_PIPE_TIMING)
+// per-wave cycle accounting (variant builds only; a clock read also waits for the wave's outstanding LDS operations, so
+// "work" includes the drain): work = barrier exit -> barrier entry, wait = inside the barrier; the wave that waits
+// least is the one the interval waits for
+#define PIPE_CLOCK_DECL long long pc_work = 0, pc_wait = 0, pc_last = __builtin_readcyclecounter(); long long pc_n = 0;
+#define PIPE_BARRIER() do { const long long c0_ = __builtin_readcyclecounter(); if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier(); \
+    const long long c1_ = __builtin_readcyclecounter(); pc_work += c0_ - pc_last; pc_wait += c1_ - c0_; pc_last = c1_; ++pc_n; } while (0)
+#define PIPE_CLOCK_REPORT() do { if (blockIdx.x == 5 && lane == 0) printf("k_pipe wave %d: %.1f cycles of work + %.1f in the barrier per interval (%lld intervals)\n", \
+    wave, (double)pc_work / (double)pc_n, (double)pc_wait / (double)pc_n, pc_n); } while (0)
+#else
+#define PIPE_CLOCK_DECL
+#define PIPE_CLOCK_REPORT() do {} while (0)
 #define PIPE_BARRIER() do { if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier(); } while (0)
+#endif
 // (the builtin, not inline asm: the compiler's own wait-count pass then knows that the LDS reads of this
 // interval have landed and does not guard next interval's arithmetic with waits of its own)
 #ifndef ALZ_PIPE_DRAINB
@@ -517,6 +733,7 @@ template <bool CM, int SPW, int G, unsigned PB0, unsigned PA0, unsigned PB1, uns
           unsigned PA2, unsigned PB3, unsigned PA3, bool FMA = false>
 __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CArgs p) {   // (second figure: waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  PIPE_CLOCK_DECL
   constexpr int T = 16, NW = 4 / SPW;
   constexpr int NCHK = G / 8;                    // 1 KiB DMA / store chunks per tile
   constexpr int kSlot = G * 128 + NCHK * 16;     // tile + 16 bytes of pad per chunk
@@ -726,15 +943,17 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
         if (wave == NW - 1) {
           if (DIRECT_OUT) {
             double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
-            section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+            section_tile_emit<nb_of(PB3), PB3, PA3, FMA, 3>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
                 [&](int j, double a, double b) {
+                  if (ALZ_DBG(p, 32)) return;
                   __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
                   __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
                 }, [](int) {});
           } else {
             char *dst = yring + (int)(tile % 2) * kSlot + lane_off;
-            section_tile_emit<nb_of(PB3), PB3, PA3, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+            section_tile_emit<nb_of(PB3), PB3, PA3, FMA, 3>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
                 [&](int j, double a, double b) {
+                  if (ALZ_DBG(p, 32)) return;
                   if constexpr (CM) {
                     cdbl2 w;
                     w.x = a;
@@ -749,14 +968,15 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
         } else {
           char *dst = qring + (wave * 2 + (int)(tile % 2)) * kSlot + cl * 16;
           auto emit = [&](int j, double a, double b) {
+            if (ALZ_DBG(p, 32)) return;
             cdbl2 w;
             w.x = a;
             w.y = b;
             *reinterpret_cast<cdbl2 *>(dst + j * kPiece) = w;
           };
-          if (wave == 0) section_tile_emit<nb_of(PB0), PB0, PA0, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
-          else if (wave == 1) section_tile_emit<nb_of(PB1), PB1, PA1, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
-          else section_tile_emit<nb_of(PB2), PB2, PA2, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+          if (wave == 0) section_tile_emit<nb_of(PB0), PB0, PA0, FMA, 0>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+          else if (wave == 1) section_tile_emit<nb_of(PB1), PB1, PA1, FMA, 1>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
+          else section_tile_emit<nb_of(PB2), PB2, PA2, FMA, 2>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0], emit, [](int) {});
         }
       } else {
         do_sections(v);
@@ -774,21 +994,24 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       constexpr unsigned paS = S == 1 ? PA1 : S == 2 ? PA2 : PA3;
       const char *src = qring + ((S - 1) * 2 + (int)(pf_tile & 1)) * kSlot + cl * 16;
       auto pre = [&](int j) {
+        if (ALZ_DBG(p, 64)) return;                       // (timing ablation: the tile's values are whatever is there)
         const cdbl2 w = *reinterpret_cast<const cdbl2 *>(src + j * kPiece);
         nxt[2 * j] = w.x;
         nxt[2 * j + 1] = w.y;
       };
       if constexpr (S == NW - 1 && DIRECT_OUT) {
         double *dst = p.y + (tile * T) * p.ldy + c0 + lane;
-        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA, S>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
             [&](int j, double a, double b) {
+              if (ALZ_DBG(p, 32)) return;
               __builtin_nontemporal_store(a, dst + (2 * j) * p.ldy);
               __builtin_nontemporal_store(b, dst + (2 * j + 1) * p.ldy);
             }, pre);
       } else if constexpr (S == NW - 1) {
         char *dst = yring + (int)(tile & 1) * kSlot + lane_off;
-        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA, S>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
             [&](int j, double a, double b) {
+              if (ALZ_DBG(p, 32)) return;
               if constexpr (CM) {
                 cdbl2 w;
                 w.x = a;
@@ -801,8 +1024,9 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
             }, pre);
       } else {
         char *dst = qring + (S * 2 + (int)(tile & 1)) * kSlot + cl * 16;
-        section_tile_emit<nb_of(pbS), pbS, paS, FMA>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
+        section_tile_emit<nb_of(pbS), pbS, paS, FMA, S>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0],
             [&](int j, double a, double b) {
+              if (ALZ_DBG(p, 32)) return;
               cdbl2 w;
               w.x = a;
               w.y = b;
@@ -965,11 +1189,13 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
       }
     }
   }
+  PIPE_CLOCK_REPORT();
 #undef ALZ_COFF
 }
 
 #undef PIPE_BARRIER
 #undef PIPE_DRAIN
+
 typedef void (*casc_fn)(CArgs);
 
 template <bool CM>

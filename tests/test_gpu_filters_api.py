@@ -138,7 +138,7 @@ def test_fused_gammatone_bank(al, strategy, layout):
   bank = al.gammatone_bank(fcs, S, strategy=strategy, Hz=Hz)
   bank.reset()
   y = bank.process(x if layout == "chan" else np.ascontiguousarray(x.T), layout=layout)
-  assert any(k in bank.last_kernel for k in ("k_casc", "k_pipe", "k_tandem"))
+  assert any(k in bank.last_kernel for k in ("k_casc", "k_pipe", "k_flow"))
   if layout == "time":
     y = y.T
   assert y.shape == (B * S, N)
@@ -173,7 +173,7 @@ def test_fused_diagonal_cascade_of_biquads(al):
   bank = al.FilterBank([(b1, a1), (b2, a2)], n_inputs=C)
   bank.reset(memory=[0.25, -0.5], zero=0.125)
   y = bank.process(x)
-  assert any(k in bank.last_kernel for k in ("k_casc", "k_pipe", "k_tandem"))
+  assert any(k in bank.last_kernel for k in ("k_casc", "k_pipe", "k_flow"))
   yh = np.tile(np.array([0.25, -0.5, 0.25, -0.5]), (C, 1))
   ref = oracle.bank([3, 3], [3, 3], np.concatenate([b1, b2], axis=1), np.concatenate([a1, a2], axis=1), x,
                     xh=np.full((C, 4), 0.125), yh=yh, zero=0.125)

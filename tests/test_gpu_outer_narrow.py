@@ -70,7 +70,7 @@ def test_gammatone_bank_on_few_streams(alz, oracle, layout, streams, bands):
   ref = gammatone_reference(alz, oracle, fcs, Hz, x)
   assert same_bits(y if layout == "chan" else y.T, ref), bank.last_kernel
   if (streams * bands) % 64 == 0:        # whole 64-channel groups: the wave pipeline takes them
-    assert "k_pipe" in bank.last_kernel or "k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel, bank.last_kernel
+    assert "k_flow" in bank.last_kernel or "k_pipe" in bank.last_kernel or "k_duo" in bank.last_kernel or "k_wave" in bank.last_kernel, bank.last_kernel
   # a second block: the state carried on the device, the expanded input rebuilt for the new block
   x2 = rng.uniform(-1, 1, (streams, 777))
   xin2 = x2 if layout == "chan" else np.ascontiguousarray(x2.T)
