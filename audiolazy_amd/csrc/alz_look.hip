@@ -663,12 +663,31 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   p.power = power; p.z = (unsigned long long *)zbuf; p.err = err;
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
-  ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
   const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);
-  ALZ_HIP_CHECK(hipGetLastError());
+  // Every workgroup of the launch waits on others: they must all be resident at once.  The runtime is asked to
+  // guarantee exactly that (a cooperative launch: it refuses a grid that the device cannot hold -- occupancy of this
+  // kernel with its 137 KiB of LDS times the CUs visible to this process, CU masks included); where it refuses, or
+  // the device has no cooperative launches, the caller runs the three-launch form instead.  What no launch API can
+  // promise is that OTHER work leaves the CUs free in time: a workgroup that starts late only delays its neighbours,
+  // and one that starts later than the spin cap allows makes the kernel give up -- which every entry point of the
+  // handle reports (alz_api.hip take_look_error), never a silently bad block.
+  int coop = 0, per_cu = 0;
+  ALZ_HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
+  if (!coop) return ALZ_OK;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 256, lds) != hipSuccess || (int64_t)per_cu * cus < groups * W) {
+    (void)hipGetLastError();
+    return ALZ_OK;
+  }
+  ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
+  void *args[] = {(void *)&p};
+  const hipError_t le = hipLaunchCooperativeKernel((const void *)fn, dim3((unsigned)(groups * W)), dim3(256), args, (unsigned)lds, stream);
+  if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorNotSupported || le == hipErrorLaunchOutOfResources) {
+    (void)hipGetLastError();                                     // not co-resident here: the three-launch form takes the block
+    return ALZ_OK;
+  }
+  if (le != hipSuccess) return fail(ALZ_E_HIP, std::string("k_look cooperative launch: ") + hipGetErrorString(le));
   *done_samples = K * L;
   *kernel_name = "k_look";
   return ALZ_OK;

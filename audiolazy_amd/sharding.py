@@ -103,6 +103,30 @@ def mixdown(y_local, group=None, dst=None, force=False):
   return out if dist.get_rank(group) == dst else None
 
 
+def mix_exact(y_local, n_channels, channel_dim=-1, group=None, dst=None, force=False):
+  """The mix of EVERY channel of a sharded block in the reference's own order -- ``((c0 + c1) + c2) + ...`` over the
+  global channel index, what ``ParallelFilter.__call__`` computes (reference lazy_filters.py:1048-1054:
+  ``reduce(operator.add, ...)``) -- bit-identical to the single-process sum whatever the number of ranks.  One
+  gather of the shards (to ``dst``, or to every rank) followed by the ordered sum on the device (alz_mix_dev); the
+  all-reduce form, :func:`mixdown`, moves 1 / C of the bytes but sums in the collective's order.  Returns the mixed
+  block with ``channel_dim`` removed (None on the ranks that are not ``dst``)."""
+  full = gather_channels(y_local, n_channels, channel_dim=channel_dim, group=group, dst=dst, force=force)
+  if full is None:
+    return None
+  moved = full.movedim(channel_dim, 0)
+  if moved.shape[0] != n_channels:            # (no process group: the local block is the whole block)
+    n_channels = moved.shape[0]
+  rest = tuple(moved.shape[1:])
+  if moved.is_cuda:
+    from .bank import mix_sets
+    flat = moved.reshape(n_channels, -1).contiguous()
+    return mix_sets(flat, n_channels, 1, layout="chan").reshape(rest)
+  acc = moved[0].clone()
+  for ch in range(1, n_channels):             # CPU tensors (the gloo test mode): the same order, one add per channel
+    acc = acc + moved[ch]
+  return acc
+
+
 class DirectComm(object):
   """The same single collective through the C ABI's own RCCL binding (include/alz.h: alz_comm_*) -- for callers
   that drive the engine without torch.distributed.  One process per GPU; rank 0 makes the 128-byte id

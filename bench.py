@@ -718,8 +718,11 @@ def wl_collective(ctx, args, C, n):
   y = ctx.noise((n, C), 9)
   part = y.sum(dim=1)
   reps, out = 3, {}
+  gathered = None
   for key, fn, nbytes in (("mixdown_all_reduce", lambda: sharding.mixdown(part, force=True), n * 8),
                           ("gather_to_rank0", lambda: sharding.gather_channels(y, ctx.world * C, channel_dim=1, dst=0, force=True),
+                           n * C * 8),
+                          ("mix_exact_to_rank0", lambda: sharding.mix_exact(y, ctx.world * C, channel_dim=1, dst=0, force=True),
                            n * C * 8)):
     got = fn()                                   # warm-up (communicator set-up) and the checked result
     ctx.sync_all()
@@ -733,8 +736,19 @@ def wl_collective(ctx, args, C, n):
     if key == "mixdown_all_reduce":
       tot = sum(r[0] for r in ctx.all_ranks([float(part.sum())]))
       ok = abs(float(got.sum()) - tot) <= 1e-9 * max(1.0, abs(tot)) and (ctx.world > 1 or bool(torch.equal(got, part)))
+    elif key == "mix_exact_to_rank0":
+      # the reference's order over the GLOBAL channel index: ((c0 + c1) + c2) ..., bit for bit (checked on 512 rows)
+      if ctx.rank == 0:
+        rows = gathered[:512]
+        acc = rows[:, 0].clone()
+        for ch in range(1, rows.shape[1]):
+          acc = acc + rows[:, ch]
+        ok = tuple(got.shape) == (n,) and bool(torch.equal(got[:512], acc))
+      else:
+        ok = got is None
     elif ctx.rank == 0:
       ok = tuple(got.shape) == (n, ctx.world * C) and bool(torch.equal(got[:, :C], y))
+      gathered = got
     else:
       ok = got is None
     out[key]["check"] = "ok" if all(r[0] == 1.0 for r in ctx.all_ranks([1.0 if ok else 0.0])) else "MISMATCH"
@@ -751,7 +765,7 @@ def wl_collective(ctx, args, C, n):
       out["c_abi_direct_rccl"] = {"check": "ok" if ok else "MISMATCH", "calls": "alz_comm_create / alz_comm_gather / alz_comm_sum"}
     except Exception as exc:        # (reported, not fatal: the torch.distributed path above is the one bench.py relies on)
       out["c_abi_direct_rccl"] = {"check": "skipped", "why": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
-  del y
+  del y, gathered
   torch.cuda.empty_cache()
   bad = [k for k, v in out.items() if v["check"] not in ("ok", "skipped")]
   return {"workload": "downstream step, outside the filter path: channel mix over ranks as one all_reduce of the per-rank "

@@ -112,7 +112,7 @@ def test_one_rank_group_on_rccl():
   assert len(line["per_rank"]) == 1 and abs(line["per_rank"][0]["value"] - line["value"]) / line["value"] < 1e-6
   col = line["secondary"]["downstream_collective"]
   assert col["backend"].startswith("nccl") and col["parity"].startswith("collective results checked")
-  assert set(col["collectives"]) == {"mixdown_all_reduce", "gather_to_rank0", "c_abi_direct_rccl"}
+  assert set(col["collectives"]) == {"mixdown_all_reduce", "gather_to_rank0", "mix_exact_to_rank0", "c_abi_direct_rccl"}
   # ("skipped" is what a direct-RCCL leg that threw reports: it must have RUN here)
   assert all(c["check"] == "ok" for c in col["collectives"].values()), col["collectives"]
 

@@ -60,6 +60,17 @@ def _worker(rank, world, port, C, N, ret):
     part = torch.from_numpy(y_local.sum(axis=1))
     mix = sharding.mixdown(part)
     ok = ok and np.allclose(mix.numpy(), ref.sum(axis=1), rtol=1e-12, atol=1e-12)
+    # ... and the ordered mix: ((c0 + c1) + c2) ... over the GLOBAL channel index (ParallelFilter's order,
+    # lazy_filters.py:1048-1054), bit for bit whatever the number of ranks
+    acc = ref[:, 0].copy()
+    for ch in range(1, C):
+      acc = acc + ref[:, ch]
+    exact = sharding.mix_exact(torch.from_numpy(y_local), C, channel_dim=1)
+    ok = ok and np.array_equal(exact.numpy().view(np.uint64), acc.view(np.uint64))
+    exact0 = sharding.mix_exact(torch.from_numpy(np.ascontiguousarray(y_local.T)), C, channel_dim=0, dst=0)
+    ok = ok and ((exact0 is None) == (rank != 0))
+    if rank == 0:
+      ok = ok and np.array_equal(exact0.numpy().view(np.uint64), acc.view(np.uint64))
     ret[rank] = bool(ok)
   finally:
     dist.destroy_process_group()
