@@ -1,0 +1,1 @@
+cd $GRAFT_REPO_ROOT && ./tools/ubench_ldsq
