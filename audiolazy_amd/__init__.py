@@ -9,19 +9,21 @@ for gfx950 in libalzhip.so (C ABI: include/alz.h).  Filter design, the z**-1 alg
 Stream type stay on the host in float64 and follow the reference's semantics.
 """
 from ._ffi import ParCorError, load as load_library, device_count, last_kernel  # noqa: F401
-from .stream import Stream, ControlStream, Streamix, blocks, thub, cycle, repeat, count, chain, zero_pad, rint  # noqa: F401
+from .stream import (Stream, ControlStream, Streamix, StreamTeeHub, MemoryLeakWarning, blocks, thub, tostream,  # noqa: F401
+                     avoid_stream, cycle, repeat, count, chain, zero_pad, rint)
 from .bank import FilterBank, memory_to_hist, sections_of, block_size, mix_tracks, mix_sets  # noqa: F401
 from .poly import Poly, x  # noqa: F401
 from .strategy import StrategyDict  # noqa: F401
-from .filters import (LinearFilter, ZFilter, z, CascadeFilter, ParallelFilter, comb, resonator,  # noqa: F401
-                      lowpass, highpass)
+from .filters import (LinearFilter, LinearFilterProperties, ZFilter, z, FilterList, CascadeFilter, ParallelFilter,  # noqa: F401
+                      comb, resonator, lowpass, highpass)
 from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
 from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
 from .synth import white_noise, zeros, zeroes, ones, karplus_strong  # noqa: F401
 from .analysis import envelope, envelope_block, maverage, amdf, clip  # noqa: F401
 from . import maps  # noqa: F401
 from .pcm import WavStream, chunks, decode_pcm, encode_pcm  # noqa: F401
-from .misc import dB10, dB20, freq2lag, lag2freq, almost_eq, line  # noqa: F401
+from .misc import (dB10, dB20, freq2lag, lag2freq, freq_to_lag, lag_to_freq, almost_eq, line, cached, elementwise,  # noqa: F401
+                   DEFAULT_SAMPLE_RATE)
 
 
 def sHz(rate):

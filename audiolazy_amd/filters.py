@@ -16,6 +16,8 @@ per-sample Python execution path in this package.
 import cmath
 import math
 import numbers
+import operator
+from functools import reduce as _reduce
 
 from .poly import Poly
 from .strategy import StrategyDict
@@ -24,30 +26,10 @@ __all__ = ["LinearFilter", "ZFilter", "z", "CascadeFilter", "ParallelFilter", "c
            "lowpass", "highpass"]
 
 
-class LinearFilter(object):
-  """A rational transfer function in ``z ** -1`` (reference lazy_filters.py:110-338).
+class LinearFilterProperties(object):
+  """Coefficient views shared by every linear filter -- ZFilter, CascadeFilter, ParallelFilter -- from its
+  ``numpoly`` / ``denpoly`` (reference lazy_filters.py:47-95)."""
 
-  ``numpoly`` / ``denpoly`` are :class:`Poly` in x = z ** -1; ``numlist`` /
-  ``denlist`` are the dense coefficient lists the engine consumes.
-  """
-
-  def __init__(self, numerator=None, denominator=None):
-    if isinstance(numerator, LinearFilter):          # filter type cast (reference :115-120)
-      if denominator is not None:
-        numerator = numerator / denominator
-      self.numpoly, self.denpoly = numerator.numpoly, numerator.denpoly
-    else:
-      self.numpoly = Poly(numerator)
-      self.denpoly = Poly({0: 1} if denominator is None else denominator)
-    # the denominator starts at z ** 0: a common delay / advance factor is cancelled (:126-132); a
-    # denominator with no terms (division by the zero filter) is the reference's ``min()`` of nothing
-    power = min(k for k, _ in self.denpoly.terms())   # ValueError when there is no term, like the reference
-    if power != 0:
-      shift = Poly([0, 1]) ** -power
-      self.numpoly = self.numpoly * shift
-      self.denpoly = self.denpoly * shift
-
-  # -- coefficient views (reference :55-96) -------------------------------------
   @staticmethod
   def _causal_list(poly):
     if any(k < 0 for k, _ in poly.terms()):
@@ -71,6 +53,39 @@ class LinearFilter(object):
   @property
   def dendict(self):
     return dict(self.denpoly.terms())
+
+  @property
+  def numpolyz(self):
+    """The numerator as a Poly in ``z`` instead of ``z ** -1`` (for roots; reference :77-85)."""
+    return Poly(self.numerator[::-1])
+
+  @property
+  def denpolyz(self):
+    return Poly(self.denominator[::-1])
+
+
+class LinearFilter(LinearFilterProperties):
+  """A rational transfer function in ``z ** -1`` (reference lazy_filters.py:110-338).
+
+  ``numpoly`` / ``denpoly`` are :class:`Poly` in x = z ** -1; ``numlist`` /
+  ``denlist`` are the dense coefficient lists the engine consumes.
+  """
+
+  def __init__(self, numerator=None, denominator=None):
+    if isinstance(numerator, LinearFilter):          # filter type cast (reference :115-120)
+      if denominator is not None:
+        numerator = numerator / denominator
+      self.numpoly, self.denpoly = numerator.numpoly, numerator.denpoly
+    else:
+      self.numpoly = Poly(numerator)
+      self.denpoly = Poly({0: 1} if denominator is None else denominator)
+    # the denominator starts at z ** 0: a common delay / advance factor is cancelled (:126-132); a
+    # denominator with no terms (division by the zero filter) is the reference's ``min()`` of nothing
+    power = min(k for k, _ in self.denpoly.terms())   # ValueError when there is no term, like the reference
+    if power != 0:
+      shift = Poly([0, 1]) ** -power
+      self.numpoly = self.numpoly * shift
+      self.denpoly = self.denpoly * shift
 
   def __iter__(self):
     """(numdict, dendict): what the reference's helpers compare filters by (reference :134-136)."""
@@ -111,10 +126,22 @@ class LinearFilter(object):
         and self.denpoly == other.denpoly
 
   def __ne__(self, other):
-    return not self == other
+    # (the reference's own definition, :683-686: BOTH polynomials must differ, and nothing else is "unequal")
+    if isinstance(other, LinearFilter):
+      return self.numpoly != other.numpoly and self.denpoly != other.denpoly
+    return False
 
   def __hash__(self):
     return hash((self.numpoly, self.denpoly))
+
+  @property
+  def poles(self):
+    """Roots of the denominator in ``z`` (reference :640-657; numpy.roots like there)."""
+    return self.denpolyz.roots
+
+  @property
+  def zeros(self):
+    return self.numpolyz.roots
 
   # -- analysis -----------------------------------------------------------------
   def freq_response(self, freq):
@@ -338,10 +365,36 @@ class ZFilter(LinearFilter):
              sum(v * seq ** -k for k, v in self.denpoly.terms())
     return super(ZFilter, self).__call__(seq, memory=memory, zero=zero)
 
-  def __repr__(self):
-    return "ZFilter(%r, %r)" % (self.numlist if self.is_causal() else dict(self.numpoly.terms()),
-                                self.denpoly.values() if self.denpoly.is_polynomial()
-                                else dict(self.denpoly.terms()))
+  def __str__(self):
+    """The reference's text form (lazy_filters.py:782-817): numerator over denominator in powers of ``z``, the shorter
+    line centred, only the numerator when there is no feedback."""
+    from .poly import _term_text, _sum_text
+    sides = []
+    for poly, letter in ((self.numpoly, "b"), (self.denpoly, "a")):
+      parts = []
+      for power, value in poly.terms():
+        if hasattr(value, "__iter__"):
+          value = ("%s%s" % (letter, power)).replace(".", "_").replace("-", "m")
+        if value != 0.:
+          parts.append(_term_text(-power, value, "z"))
+      sides.append(parts)
+    num = _sum_text(sides[0])
+    if not sides[1]:
+      raise TypeError("reduce() of empty sequence with no initial value")     # (what the reference's reduce raises)
+    den = _sum_text(sides[1])
+    if den == "1":
+      return num
+    line = "-" * max(len(num), len(den))
+    pad = " " * (abs(len(num) - len(den)) // 2)
+    if len(num) > len(den):
+      den = pad + den
+    elif len(den) > len(num):
+      num = pad + num
+    # (lines longer than 80 characters continue below, 80 at a time)
+    pieces = [slice(80 * b, 80 * (b + 1)) for b in range(len(line) // 80 + 1)]
+    return "\n\n    ...continue...\n\n".join("\n".join([num[p], line[p], den[p]]) for p in pieces)
+
+  __repr__ = __str__
 
 
 from .stream import IGNORED_CLASSES as _stream_ignored  # noqa: E402
@@ -374,7 +427,7 @@ def _elementwise_freq(method):
   return wrapper
 
 
-class FilterList(list):
+class FilterList(list, LinearFilterProperties):
   """A list of filters that is itself a filter; a single filter or an iterable of filters
   builds it (reference :906-968).  Items that are not callable (numbers, coefficient lists)
   count as the LinearFilter they cast to (``callables``, :955-961); ``+`` and ``*`` act like on
@@ -464,27 +517,30 @@ class CascadeFilter(FilterList):
 
   @property
   def numpoly(self):
-    out = None
-    for poly in self._polys("numpoly"):
-      out = poly if out is None else out * poly
-    return Poly(1) if out is None else out
+    return _reduce(operator.mul, self._polys("numpoly"))
 
   @property
   def denpoly(self):
-    out = None
-    for poly in self._polys("denpoly"):
-      out = poly if out is None else out * poly
-    return Poly(1) if out is None else out
+    return _reduce(operator.mul, self._polys("denpoly"))
 
   @_elementwise_freq
   def freq_response(self, freq):
-    out = None
-    for f in self.callables:
-      if not hasattr(f, "freq_response"):
-        raise AttributeError("Non-linear filter")
-      r = f.freq_response(freq)
-      out = r if out is None else out * r
-    return out
+    members = self.callables
+    if any(not hasattr(f, "freq_response") for f in members):
+      raise AttributeError("Non-linear filter")
+    return _reduce(operator.mul, (f.freq_response(freq) for f in members))
+
+  @property
+  def poles(self):
+    if not self.is_lti():
+      raise AttributeError("Not a LTI filter")
+    return _reduce(operator.concat, (f.poles for f in self.callables))
+
+  @property
+  def zeros(self):
+    if not self.is_lti():
+      raise AttributeError("Not a LTI filter")
+    return _reduce(operator.concat, (f.zeros for f in self.callables))
 
 
 class ParallelFilter(FilterList):
@@ -529,27 +585,30 @@ class ParallelFilter(FilterList):
   def numpoly(self):
     if not self.is_linear():
       raise AttributeError("Non-linear filter")
-    total = None
-    for f in self.callables:
-      total = f if total is None else total + f
-    return total.numpoly
+    return _reduce(operator.add, self).numpoly        # (the members as they are, like the reference :1056-1060)
 
   @property
   def denpoly(self):
-    out = None
-    for poly in self._polys("denpoly"):
-      out = poly if out is None else out * poly
-    return Poly(1) if out is None else out
+    return _reduce(operator.mul, self._polys("denpoly"))
 
   @_elementwise_freq
   def freq_response(self, freq):
-    out = None
-    for f in self.callables:
-      if not hasattr(f, "freq_response"):
-        raise AttributeError("Non-linear filter")
-      r = f.freq_response(freq)
-      out = r if out is None else out + r
-    return out
+    members = self.callables
+    if any(not hasattr(f, "freq_response") for f in members):
+      raise AttributeError("Non-linear filter")
+    return _reduce(operator.add, (f.freq_response(freq) for f in members))
+
+  @property
+  def poles(self):
+    if not self.is_lti():
+      raise AttributeError("Not a LTI filter")
+    return _reduce(operator.concat, (f.poles for f in self.callables))
+
+  @property
+  def zeros(self):
+    if not self.is_lti():
+      raise AttributeError("Not a LTI filter")
+    return _reduce(operator.add, (ZFilter(f) for f in self)).zeros
 
   def _call_bank(self, seq, memories, zero, block):
     """All filters as the coefficient sets of one OUTER bank over the single input, then the

@@ -37,6 +37,58 @@ def freq2lag(v):
 
 
 lag2freq = freq2lag
+freq_to_lag = lag_to_freq = freq2lag          # (the reference's deprecated names, lazy_misc.py:326, 332)
+
+DEFAULT_SAMPLE_RATE = 44100                   # Hz (lazy_misc.py:41)
+
+
+def cached(func):
+  """Memoise a function of positional arguments; the results live in ``f.cache``, a dict keyed by the argument tuple
+  (lazy_misc.py:335-349)."""
+  import functools
+
+  class Cache(dict):
+    def __missing__(self, key):
+      self[key] = result = func(*key)
+      return result
+  cache = Cache()
+  f = functools.wraps(func)(lambda *key: cache[key])
+  f.cache = cache
+  return f
+
+
+def elementwise(name="", pos=None):
+  """Decorator factory: the decorated function maps over ONE of its arguments (keyword ``name`` and / or position
+  ``pos``; the first positional one by default) when that argument is an iterable -- a generator gives a generator, a
+  NumPy array an array, a Stream a Stream, any other container its own type (lazy_misc.py:163-228)."""
+  import functools
+  import itertools
+  import types
+  if name == "" and pos is None:
+    pos = 0
+
+  def decorator(func):
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+      positional = pos is not None and pos < len(args)
+      arg = args[pos] if positional else kwargs[name]
+      if hasattr(arg, "__iter__") and not isinstance(arg, (str, bytes)):
+        if positional:
+          data = (func(*(args[:pos] + (v,) + args[pos + 1:]), **kwargs) for v in arg)
+        else:
+          data = (func(*args, **dict(kwargs, **{name: v})) for v in arg)
+        if isinstance(arg, (types.GeneratorType, range, enumerate, zip, itertools.zip_longest, map, filter)):   # (lazy_compat.py:52-53)
+          return data
+        kind = type(arg)
+        if getattr(kind, "__module__", None) == "numpy":
+          import numpy as np
+          return (np.array if kind.__name__ == "ndarray" else np.asmatrix)(list(data))
+        if issubclass(kind, Stream):
+          return Stream(data)
+        return kind(data)
+      return func(*args, **kwargs)
+    return wrapper
+  return decorator
 
 
 def _pairs(a, b, pad):

@@ -271,6 +271,29 @@ class _MixSchedule(object):
     return total
 
 
+def avoid_stream(cls):
+  """Class decorator: instances are left alone by a Stream's operators -- the other operand's own reflected operator
+  decides (lazy_stream.py:400-414)."""
+  IGNORED_CLASSES.append(cls)
+  return cls
+
+
+def tostream(func, module_name=None):
+  """Decorator: the function's result (typically a generator) comes back as a Stream (lazy_stream.py:417-433)."""
+  import functools
+
+  @functools.wraps(func)
+  def new_func(*args, **kwargs):
+    return Stream(func(*args, **kwargs))
+  if module_name is not None:
+    new_func.__module__ = module_name
+  return new_func
+
+
+class MemoryLeakWarning(Warning):
+  """For StreamTeeHub copies that were never used (lazy_stream.py:465-466)."""
+
+
 class Streamix(Stream):
   """Stream mixer: iterables that enter at their own times, summed sample by sample in the
   order they were added, starting from ``zero`` (reference lazy_stream.py:633-724).

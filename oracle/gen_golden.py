@@ -678,8 +678,19 @@ def composition_cases():
   return out
 
 
+def surface_cases():
+  """Attribute surface of Poly and of the filter objects (oracle/surface_probes.py), the reference's outcome of every
+  probe on seeded random cases: {seed, n, rows} per family."""
+  import surface_probes as sp
+  return dict(poly=dict(seed=20260925, n=160, rows=sp.poly_outcomes(al, 20260925, 160)),
+              filters=dict(seed=20260926, n=160, rows=sp.filter_outcomes(al, 20260926, 160)))
+
+
 if __name__ == "__main__":
   print("audiolazy", al.__version__, "numpy", np.__version__)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-surface":
+    dump("surface.json", surface_cases())
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-maps":
     dump("maps.json", maps_cases())
     sys.exit(0)
@@ -709,3 +720,4 @@ if __name__ == "__main__":
   dump("lpc_strategies.json", lpc_strategy_cases())
   dump("generic_items.json", generic_item_cases())
   dump("composition.json", composition_cases())
+  dump("surface.json", surface_cases())
