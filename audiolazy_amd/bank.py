@@ -69,7 +69,9 @@ def sections_of(filt):
   A CascadeFilter-like object (a list of filters, reference lazy_filters.py
   :970-1021) contributes one section per item, in call order (:988-990).
   """
-  if hasattr(filt, "numlist") or (isinstance(filt, tuple) and len(filt) == 2):
+  # (a CascadeFilter IS a list and, like every linear filter of the reference, also has numlist / denlist -- of the
+  #  PRODUCT polynomial: its sections are its members, never that product)
+  if not isinstance(filt, list) and (hasattr(filt, "numlist") or (isinstance(filt, tuple) and len(filt) == 2)):
     return [_coef_lists(filt)]
   if isinstance(filt, (list, tuple)):
     out = []

@@ -289,7 +289,7 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
     boff += nb[s];
     aoff += na[s];
   }
-  h->scan.resize((size_t)n_sections + 1);   // [n_sections]: the fused time-parallel cascade's own scratch
+  h->scan.resize((size_t)n_sections + 2);   // [n_sections]: the fused time-parallel cascade's own scratch; [n_sections + 1]: the same for sections 1 .. when section 0 runs by itself
   *out = h;
   return ALZ_OK;
 }
@@ -671,6 +671,30 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
     int rc = alz::launch_cascade(h->sec.data(), h->n_sections, io, st, &fused_n, &fused_c, &name);
     if (rc) return rc;
     if (fused_c > 0) note(name);
+  }
+  // Opt-in time-parallel mode on a cascade whose FIRST section the fused form does not take (gammatone.sampled,
+  // reference lazy_auditory.py:158-181: eight numerator taps of +-1e3 that cancel -- carried through the fused
+  // chunk-state recursion they cost ten digits): that section runs by itself (its own chunked pass, its numerator exact),
+  // the others, biquad-class, run fused over its output, in place: two round trips through HBM instead of four.
+  if (fused_c == 0 && h->time_parallel != 0 && h->n_sections >= 3 && layout == ALZ_CHAN_MAJOR && x_dev != y_dev &&
+      h->sec[0].nb > 3) {
+    int rc = run_sections_on(0, h->channels, 0, n, 0, 1, st);
+    if (rc) return rc;
+    io.n = n;
+    io.x = y_dev; io.y = y_dev;
+    io.sxn = syn; io.sxc = syc; io.syn = syn; io.syc = syc;
+    io.map_input = 0; io.pre_op = 0;
+    io.c_first = 0; io.c_count = h->channels;
+    bool taken = false;
+    const char *name = "";
+    rc = alz::launch_scan_cascade(h->sec.data() + 1, h->n_sections - 1, io, st, h->time_parallel < 0 ? 0 : h->time_parallel,
+                                  &h->scan[(size_t)h->n_sections + 1], &taken, &name);
+    if (rc) return rc;
+    if (taken) {
+      note(name);
+      return ALZ_OK;
+    }
+    return run_sections_on(0, h->channels, 0, n, 1, h->n_sections, st);
   }
   if (fused_c == 0) return run_sections(0, h->channels, 0, n);
   if (fused_c < h->channels) {
