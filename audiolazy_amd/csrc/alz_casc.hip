@@ -1207,6 +1207,7 @@ static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
   ALZ_CASC(3, 3, 3, 3, 3, 3, 3, 3, 4)        // gammatone.slaney
   ALZ_CASC(5, 3, 1, 3, 5, 3, 1, 3, 4)        // gammatone.klapuri
   ALZ_CASC(0xFE, 3, 1, 3, 1, 3, 1, 3, 4)     // gammatone.sampled (8-tap numerator, b0 == 0)
+  ALZ_CASC(1, 3, 1, 3, 1, 3, 0, 0, 3)        // gammatone.sampled's sections 1 - 3 (time-parallel mode: section 0 runs by itself)
   ALZ_CASC(1, 1, 1, 1, 0, 0, 0, 0, 2)        // lowpass.pole twice as a cascade
   ALZ_CASC(7, 3, 7, 3, 0, 0, 0, 0, 2)        // two general biquads
   ALZ_CASC(7, 3, 7, 3, 7, 3, 7, 3, 4)        // four general biquads
