@@ -682,6 +682,13 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   }
   ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
   void *args[] = {(void *)&p};
+  if (ALZ_TUNE("ALZ_LOOK_COOP", 1) == 0) {       // (tuning builds: the plain launch of round 3, for A/B timing)
+    hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);
+    ALZ_HIP_CHECK(hipGetLastError());
+    *done_samples = K * L;
+    *kernel_name = "k_look(plain launch)";
+    return ALZ_OK;
+  }
   const hipError_t le = hipLaunchCooperativeKernel((const void *)fn, dim3((unsigned)(groups * W)), dim3(256), args, (unsigned)lds, stream);
   if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorNotSupported || le == hipErrorLaunchOutOfResources) {
     (void)hipGetLastError();                                     // not co-resident here: the three-launch form takes the block
