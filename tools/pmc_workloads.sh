@@ -2,7 +2,7 @@
 # HBM traffic of every workload bench.py reports, by rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes,
 # kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes): one run per workload and counter, the
 # counter summed over this library's kernels and divided by the number of steps.  Output: gpurun_out/<tag>/pmc_*.json,
-# merged by tools/pmc_table.py into profiles/r03_pmc_traffic_table.json.
+# merged by tools/pmc_table.py into profiles/r0N_pmc_traffic_table.json.
 #   usage: tools/pmc_workloads.sh <tag> [regex: only the workloads whose key matches]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
@@ -25,12 +25,14 @@ run headline
 run fir256_bit_exact --workload fir
 run fir256_fma --workload fir --fused
 run gammatone --workload gammatone
+run gammatone_fma --workload gammatone --fused
 run gammatone_one_stream --workload gammatone --streams 1
 run gammatone_one_stream_time_parallel --workload gammatone --streams 1 --time-parallel 1
 run lpc --workload lpc
 run lpc_bit_identical --workload lpc --lpc-exact
 run lpc_fma --workload lpc --fused
 run lpc_1m --workload lpc --lpc-frames 1048576
+run lpc_1m_bit_identical --workload lpc --lpc-frames 1048576 --lpc-exact
 run envelope_abs --workload envelope
 run timevar_shared --workload timevar
 run timevar_per_channel --workload timevar --streams 0
