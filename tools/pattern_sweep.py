@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import audiolazy_amd as al
-C, N = 4096, 1 << 18
+C, N = 4096, 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 18)
 s, Hz = al.sHz(48000)
 fc = np.geomspace(50., 20000., C)
 designs = {
@@ -26,3 +26,11 @@ for name, d in designs.items():
   e1.record(); torch.cuda.synchronize()
   ms = e0.elapsed_time(e1) / 3
   print("%-34s %-12s %7.1f Gsamples/s" % (name, bank.last_kernel, C * N / ms / 1e6))
+  if name.startswith("lowpass.pole (b0"):
+    bank.set_input_map("abs")
+    bank.reset()
+    bank.process(x, out=y); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3): bank.process(x, out=y)
+    e1.record(); torch.cuda.synchronize()
+    print("%-34s %-12s %7.1f Gsamples/s" % (name + " after |x|", bank.last_kernel, C * N / (e0.elapsed_time(e1) / 3) / 1e6))
