@@ -54,6 +54,7 @@ struct WArgs {
   // j * chunk_c + c of the state arrays (whose stride `channels` is then n_chunks * chunk_c).
   // All three are 0 in an ordinary launch (gridDim.y == 1).
   int64_t chunk_x, chunk_y, chunk_c;
+  int aux_pace;   // k_duo, one-pole banks that fill the chip: pauses (x 64 cycles) between the quarters of AUX's feed-forward pass
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -366,6 +367,7 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_CHUNKWAIT
 #define ALZ_DUO_CHUNKWAIT 1
 #endif
+
 #ifndef ALZ_DUO_STORER
 #define ALZ_DUO_STORER 1     // a third wave stores the finished tiles (not in the FMA mode; profiles/NOTES_r03.md 11)
 #endif
@@ -475,46 +477,91 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
       const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
       const char *x_d2[2] = {xs + (q - 2) * kStep - adj2, xs + (q - 2) * kStep};
       double x0[16], x1[16], x2[16];
+      auto read_rows = [&](int j0, int j1) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if constexpr (PB & 1u) x0[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
-        if constexpr (PB & 2u) {
-          if (j > 0) x1[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
+        for (int j = j0; j < j1; ++j) {
+          if constexpr (PB & 1u) x0[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
+          if constexpr (PB & 2u) {
+            if (j > 0) x1[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
+          }
+          if constexpr (PB & 4u) {
+            if (j > 0) x2[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j)));
+          }
         }
-        if constexpr (PB & 4u) {
-          if (j > 0) x2[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j)));
+      };
+      auto sum_rows = [&](int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+          double acc = 0.0;
+          bool first = true;
+          if constexpr (PB & 1u) { acc = b0 * x0[j]; first = false; }
+          if constexpr (PB & 2u) {
+            if (FMA && !first) acc = __builtin_fma(b1, x1[j], acc);
+            else { const double v = b1 * x1[j]; acc = first ? v : acc + v; }
+            first = false;
+          }
+          if constexpr (PB & 4u) {
+            if (FMA && !first) acc = __builtin_fma(b2, x2[j], acc);
+            else { const double v = b2 * x2[j]; acc = first ? v : acc + v; }
+            first = false;
+          }
+          *reinterpret_cast<double *>(ps + (4 * j + q) * kStep) = acc;
         }
-      }
-      // j == 0: samples q - 1 and q - 2 may lie before the tile
-      if constexpr ((PB & 6u) != 0) {
-        double pm1, pm2;                        // x[-1], x[-2] relative to this tile
-        if (t > 0) {
-          pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1)));
-          pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2)));
+      };
+      auto edge_rows = [&]() {
+        // j == 0: samples q - 1 and q - 2 may lie before the tile
+        if constexpr ((PB & 6u) != 0) {
+          double pm1, pm2;                        // x[-1], x[-2] relative to this tile
+          if (t > 0) {
+            pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1)));
+            pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2)));
+          } else {
+            pm1 = d1;
+            pm2 = d2;
+          }
+          const double c0 = xat(0), c1 = xat(1);
+          if constexpr (PB & 2u) x1[0] = q == 0 ? pm1 : q == 1 ? c0 : q == 2 ? c1 : xat(2);
+          if constexpr (PB & 4u) x2[0] = q == 0 ? pm2 : q == 1 ? pm1 : q == 2 ? c0 : c1;
+        }
+      };
+      // A one-pole bank's recurrence wave steps in ~13 cycles instead of 28 and needs its p rows that much sooner; this
+      // wave's 16 reads + 16 writes in one burst then stand in the LDS queue in front of them.  With every CU busy
+      // (the launcher decides: aux_pace > 0) the tile goes out in four quarters with pauses between them -- this wave
+      // has most of the interval to spare: 4096 channels x 2^20 282 - 293 -> 309 - 340 Gsamples/s over three boxes
+      // (channel-major 267 - 313 -> 319 - 356; profiles/NOTES_r04.md 4).
+      bool paced = false;
+      if constexpr (PB == 1u && PA == 1u && !FMA && !NOSTORE) paced = p.aux_pace > 0;
+      if (paced) {
+        const int units = p.aux_pace & 15;
+        if (p.aux_pace & 16) {                   // eighths
+          read_rows(0, 2);
+          edge_rows();
+          sum_rows(0, 2);
+#pragma unroll
+          for (int g = 1; g < 8; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < units; ++r) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_rows(2 * g, 2 * g + 2);
+            sum_rows(2 * g, 2 * g + 2);
+          }
         } else {
-          pm1 = d1;
-          pm2 = d2;
-        }
-        const double c0 = xat(0), c1 = xat(1);
-        if constexpr (PB & 2u) x1[0] = q == 0 ? pm1 : q == 1 ? c0 : q == 2 ? c1 : xat(2);
-        if constexpr (PB & 4u) x2[0] = q == 0 ? pm2 : q == 1 ? pm1 : q == 2 ? c0 : c1;
-      }
+          read_rows(0, 4);
+          edge_rows();
+          sum_rows(0, 4);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double acc = 0.0;
-        bool first = true;
-        if constexpr (PB & 1u) { acc = b0 * x0[j]; first = false; }
-        if constexpr (PB & 2u) {
-          if (FMA && !first) acc = __builtin_fma(b1, x1[j], acc);
-          else { const double v = b1 * x1[j]; acc = first ? v : acc + v; }
-          first = false;
+          for (int g = 1; g < 4; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < units; ++r) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_rows(4 * g, 4 * g + 4);
+            sum_rows(4 * g, 4 * g + 4);
+          }
         }
-        if constexpr (PB & 4u) {
-          if (FMA && !first) acc = __builtin_fma(b2, x2[j], acc);
-          else { const double v = b2 * x2[j]; acc = first ? v : acc + v; }
-          first = false;
-        }
-        *reinterpret_cast<double *>(ps + (4 * j + q) * kStep) = acc;
+      } else {
+        read_rows(0, 16);
+        edge_rows();
+        sum_rows(0, 16);
       }
     };
     auto store_tile = [&](int64_t t) {
@@ -822,6 +869,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   }
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
+  // One-pole banks that fill the chip once, long blocks: AUX's feed-forward pass in quarters with 2 x 64-cycle pauses.
+  // Measured on three boxes (profiles/r04_duo_patterns.log): 4096 channels x 2^20 time-major +2 / +13 / +10 ... 16 %,
+  // channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three pauses are better on one box and worse on the
+  // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
+  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && sec.present_b == 1u && sec.present_a == 1u)
+                   ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)

@@ -194,6 +194,41 @@ def _gpu_noise(shape, seed):
   return x
 
 
+@pytest.mark.parametrize("layout", ["time", "chan"])
+@pytest.mark.parametrize("absmap", [False, True])
+def test_one_pole_bank_long_block_paced_feed_forward(alz, oracle, layout, absmap):
+  """4096 one-pole channels (lowpass.pole, envelope.abs's filter) x 2^17 + 196 samples: the shape for which k_duo's
+  AUX wave sends its feed-forward pass out in paced quarters (round 4) -- 64 strided channels against the C oracle over
+  the WHOLE block, bit for bit, in both layouts, with and without |x| on the reads, then a second block from the state."""
+  import torch
+  C, N, N2 = 4096, (1 << 17) + 196, 4096 + 34
+  rng = np.random.default_rng(17)
+  pole = rng.uniform(0.5, 0.9995, C)
+  b, a = (1 - pole)[:, None].copy(), np.stack([np.ones(C), -pole], axis=1)
+  tm = layout == "time"
+  x = _gpu_noise((N + N2, C) if tm else (C, N + N2), 23)
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  if absmap:
+    bank.set_input_map("abs")
+  bank.reset()
+  x1 = x[:N] if tm else x[:, :N].contiguous()
+  x2 = x[N:] if tm else x[:, N:].contiguous()
+  y1 = bank.process(x1, layout=layout)
+  assert "k_duo" in bank.last_kernel, bank.last_kernel
+  y2 = bank.process(x2, layout=layout)
+  pick = np.linspace(0, C - 1, 64).astype(int)
+  idx = torch.from_numpy(pick).cuda()
+  dim = 1 if tm else 0
+  got = torch.cat([y1, y2], dim=0 if tm else 1).index_select(dim, idx).cpu().numpy()
+  xs = x.index_select(dim, idx).cpu().numpy()
+  if absmap:
+    xs = np.abs(xs)
+  del x, x1, x2, y1, y2
+  torch.cuda.empty_cache()
+  ref = oracle.bank([1], [2], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), xs, layout=layout)
+  assert same_bits(got, ref)
+
+
 def test_cfg2_full_block_length_on_strided_channels(alz, oracle, bench):
   """configs[1] at its real block length: 4096 channels x 2^20 samples through k_duo, 64 strided channels compared with
   the C oracle over the WHOLE block (every one of the 16 384 tiles a benchmark step walks), bit for bit."""
