@@ -35,6 +35,9 @@ static constexpr int kRing = 4;           // LDS slots per wave
 static constexpr int kChunks = 8;         // 1 KiB DMA instructions per tile
 static constexpr int kSlotBytes = 8192 + kChunks * 16;
 
+#ifndef ALZ_PACE_ALL
+#define ALZ_PACE_ALL 0   // (variant builds: the paced feed-forward pass for every tap pattern)
+#endif
 struct WArgs {
   const double *x;
   double *y;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
       // has most of the interval to spare: 4096 channels x 2^20 282 - 293 -> 309 - 340 Gsamples/s over three boxes
       // (channel-major 267 - 313 -> 319 - 356; profiles/NOTES_r04.md 4).
       bool paced = false;
-      if constexpr (PB == 1u && PA == 1u && !FMA && !NOSTORE) paced = p.aux_pace > 0;
+      if constexpr (((PB == 1u && PA == 1u) || ALZ_PACE_ALL) && !FMA && !NOSTORE) paced = p.aux_pace > 0;
       if (paced) {
         const int units = p.aux_pace & 15;
         if (p.aux_pace & 16) {                   // eighths
@@ -873,7 +876,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // Measured on three boxes (profiles/r04_duo_patterns.log): 4096 channels x 2^20 time-major +2 / +13 / +10 ... 16 %,
   // channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three pauses are better on one box and worse on the
   // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
-  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && sec.present_b == 1u && sec.present_a == 1u)
+  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
