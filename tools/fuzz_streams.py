@@ -50,13 +50,15 @@ P={
  "dB20": lambda m,a,b: list(m.dB20(a)), "dB10": lambda m,a,b: m.dB10(4.0),
  "sHz": lambda m,a,b: list(m.sHz(48000)), "freq2lag": lambda m,a,b: m.freq2lag(.3), "zeros": lambda m,a,b: m.zeros(3).take(5), "ones": lambda m,a,b: m.ones(2).take(5), "zeros_inf": lambda m,a,b: m.zeros().take(3),
 }
-bad={}
+bad={}; known={}
 N=int(sys.argv[1]) if len(sys.argv)>1 else 200
 for i in range(N):
     a,b=data(),data()
     for name,p in P.items():
         x=outcome(lambda:p(ref,list(a),list(b))); y=outcome(lambda:p(own,list(a),list(b)))
-        if x!=y:
+        if x==("raises","RuntimeError") and y[0]!="raises":
+            known[name]=known.get(name,0)+1   # PEP 479: the reference's take / skip generators die at a finite stream's end on Python >= 3.7
+        elif x!=y:
             bad[name]=bad.get(name,0)+1
             if bad[name]<=2: print(name,a,b,"\n  ref",str(x)[:200],"\n  own",str(y)[:200])
-print("cases",N,"differences",bad,"of",len(P))
+print("cases",N,"differences",bad,"of",len(P),"| reads past a finite stream's end (reference: RuntimeError, own: the short result)",known)
