@@ -61,6 +61,7 @@ SIGNATURES = {
   "alz_levinson_dev": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _vp]),
   "alz_levinson_dev_ex": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp, _int, _int, _vp]),
   "alz_acorr_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
+  "alz_lag_matrix_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _int, _vp]),
   "alz_mix_dev": (_int, [_vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _int, _vp]),
   "alz_mix_tracks_dev": (_int, [_int, _vp, _vp, _vp, ctypes.c_double, _i64, _vp, _int, _vp]),
   "alz_pcm_decode_dev": (_int, [_vp, _int, _int, _i64, _vp, _int, _vp]),

@@ -386,6 +386,25 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
   }
 }
 
+// lag_matrix (lazy_analysis.py:315-342), the covariance-method statistics of lpc.covar / lpc.kcovar
+// (lazy_lpc.py:285, :310): cell (j, i) of a frame is sum(blk[n - i] * blk[n - j] for n = max_lag .. L - 1), added
+// left to right from 0 like Python's sum.  One lane per cell; consecutive lanes take consecutive i, so a step's
+// blk[n - i] reads of a row are one contiguous run and blk[n - j] is a broadcast.  A caller-side helper (P^2
+// independent sums of L - P + 1 terms), not one of the streaming kernels.
+__global__ __launch_bounds__(256) void k_lag_matrix(const double *__restrict__ sig, int64_t n_frames, int frame_len,
+                                                     int64_t hop, int P, double *__restrict__ out) {
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t cells = (int64_t)P * P;
+  if (cell >= n_frames * cells) return;
+  const int64_t f = cell / cells;
+  const int r = (int)(cell % cells);
+  const int j = r / P, i = r % P;
+  const double *blk = sig + f * hop;
+  double acc = 0.0;
+  for (int n = P - 1; n < frame_len; ++n) acc = acc + blk[n - i] * blk[n - j];
+  out[cell] = acc;
+}
+
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
 template <int LEV, bool FMA = false, int RING = 3>
@@ -678,6 +697,29 @@ int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_
                                                 (hipStream_t)stream, &rc))
     rc = alz::launch_lpc(sig_dev, n_frames, frame_len, hop, max_lag, nullptr, nullptr, nullptr, r_dev, 0,
                          (hipStream_t)stream);
+  if (prev != device) (void)hipSetDevice(prev);
+  return rc;
+}
+
+int alz_lag_matrix_dev(const double *sig_dev, int64_t n_frames, int frame_len, int64_t hop, int max_lag,
+                       double *phi_dev, int device, void *stream) {
+  if (!sig_dev || !phi_dev) return alz::fail(ALZ_E_ARG, "NULL argument");
+  if (max_lag < 0 || frame_len < 1 || hop < 0 || n_frames < 0) return alz::fail(ALZ_E_ARG, "bad lag_matrix shape");
+  if (max_lag >= frame_len) return alz::fail(ALZ_E_ARG, "Block length should be higher than order");
+  const int64_t cells = (int64_t)(max_lag + 1) * (max_lag + 1);
+  if (n_frames > 0 && cells > (INT64_C(0x7fffffff) * 256) / n_frames) return alz::fail(ALZ_E_ARG, "lag_matrix batch too large");
+  int prev = 0;
+  ALZ_HIP_CHECK(hipGetDevice(&prev));
+  if (prev != device) ALZ_HIP_CHECK(hipSetDevice(device));
+  int rc = ALZ_OK;
+  alz::note_kernel("");
+  if (n_frames > 0) {
+    const int64_t blocks = (n_frames * cells + 255) / 256;
+    alz::k_lag_matrix<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(sig_dev, n_frames, frame_len, hop,
+                                                                                    max_lag + 1, phi_dev);
+    if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_lag_matrix launch failed");
+    alz::note_kernel("k_lag_matrix", true);
+  }
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
 }

@@ -4,7 +4,15 @@ Host mirror of the reference's ``acorr`` (audiolazy/lazy_analysis.py:277-312),
 ``levinson_durbin`` (audiolazy/lazy_lpc.py:52-136) and ``lpc.kautocor``
 (audiolazy/lazy_lpc.py:229-272) for many frames at once; frames are what
 ``Stream.blocks(size=frame_len, hop=hop)`` would yield from one signal.
+
+Beside the path: the covariance-method callers of the same file -- ``lag_matrix`` (lazy_analysis.py:315-342, on the
+GPU, batched as ``lag_matrix_frames``), ``lpc.covar`` / ``lpc.kcovar`` (lazy_lpc.py:275-340), and the lattice /
+stability helpers ``parcor``, ``parcor_stable``, ``lsf``, ``lsf_stable``, ``toeplitz`` (:44-49, :343-487), which are
+coefficient algebra on the host like the reference's.
 """
+import cmath
+import itertools
+import numbers
 import ctypes
 
 import numpy as np
@@ -91,19 +99,74 @@ def acorr_frames(sig, frame_len, max_lag, hop=None, device=0):
   return d_r.download((F, max_lag + 1), np.float64)
 
 
+def lag_matrix_frames(sig, frame_len, max_lag, hop=None, device=0):
+  """lag_matrix(blk, max_lag) for every full frame: phi [F, max_lag+1, max_lag+1], cell (j, i) the sum of
+  ``blk[n - i] * blk[n - j]`` over n = max_lag .. frame_len - 1 in the reference's order (lazy_analysis.py:340-342),
+  so the doubles are the reference's."""
+  L = _ffi.load()
+  hop = frame_len if hop is None else hop
+  if max_lag >= frame_len:
+    raise ValueError("Block length should be higher than order")
+  flat = np.ascontiguousarray(sig, dtype=np.float64).reshape(-1)
+  F = _frame_count(flat.size, frame_len, hop)
+  P = max_lag + 1
+  d_sig = _DevBuf(max(flat.nbytes, 8), device).upload(flat)
+  d_phi = _DevBuf(max(F * P * P * 8, 8), device)
+  _ffi.check(L.alz_lag_matrix_dev(d_sig.ptr, F, frame_len, hop, max_lag, d_phi.ptr, device, None))
+  _ffi.check(L.alz_device_sync(device))
+  return d_phi.download((F, P, P), np.float64)
+
+
 # ---------------------------------------------------------------------------
 # the reference's single-block operator surface (lazy_analysis.py:277-312,
 # lazy_lpc.py:52-136, 229-272), executed on the GPU one frame at a time
 # ---------------------------------------------------------------------------
+_EXACT_INT = 1 << 26   # |ints| below this multiply exactly in float64: the engine's doubles are then the reference's
+
+
+def _block_fits_engine(blk):
+  """The float64 engine takes a block of real floats (ints among them only while their products stay exact).  A
+  block of nothing but ints stays integer arithmetic in the reference (doctest lazy_analysis.py:298-306 prints ints),
+  and complex / Fraction / symbolic items never were floats: those run the reference's sums on the host."""
+  any_float = False
+  for v in blk:
+    if isinstance(v, (float, np.floating)):
+      any_float = True
+    elif isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -_EXACT_INT < v < _EXACT_INT:
+      pass
+    else:
+      return False
+  return any_float
+
+
 def acorr(blk, max_lag=None):
   """Autocorrelation of a block for lags 0..max_lag (default len(blk) - 1);
   same summation order as the reference, so the doubles are identical."""
-  blk = [float(v) for v in blk]
   if max_lag is None:
     max_lag = len(blk) - 1
-  if len(blk) == 0:
-    return [0.] * (max_lag + 1)
-  return acorr_frames(blk, len(blk), max_lag)[0].tolist()
+  if not _block_fits_engine(blk):
+    return [sum(blk[n] * blk[n + tau] for n in range(len(blk) - tau)) for tau in range(max_lag + 1)]
+  return acorr_frames([float(v) for v in blk], len(blk), max_lag)[0].tolist()
+
+
+def lag_matrix(blk, max_lag=None):
+  """The lag (covariance) matrix of a block as a list of lists (reference lazy_analysis.py:315-342): cell (j, i) is
+  the sum of ``blk[n - i] * blk[n - j]`` over every n that needs no padding.  Float blocks are summed on the GPU in
+  the reference's order (``lag_matrix_frames``)."""
+  if max_lag is None:
+    max_lag = len(blk) - 1
+  elif max_lag >= len(blk):
+    raise ValueError("Block length should be higher than order")
+  if max_lag < 0 or not _block_fits_engine(blk):
+    size = range(max_lag + 1)
+    return [[sum(blk[n - i] * blk[n - j] for n in range(max_lag, len(blk))) for i in size] for j in size]
+  return lag_matrix_frames([float(v) for v in blk], len(blk), max_lag)[0].tolist()
+
+
+def toeplitz(vect):
+  """The symmetric Toeplitz matrix (list of lists) with ``vect`` as its first row and column (lazy_lpc.py:44-49)."""
+  size = len(vect)
+  return [[vect[abs(col - row)] for col in range(size)] for row in range(size)]
 
 
 def levinson_durbin(acdata, order=None, device=0, exact=True):
@@ -178,17 +241,131 @@ def _autocor(blk, order=None, device=0):
     return _nautocor(blk, order, device=device)
 
 
+def _covar(blk, order=None, device=0):
+  """lpc.covar: the covariance method, its normal equations solved with numpy.linalg.pinv (reference
+  lazy_lpc.py:275-294).  The lag matrix comes from the GPU; the dense solve is the NumPy call the reference makes."""
+  from .filters import z
+  lagm = lag_matrix(blk, order)
+  phi = np.array(lagm)
+  solved = np.dot(np.linalg.pinv(phi[1:, 1:]), -phi[1:, :1])
+  coeffs = solved.T.tolist()[0]
+  filt = 1 + sum(ai * z ** -i for i, ai in enumerate(coeffs, 1))
+  filt.error = phi[0, 0] + sum(a * c for a, c in zip(lagm[0][1:], coeffs))
+  return filt
+
+
+def _kcovar(blk, order=None, device=0):
+  """lpc.kcovar: the covariance statistics solved greedily, one lattice-like stage per coefficient (reference
+  lazy_lpc.py:297-340): a basis B_0, B_1, ... of delayed filters orthogonal under the inner product the lag matrix
+  defines, the m-th coefficient being minus the projection of z**-m's partner on B_{m-1}.  ``ValueError("Unstable
+  filter")`` when a coefficient leaves (-1, 1), ``ZeroDivisionError`` when a basis filter has no energy."""
+  from .filters import ZFilter, z
+  phi = lag_matrix(blk, order)
+  order = len(phi) - 1
+
+  def inner(a, b):
+    total = 0
+    for i, ai in enumerate(a.numlist):
+      for j, bj in enumerate(b.numlist):
+        total = total + phi[i][j] * ai * bj
+    return total
+
+  analysis = ZFilter(1)
+  basis = [z ** -1]
+  energy = [inner(basis[0], basis[0])]
+  for m in itertools.count(1):
+    try:
+      k = -inner(analysis, z ** -m) / energy[m - 1]
+    except ZeroDivisionError:
+      raise ZeroDivisionError("Can't find next coefficient")
+    if k >= 1 or k <= -1:
+      raise ValueError("Unstable filter")
+    analysis += k * basis[m - 1]
+    if m >= order:
+      analysis.error = inner(analysis, analysis)
+      return analysis
+    delayed = z ** -(m + 1)
+    shares = [inner(delayed, basis[q]) / energy[q] for q in range(m)]
+    basis.append(delayed - sum(shares[q] * basis[q] for q in range(m)))
+    energy.append(inner(basis[m], basis[m]))
+
+
+def _monic_fir(fir_filt):
+  """The filter with its constant denominator divided out; feedback is a ValueError (lazy_lpc.py:384-388)."""
+  den = fir_filt.denominator
+  if len(den) != 1:
+    raise ValueError("Filter has feedback")
+  if den[0] != 1:
+    fir_filt = fir_filt / den[0]
+  return fir_filt
+
+
+def parcor(fir_filt):
+  """Generator of the partial correlation (reflection) coefficients of a FIR filter, last stage first: Levinson-
+  Durbin run backwards (reference lazy_lpc.py:343-395).  ParCorError when a coefficient of magnitude one stops the
+  decomposition."""
+  from .filters import z
+  fir_filt = _monic_fir(fir_filt)
+  for m in range(len(fir_filt.numerator) - 1, 0, -1):
+    k = fir_filt.numpoly[m]
+    yield k
+    mirrored = fir_filt(1 / z) * z ** -m
+    try:
+      fir_filt = (fir_filt - k * mirrored) / (1 - k ** 2)
+    except ZeroDivisionError:
+      raise ParCorError("Can't find next PARCOR coefficient")
+    fir_filt = (fir_filt - fir_filt.numpoly[0]) + 1   # the leading 1 again, whatever the rounding made of it
+
+
+def parcor_stable(filt):
+  """True when every reflection coefficient of the filter's denominator lies inside the unit circle (reference
+  lazy_lpc.py:398-425); a coefficient ON it (critical stability, or a ParCorError) counts as unstable."""
+  from .filters import ZFilter
+  try:
+    return all(abs(k) < 1 for k in parcor(ZFilter(filt.denpoly)))
+  except ParCorError:
+    return False
+
+
+def lsf(fir_filt):
+  """Line spectral frequencies of a FIR filter in rad/sample (reference lazy_lpc.py:428-457): the root angles of
+  the palindromic P = A + z**-1 A(1/z) and the antipalindromic Q = A - z**-1 A(1/z), each sorted, then interleaved
+  starting with the family that holds the lowest angle.  (The reference takes the angles with its elementwise
+  ``phase``, which NumPy 2 no longer lets it apply to an array; this is the same cmath.phase per root.)"""
+  from .filters import ZFilter, z
+  fir_filt = _monic_fir(fir_filt)
+  rev_filt = ZFilter(fir_filt.numerator[::-1]) * z ** -1
+  angles = []
+  for family in (fir_filt + rev_filt, fir_filt - rev_filt):
+    roots = np.roots(family.numerator[::-1])
+    angles.append(sorted(np.array([cmath.phase(r) for r in roots])))
+  out = ()
+  for pair in zip(*sorted(angles)):
+    out = out + pair
+  return out
+
+
+def lsf_stable(filt):
+  """True when the line spectral frequencies of the filter's denominator strictly alternate between the two
+  families (reference lazy_lpc.py:460-487); equal neighbours count as unstable."""
+  from .filters import ZFilter
+  lsf_data = lsf(ZFilter(filt.denpoly))
+  return all(lsf_data[i] < lsf_data[i + 1] for i in range(len(lsf_data) - 1))
+
+
 def _make_lpc():
   from .strategy import StrategyDict
   sd = StrategyDict("lpc")
   sd.strategy("autocor", "acorr", "autocorrelation", "auto_correlation")(_autocor)
   sd.strategy("nautocor", "nacorr", "nautocorrelation", "nauto_correlation")(_nautocor)
   sd.strategy("kautocor", "kacorr", "kautocorrelation", "kauto_correlation")(_kautocor)
+  sd.strategy("covar", "cov", "covariance", "ncovar", "ncov", "ncovariance")(_covar)
+  sd.strategy("kcovar", "kcov", "kcovariance")(_kcovar)
   return sd
 
 
 # The autocorrelation-method strategies, with the reference's default (``lpc(blk, order)`` is
 # ``lpc.autocor``).  ``kautocor`` is the one BASELINE/SURVEY put on the hot path (batched:
-# ``kautocor_frames``); the covariance methods (``covar`` / ``kcovar``) are out of scope (SURVEY.md
-# section 2).
+# ``kautocor_frames``); the covariance methods (``covar`` / ``kcovar``) take their lag matrix from the GPU and do
+# the reference's small solves on the host.
 lpc = _make_lpc()

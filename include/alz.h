@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 300 /* 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
+#define ALZ_VERSION 310 /* 0.3.1: + alz_lag_matrix_dev; 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
@@ -180,6 +180,13 @@ int alz_levinson_dev_ex(const double *r_dev, int64_t n_frames, int n_lags, int o
 /* acorr alone (lazy_analysis.py:277-312): r [n_frames, max_lag+1] */
 int alz_acorr_dev(const double *sig_dev, int64_t n_frames, int frame_len,
                   int64_t hop, int max_lag, double *r_dev, int device, void *stream);
+/* lag_matrix (lazy_analysis.py:315-342) for every frame: phi [n_frames, max_lag+1, max_lag+1], cell (j, i) =
+ * sum(blk[n - i] * blk[n - j] for n in max_lag .. frame_len - 1), added left to right from 0: the doubles of the
+ * reference.  These are the statistics lpc.covar (lazy_lpc.py:275-294) and lpc.kcovar (:297-340) start from; their
+ * small dense solves stay on the host (audiolazy_amd/lpc.py), like lpc.nautocor's.  max_lag >= frame_len is
+ * ALZ_E_ARG (the reference's ValueError("Block length should be higher than order"), :337-338). */
+int alz_lag_matrix_dev(const double *sig_dev, int64_t n_frames, int frame_len,
+                       int64_t hop, int max_lag, double *phi_dev, int device, void *stream);
 
 /* ---- either side of the path: mixdown and sample formats ---------------------------------- */
 /* ParallelFilter.__call__ (lazy_filters.py:1048-1054): the outputs of the filters fed with the

@@ -159,6 +159,24 @@ void alzo_acorr(const double *blk, int64_t len, int max_lag, double *r)
 }
 
 /*
+ * lag_matrix (lazy_analysis.py:335-342), row-major phi[j][i], P = max_lag + 1:
+ *   [[sum(blk[n - i] * blk[n - j] for n in range(max_lag, len(blk))) for i in range(P)] for j in range(P)]
+ * Python's sum starts from int 0 and adds left to right.  Returns -1 when max_lag >= len (the reference's ValueError).
+ */
+int alzo_lag_matrix(const double *blk, int64_t len, int max_lag, double *phi)
+{
+  if (max_lag < 0 || max_lag >= len) return -1;
+  const int P = max_lag + 1;
+  for (int j = 0; j < P; ++j)
+    for (int i = 0; i < P; ++i) {
+      double acc = 0.0;
+      for (int64_t n = max_lag; n < len; ++n) acc = acc + blk[n - i] * blk[n - j];
+      phi[j * P + i] = acc;
+    }
+  return 0;
+}
+
+/*
  * levinson_durbin (lazy_lpc.py:115-136), restated with the reference's dense
  * inner products (O(order^3) overall):
  *   inner(a, b) = sum(acdata[|i-j|] * a_i * b_j  for i.. for j..)   (:121-125)
