@@ -17,7 +17,8 @@ from .strategy import StrategyDict  # noqa: F401
 from .filters import (LinearFilter, LinearFilterProperties, ZFilter, z, FilterList, CascadeFilter, ParallelFilter,  # noqa: F401
                       comb, resonator, lowpass, highpass)
 from .auditory import erb, gammatone_erb_constants, gammatone, gammatone_bank, erb_space  # noqa: F401
-from .lpc import acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames  # noqa: F401
+from .lpc import (acorr, levinson_durbin, lpc, kautocor_frames, acorr_frames, lag_matrix, lag_matrix_frames,  # noqa: F401
+                  toeplitz, parcor, parcor_stable, lsf, lsf_stable)
 from .synth import white_noise, zeros, zeroes, ones, karplus_strong  # noqa: F401
 from .analysis import envelope, envelope_block, maverage, amdf, clip  # noqa: F401
 from . import maps  # noqa: F401

@@ -292,6 +292,95 @@ def lpc_strategy_cases():
   return out
 
 
+def covariance_cases():
+  """The covariance-method callers beside the path: ``lag_matrix`` (lazy_analysis.py:315-342), ``lpc.covar`` /
+  ``lpc.kcovar`` (lazy_lpc.py:275-340), ``parcor`` / ``parcor_stable`` (:343-425), ``toeplitz`` (:44-49).  Float
+  results as hex, integer ones as ``repr``; every case that raises stores the exception's type and text.  ``lsf`` /
+  ``lsf_stable`` are absent: the reference's own call raises under NumPy 2 (its elementwise ``phase`` on an array)."""
+  from audiolazy import lag_matrix, parcor, parcor_stable, toeplitz
+
+  def outcome(fn):
+    try:
+      return dict(value=fn())
+    except Exception as exc:
+      return dict(raises=type(exc).__name__, text=str(exc))
+
+  fr = noise(480, 4242)
+  res = resonator.z_exp(700 * Hz, 40 * Hz)
+  ar = list(res(noise(480 + 200, 5)))[200:]
+  periodic = [-1., 0., 1., 0.] * 50                       # README.rst:360-365: lpc.covar(blk, 4) = 1 + .5 z^-2 - .5 z^-4
+  ints = [1, 2, 3, 4, 5, -1, 2, -6, 3, 1]
+  mixed = [1, 2.5, -3, 4, .125, -1, 2, -6.75, 3, 1]
+  blocks = dict(noise=fr, resonant=ar, periodic=periodic, silent=[0.] * 40, short=noise(9, 11), ints=ints, mixed=mixed,
+                ramp=[float(i) for i in range(1, 13)])
+  out = dict(blocks={k: (hx(v) if k not in ("ints", "mixed") else repr(v)) for k, v in blocks.items()},
+             lag_matrix=[], covar=[], kcovar=[], parcor=[], parcor_stable=[], toeplitz=[])
+  for name, lag in (("noise", 2), ("noise", 16), ("resonant", 8), ("short", None), ("short", 0), ("short", 8),
+                    ("periodic", 4), ("silent", 3), ("mixed", 3)):
+    out["lag_matrix"].append(dict(blk=name, max_lag=lag, phi=hx(lag_matrix(blocks[name], lag))))
+  out["lag_matrix"].append(dict(blk="ints", max_lag=2, phi_repr=repr(lag_matrix(ints, 2))))
+  out["lag_matrix"].append(dict(blk="ints", max_lag=None, phi_repr=repr(lag_matrix(ints))))
+  for lag in (9, 10, 50):
+    out["lag_matrix"].append(dict(blk="short", max_lag=lag, **outcome(lambda: hx(lag_matrix(blocks["short"], lag)))))
+
+  def filt_outcome(fn):
+    def run():
+      f = fn()
+      return dict(coefs=hx(f.numlist), first_is_int=isinstance(f.numlist[0], int), den=hx(f.denlist),
+                  error=hx(f.error), error_type=type(f.error).__name__)
+    return outcome(run)
+
+  for name in ("noise", "resonant", "periodic", "ramp", "ints", "mixed", "silent", "short"):
+    for order in ((1, 2, 4, 8, 16) if name in ("noise", "resonant") else (1, 2, 4)):
+      out["covar"].append(dict(blk=name, order=order, **filt_outcome(lambda: lpc.covar(blocks[name], order))))
+      out["kcovar"].append(dict(blk=name, order=order, **filt_outcome(lambda: lpc.kcovar(blocks[name], order))))
+  for alias in ("cov", "covariance", "ncovar", "ncov", "ncovariance", "kcov", "kcovariance"):
+    f = lpc[alias](fr, 3)
+    out["covar"].append(dict(blk="noise", order=3, alias=alias, value=dict(
+        coefs=hx(f.numlist), first_is_int=isinstance(f.numlist[0], int), den=hx(f.denlist), error=hx(f.error),
+        error_type=type(f.error).__name__)))
+
+  def parcor_outcome(filt):
+    got = []
+    try:
+      for k in parcor(filt):
+        got.append(k)
+      return dict(ks=hx(got))
+    except Exception as exc:
+      return dict(ks=hx(got), raises=type(exc).__name__, text=str(exc))
+
+  designs = dict(
+    doctest=lambda: levinson_durbin([1, 2, 3, 4, 5, 3, 2, 1]),
+    kautocor8=lambda: lpc.kautocor(fr, 8),
+    kautocor16=lambda: lpc.kautocor(ar, 16),
+    gain2=lambda: ZFilter([2., 1., .5, -.25], [2.]),
+    unit_tap=lambda: 1 + z ** -1,                          # k = 1: 1 - k**2 = 0 -> ParCorError after the first value
+    mid_unit=lambda: 1 + .5 * z ** -1 + 1. * z ** -2,
+    feedback=lambda: (1 + .5 * z ** -1) / (1 - .3 * z ** -1),
+    constant=lambda: ZFilter([1.]),
+    ints=lambda: ZFilter([1, 2, 3]),
+  )
+  for name, make in designs.items():
+    f = make()
+    out["parcor"].append(dict(name=name, num=hx(f.numlist), den=hx(f.denlist), **parcor_outcome(f)))
+  stable_designs = dict(
+    resonator=lambda: resonator.z_exp(700 * Hz, 40 * Hz),
+    lowpass=lambda: lowpass.pole(1000 * Hz),
+    kautocor_inverse=lambda: 1 / lpc.kautocor(ar, 12),
+    outside=lambda: 1 / (1 - 2.5 * z ** -1 + z ** -2),
+    critical=lambda: 1 / (1 - z ** -1),
+    oscillator=lambda: 1 / (1 - 1.2 * z ** -1 + z ** -2),
+    fir=lambda: 1 + .5 * z ** -1,
+    double_pole=lambda: 1 / (1 - .9 * z ** -1) ** 2,
+  )
+  for name, make in stable_designs.items():
+    f = make()
+    out["parcor_stable"].append(dict(name=name, num=hx(f.numlist), den=hx(f.denlist), **outcome(lambda: parcor_stable(f))))
+  for vect in ([1, 2, 3], [1.5], [], [4., -2., 0., 1.]):
+    out["toeplitz"].append(dict(vect=repr(vect), matrix=repr(toeplitz(vect))))
+  return out
+
+
 def generic_item_cases():
   """Items the float64 engine does not take, through the reference's type-generic generator
   (lazy_filters.py:141-264): all-integer calls keep ints (doctest :735-742), complex numbers, Fractions,
@@ -700,6 +789,9 @@ if __name__ == "__main__":
   if len(sys.argv) > 1 and sys.argv[1] == "--only-composition":
     dump("composition.json", composition_cases())
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-covariance":
+    dump("covariance.json", covariance_cases())
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-lpc-strategies":
     dump("lpc_strategies.json", lpc_strategy_cases())
     sys.exit(0)
@@ -721,3 +813,4 @@ if __name__ == "__main__":
   dump("generic_items.json", generic_item_cases())
   dump("composition.json", composition_cases())
   dump("surface.json", surface_cases())
+  dump("covariance.json", covariance_cases())
