@@ -121,22 +121,28 @@ def lag_matrix_frames(sig, frame_len, max_lag, hop=None, device=0):
 # the reference's single-block operator surface (lazy_analysis.py:277-312,
 # lazy_lpc.py:52-136, 229-272), executed on the GPU one frame at a time
 # ---------------------------------------------------------------------------
-_EXACT_INT = 1 << 26   # |ints| below this multiply exactly in float64: the engine's doubles are then the reference's
-
-
 def _block_fits_engine(blk):
-  """The float64 engine takes a block of real floats (ints among them only while their products stay exact).  A
-  block of nothing but ints stays integer arithmetic in the reference (doctest lazy_analysis.py:298-306 prints ints),
-  and complex / Fraction / symbolic items never were floats: those run the reference's sums on the host."""
-  any_float = False
+  """The float64 engine takes a block of real floats, Python ints among them only while every product and every
+  partial sum of products stays an exact double (then its doubles are the reference's).  A block of nothing but ints
+  is integer arithmetic in the reference (doctest lazy_analysis.py:298-306 prints ints), and bools, NumPy integers,
+  complex / Fraction / symbolic items never were floats: those run the reference's sums on the host."""
+  any_float, biggest = False, 0
   for v in blk:
     if isinstance(v, (float, np.floating)):
       any_float = True
-    elif isinstance(v, (int, np.integer)) and not isinstance(v, bool) and -_EXACT_INT < v < _EXACT_INT:
-      pass
+    elif type(v) is int:
+      biggest = max(biggest, abs(v))
     else:
       return False
-  return any_float
+  return any_float and biggest * biggest * len(blk) < (1 << 53)
+
+
+def _int_runs(blk):
+  """all_int(lo, hi): whether blk[lo:hi] holds only ints (prefix counts of the non-ints)."""
+  seen = [0]
+  for v in blk:
+    seen.append(seen[-1] + (type(v) is not int))
+  return lambda lo, hi: seen[hi] == seen[lo]
 
 
 def acorr(blk, max_lag=None):
@@ -144,9 +150,18 @@ def acorr(blk, max_lag=None):
   same summation order as the reference, so the doubles are identical."""
   if max_lag is None:
     max_lag = len(blk) - 1
+  size = len(blk)
+  host_sum = lambda tau: sum(blk[n] * blk[n + tau] for n in range(size - tau))
   if not _block_fits_engine(blk):
-    return [sum(blk[n] * blk[n + tau] for n in range(len(blk) - tau)) for tau in range(max_lag + 1)]
-  return acorr_frames([float(v) for v in blk], len(blk), max_lag)[0].tolist()
+    return [host_sum(tau) for tau in range(max_lag + 1)]
+  lags = acorr_frames([float(v) for v in blk], size, max_lag)[0].tolist()
+  all_int = _int_runs(blk)
+  for tau in range(min(max_lag + 1, size + 1)):       # a lag whose terms are all int x int is an int in the reference
+    if all_int(0, size - tau) and all_int(tau, size):
+      lags[tau] = host_sum(tau)
+  for tau in range(size + 1, max_lag + 1):
+    lags[tau] = 0                                       # (no terms at all: sum() of nothing)
+  return lags
 
 
 def lag_matrix(blk, max_lag=None):
@@ -157,10 +172,17 @@ def lag_matrix(blk, max_lag=None):
     max_lag = len(blk) - 1
   elif max_lag >= len(blk):
     raise ValueError("Block length should be higher than order")
+  size = len(blk)
+  host_sum = lambda i, j: sum(blk[n - i] * blk[n - j] for n in range(max_lag, size))
   if max_lag < 0 or not _block_fits_engine(blk):
-    size = range(max_lag + 1)
-    return [[sum(blk[n - i] * blk[n - j] for n in range(max_lag, len(blk))) for i in size] for j in size]
-  return lag_matrix_frames([float(v) for v in blk], len(blk), max_lag)[0].tolist()
+    return [[host_sum(i, j) for i in range(max_lag + 1)] for j in range(max_lag + 1)]
+  phi = lag_matrix_frames([float(v) for v in blk], size, max_lag)[0].tolist()
+  all_int = _int_runs(blk)
+  for j in range(max_lag + 1):                          # cells whose terms are all int x int are ints in the reference
+    for i in range(max_lag + 1):
+      if all_int(max_lag - i, size - i) and all_int(max_lag - j, size - j):
+        phi[j][i] = host_sum(i, j)
+  return phi
 
 
 def toeplitz(vect):

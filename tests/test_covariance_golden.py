@@ -105,7 +105,29 @@ def oracle_lags(monkeypatch):
     assert len(sig) == frame_len
     return oracle.lag_matrix(sig, max_lag)[None]
   monkeypatch.setattr(mod, "lag_matrix_frames", frames)
+  monkeypatch.setattr(mod, "acorr_frames", lambda sig, frame_len, max_lag, hop=None, device=0:
+                      oracle.acorr(np.asarray(sig, dtype=np.float64), max_lag)[None])
   return mod
+
+
+def test_cells_without_a_float_term_stay_integers(oracle_lags):
+  """In a block that mixes ints and floats the reference's sums start from int 0: a cell (or lag) whose terms are
+  all int x int comes back as an int, and so does the empty sum of a lag past the block."""
+  import audiolazy_amd as al
+  blk = [-4, 0, -2, 4, 4, -3, -3, 1, 0.2493200140664249, 4, 1.8972099364840025, -4, 0.3933814750538396]
+  for lag in (None, 2, 5):
+    m = len(blk) - 1 if lag is None else lag
+    want = [[sum(blk[n - i] * blk[n - j] for n in range(m, len(blk))) for i in range(m + 1)] for j in range(m + 1)]
+    got = al.lag_matrix(blk, lag)
+    assert repr(got) == repr(want)
+  assert any(isinstance(v, int) for row in al.lag_matrix(blk) for v in row)
+  for lag in (None, 3, len(blk) + 2):
+    m = len(blk) - 1 if lag is None else lag
+    want = [sum(blk[n] * blk[n + tau] for n in range(len(blk) - tau)) for tau in range(m + 1)]
+    assert repr(al.acorr(blk, lag)) == repr(want)
+  assert repr(al.acorr([.5, .25], 4)) == repr([.3125, .125, 0, 0, 0])
+  huge = [2 ** 30, .5, 2 ** 30]                          # products past 2**53: not the engine's block
+  assert repr(al.acorr(huge)) == repr([sum(huge[n] * huge[n + t] for n in range(3 - t)) for t in range(3)])
 
 
 @pytest.mark.parametrize("family", ["covar", "kcovar"])
