@@ -176,8 +176,9 @@ def test_parcor_stable():
 
 
 def test_lsf_alternates_for_a_minimum_phase_filter():
-  """The reference's lsf cannot run under NumPy 2 (its elementwise phase builds an np.mat), so no golden: the
-  properties it documents instead -- angles of P and Q interleave, starting with the lowest, for a stable filter;
+  """The reference's lsf cannot run under NumPy 2 (its elementwise phase builds an np.mat), so no generated golden
+  (tests/test_reference_lpc.py holds it to the hand-checked vectors of the reference's tests); here the properties it
+  documents -- angles of P and Q interleave, starting with the lowest, for a stable filter;
   0 and pi are the trivial roots; an unstable denominator breaks the alternation."""
   import math
   import audiolazy_amd as al
