@@ -374,6 +374,14 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_STORER
 #define ALZ_DUO_STORER 1     // a third wave stores the finished tiles (not in the FMA mode; profiles/NOTES_r03.md 11)
 #endif
+// variant builds (FMA mode): 1 = the storing wave, non-temporal tiles and (with ALZ_PACE_ALL) the paced pass for the fused
+// instantiations too; ALZ_DUO_FMA_ORDER 1 = fma(na1, y1, fma(na2, y2, p)): one dependent operation per step instead of two
+#ifndef ALZ_DUO_FMA3
+#define ALZ_DUO_FMA3 0
+#endif
+#ifndef ALZ_DUO_FMA_ORDER
+#define ALZ_DUO_FMA_ORDER 0
+#endif
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
@@ -395,8 +403,8 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
 template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0, bool NT = false>
-__global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
-  constexpr bool STORER = ALZ_DUO_STORER && !FMA && !NOSTORE;    // a third wave stores the finished tiles
+__global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
+  constexpr bool STORER = ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTORE;    // a third wave stores the finished tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -533,7 +541,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
       // has most of the interval to spare: 4096 channels x 2^20 282 - 293 -> 309 - 340 Gsamples/s over three boxes
       // (channel-major 267 - 313 -> 319 - 356; profiles/NOTES_r04.md 4).
       bool paced = false;
-      if constexpr (((PB == 1u && PA == 1u) || ALZ_PACE_ALL) && !FMA && !NOSTORE) paced = p.aux_pace > 0;
+      if constexpr (((PB == 1u && PA == 1u) || ALZ_PACE_ALL) && (!FMA || ALZ_DUO_FMA3) && !NOSTORE) paced = p.aux_pace > 0;
       if (paced) {
         const int units = p.aux_pace & 15;
         if (p.aux_pace & 16) {                   // eighths
@@ -682,8 +690,12 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && !FMA && !NOSTORE) ? 192 : 128) v
           double acc = pr[k % 3][u];
           double t2n = 0.0;
           if constexpr (FMA) {
-            if constexpr (PA & 1u) acc = __builtin_fma(na1, m1, acc);
-            if constexpr (PA & 2u) acc = __builtin_fma(na2, m2, acc);
+            if constexpr (ALZ_DUO_FMA_ORDER && PA == 3u) {
+              acc = __builtin_fma(na1, m1, __builtin_fma(na2, m2, acc));
+            } else {
+              if constexpr (PA & 1u) acc = __builtin_fma(na1, m1, acc);
+              if constexpr (PA & 2u) acc = __builtin_fma(na2, m2, acc);
+            }
           } else if constexpr (PA == 3u) {
             // the product with y[n-2] was formed one step ago (t2), so only mul -> add -> add
             // sits on the serial chain and the other product fills the first latency slot
@@ -820,7 +832,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
   const bool prefer_single = g == 16 && lanes >= single_from && !ch;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
-  const bool nt_tiles = io.stream_once && !ch && !io.fused && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
+  const bool nt_tiles = io.stream_once && !ch && (!io.fused || ALZ_DUO_FMA3) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
@@ -837,6 +849,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
                    : (cm ? pick_duo_pattern<true, false, false, false, 1>(sec.present_b, sec.present_a)
                          : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a));
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
+#if ALZ_DUO_FMA3
+    if (io.fused && nt_tiles)
+      duo_fma = true, duo = cm ? pick_duo_pattern<true, true, false, false, 0, true>(sec.present_b, sec.present_a)
+                               : pick_duo_pattern<false, true, false, false, 0, true>(sec.present_b, sec.present_a);
+    else
+#endif
     if (io.fused)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
@@ -876,7 +894,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // Measured on three boxes (profiles/r04_duo_patterns.log): 4096 channels x 2^20 time-major +2 / +13 / +10 ... 16 %,
   // channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three pauses are better on one box and worse on the
   // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
-  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
+  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!io.fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
@@ -889,7 +907,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
     if (rc) return rc;
   }
   if (ch && ch->n_chunks > 65535) return ALZ_OK;
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? ((ALZ_DUO_STORER && !duo_fma && !nostore) ? 192 : 128) : 64), lds,
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? ((ALZ_DUO_STORER && (!duo_fma || ALZ_DUO_FMA3) && !nostore) ? 192 : 128) : 64), lds,
                      stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
