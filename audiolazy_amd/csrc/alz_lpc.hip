@@ -405,6 +405,57 @@ __global__ __launch_bounds__(256) void k_lag_matrix(const double *__restrict__ s
   out[cell] = acc;
 }
 
+// The same cells, a lane per (frame, row j): the P sums of a row live in registers and every step multiplies the
+// row's own sample blk[n - j] into a window of the last P samples that is shared by all rows of the frame -- 2 P
+// FP64 operations per two (cached) loads instead of two loads per multiply-add.  The window rotates through its
+// registers (logical blk[n - k] sits in slot (k - phase) mod P), so a step moves nothing.  Each sum still adds its
+// terms in ascending n from 0.0: the reference's doubles.
+template <int P>
+__global__ __launch_bounds__(256) void k_lag_rows(const double *__restrict__ sig, int64_t n_frames, int frame_len,
+                                                   int64_t hop, double *__restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_frames * P) return;
+  const int64_t f = row / P;
+  const int j = (int)(row - f * P);
+  const double *blk = sig + f * hop;
+  double acc[P], win[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    acc[i] = 0.0;
+    win[i] = blk[P - 1 - i];                               // phase 0 at n = P - 1: slot k holds blk[n - k]
+  }
+  for (int n0 = P - 1; n0 < frame_len; n0 += P) {
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph) {
+      const int n = n0 + ph;
+      if (n < frame_len) {                                 // (uniform: every lane of the launch has the same length)
+        const double bj = blk[n - j];
+#pragma unroll
+        for (int i = 0; i < P; ++i) acc[i] = acc[i] + win[(i + P - ph) % P] * bj;
+        if (n + 1 < frame_len) win[(2 * P - 1 - ph) % P] = blk[n + 1];   // the oldest sample's slot takes the next one
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < P; ++i) out[row * P + i] = acc[i];
+}
+
+typedef void (*lag_rows_fn)(const double *, int64_t, int, int64_t, double *);
+static lag_rows_fn pick_lag_rows(int P) {
+  switch (P) {
+    case 3: return k_lag_rows<3>;
+    case 5: return k_lag_rows<5>;
+    case 9: return k_lag_rows<9>;
+    case 11: return k_lag_rows<11>;
+    case 13: return k_lag_rows<13>;
+    case 17: return k_lag_rows<17>;
+    case 21: return k_lag_rows<21>;
+    case 25: return k_lag_rows<25>;
+    case 33: return k_lag_rows<33>;
+    default: return nullptr;
+  }
+}
+
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
 template <int LEV, bool FMA = false, int RING = 3>
@@ -714,11 +765,18 @@ int alz_lag_matrix_dev(const double *sig_dev, int64_t n_frames, int frame_len, i
   int rc = ALZ_OK;
   alz::note_kernel("");
   if (n_frames > 0) {
-    const int64_t blocks = (n_frames * cells + 255) / 256;
-    alz::k_lag_matrix<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(sig_dev, n_frames, frame_len, hop,
-                                                                                    max_lag + 1, phi_dev);
+    const int P = max_lag + 1;
+    if (alz::lag_rows_fn rows = alz::pick_lag_rows(P)) {    // the curated orders: a lane per row of the matrix
+      const int64_t blocks = (n_frames * P + 255) / 256;
+      rows<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(sig_dev, n_frames, frame_len, hop, phi_dev);
+      alz::note_kernel("k_lag_matrix(rows)", true);
+    } else {
+      const int64_t blocks = (n_frames * cells + 255) / 256;
+      alz::k_lag_matrix<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(sig_dev, n_frames, frame_len, hop, P,
+                                                                                      phi_dev);
+      alz::note_kernel("k_lag_matrix", true);
+    }
     if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_lag_matrix launch failed");
-    alz::note_kernel("k_lag_matrix", true);
   }
   if (prev != device) (void)hipSetDevice(prev);
   return rc;
