@@ -569,6 +569,78 @@ __global__ __launch_bounds__(64) void k_cgemm_dot(CScanArgs p, const double *__r
   }
 }
 
+// The direct-load form with the scalar loads of the NEXT pair of samples issued before the current pair's arithmetic
+// (CGEMM_ASM=1): hand-placed s_load_dwordx16 + s_waitcnt, because the compiler waits for a scalar load where it issues it.
+// NS x 16 SGPRs per buffer, two buffers: NS = 2 fits the SGPR file.
+template <int NS, int SPLIT>
+__global__ __launch_bounds__(64) void k_cgemm_dot_asm(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge,
+                                                      double *__restrict__ part) {
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef double dbl8 __attribute__((ext_vector_type(8)));
+  static_assert(NS == 2, "two buffers of NS x 16 SGPRs");
+  const int lane = threadIdx.x;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t c0 = (int64_t)blockIdx.y * NS;
+  const int seg = blockIdx.z;
+  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls, m1 = m0 + Ls;
+  const double *xrow = p.x + j * p.L;
+  double acc[NS][4][2];
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
+  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
+  const double *ha = hr + ((c0 + 0) * p.L + m0) * 4, *hb = hr + ((c0 + 1) * p.L + m0) * 4;   // (wave-uniform)
+  dbl8 ca, cb, na, nb;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(ca), "=&s"(cb) : "s"(ha), "s"(hb) : "memory");
+  dbl2 v = *reinterpret_cast<const dbl2 *>(xrow + m0);
+  for (int64_t m = m0; m < m1; m += 2) {
+    const int64_t step = m + 2 < m1 ? 8 : 0;                    // (the last step requests its own pair again)
+    ha += step; hb += step;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(na), "=&s"(nb) : "s"(ha), "s"(hb) : "memory");
+    const dbl2 vn = *reinterpret_cast<const dbl2 *>(xrow + (m + 2 < m1 ? m + 2 : m));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0][s][0] = __builtin_fma(ca[s], v.x, acc[0][s][0]);
+      acc[0][s][1] = __builtin_fma(ca[s], xprev, acc[0][s][1]);
+      acc[0][s][0] = __builtin_fma(ca[4 + s], v.y, acc[0][s][0]);
+      acc[0][s][1] = __builtin_fma(ca[4 + s], v.x, acc[0][s][1]);
+      acc[1][s][0] = __builtin_fma(cb[s], v.x, acc[1][s][0]);
+      acc[1][s][1] = __builtin_fma(cb[s], xprev, acc[1][s][1]);
+      acc[1][s][0] = __builtin_fma(cb[4 + s], v.y, acc[1][s][0]);
+      acc[1][s][1] = __builtin_fma(cb[4 + s], v.x, acc[1][s][1]);
+    }
+    xprev = v.y;
+    v = vn;
+    // the requested pair has landed; tying the buffers to the wait keeps their copies behind it
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
+    ca = na;
+    cb = nb;
+  }
+  const int64_t V = p.K * p.C;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    const int64_t c = c0 + a;
+    double xm1 = 0.0, xm2 = 0.0;
+    if (seg == 0) {
+      xm1 = j > 0 ? xrow[-1] : (p.nb[0] > 1 ? p.xh[0][0 * p.C + c] : 0.0);
+      xm2 = j > 0 ? xrow[-2] : (p.nb[0] > 2 ? p.xh[0][1 * p.C + c] : 0.0);
+    }
+    const double *e = edge + c * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        double z = acc[a][s][k];
+        z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
+        z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
+        part[((int64_t)(seg * 8 + 2 * s + k)) * V + c * p.K + j] = z;
+      }
+    }
+  }
+}
+
 // The same sums with the input staged through LDS (CGEMM_LDS=1): a lane reading its own row costs the vector cache one
 // line access per lane and instruction (64 cycles per 16-byte load, NOTES_r04.md section 2); here every 16 samples of the
 // wave's 64 rows arrive as eight 1 KiB global_load_lds transfers (8 rows x 128 B each: 8 line accesses), XOR-swizzled on
@@ -709,7 +781,10 @@ static int cgemm_zero_state_pass(const CScanArgs &p, ScanScratch *scratch, bool 
     hipLaunchKernelGGL(k_cgemm_tables, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, stream, p, g_cgemm.hr, g_cgemm.edge);
     g_cgemm.key = scratch; g_cgemm.L = p.L; g_cgemm.C = p.C;
   }
-#if defined(CGEMM_LDS) && CGEMM_LDS
+#if defined(CGEMM_ASM) && CGEMM_ASM
+  hipLaunchKernelGGL((k_cgemm_dot_asm<NS, SPLIT>), dim3((unsigned)(p.K / 64), (unsigned)(p.C / NS), SPLIT), dim3(64), 0, stream, p,
+                     (const double *)g_cgemm.hr, (const double *)g_cgemm.edge, g_cgemm.part);
+#elif defined(CGEMM_LDS) && CGEMM_LDS
   if (p.L % (16 * SPLIT) != 0) return fail(ALZ_E_UNSUPPORTED, "dot-product zero-state pass (LDS form): shape");
   hipLaunchKernelGGL((k_cgemm_dot_lds<NS, SPLIT>), dim3((unsigned)(p.K / 64), (unsigned)(p.C / NS), SPLIT), dim3(64), 2 * 8192, stream, p,
                      (const double *)g_cgemm.hr, (const double *)g_cgemm.edge, g_cgemm.part);
