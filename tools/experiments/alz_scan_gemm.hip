@@ -745,6 +745,106 @@ __global__ __launch_bounds__(64) void k_cgemm_dot_lds(CScanArgs p, const double 
   }
 }
 
+// Both remedies together (CGEMM_LDS=2; written at the end of round 4, compiled, NOT yet run): rows through LDS as in
+// k_cgemm_dot_lds, the responses of the next pair of samples requested by hand before the current pair's arithmetic as in
+// k_cgemm_dot_asm.  (The compiler's own lgkmcnt waits for the LDS reads do not know of the scalar loads in flight; they only
+// become more conservative by them: a count reached with extra operations outstanding needs more completions, never fewer.)
+template <int NS, int SPLIT>
+__global__ __launch_bounds__(64) void k_cgemm_dot_lds_asm(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge,
+                                                          double *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char cg_smem2[];
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef double dbl8 __attribute__((ext_vector_type(8)));
+  static_assert(NS == 2, "two buffers of NS x 16 SGPRs");
+  constexpr int RING = 2;
+  const int lane = threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.x * 64, j = j0 + lane;
+  const int64_t c0 = (int64_t)blockIdx.y * NS;
+  const int seg = blockIdx.z;
+  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls;
+  const int nsteps = (int)(Ls / 16);
+  const double *xrow = p.x + j * p.L;
+  const unsigned lds0 = (unsigned)(uintptr_t)cg_smem2;
+  auto queue = [&](int st) {
+    const unsigned slot = lds0 + (unsigned)(st % RING) * 8192u;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = 8 * t + lane / 8;
+      const int piece = (lane % 8) ^ (row & 7);
+      cg_dma16(p.x + (j0 + row) * p.L + m0 + 16 * st + 2 * piece, slot + t * 1024);
+    }
+  };
+  double acc[NS][4][2];
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
+  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
+  const double *ha = hr + ((c0 + 0) * p.L + m0) * 4, *hb = hr + ((c0 + 1) * p.L + m0) * 4;   // (wave-uniform)
+  dbl8 ca, cb, na, nb;
+  queue(0);
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(ca), "=&s"(cb) : "s"(ha), "s"(hb) : "memory");
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) {
+      queue(st + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char *slot = cg_smem2 + (st % RING) * 8192 + lane * 128;
+    double cur[16];
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      const dbl2 v = *reinterpret_cast<const dbl2 *>(slot + ((pc ^ (lane & 7)) * 16));
+      cur[2 * pc] = v.x;
+      cur[2 * pc + 1] = v.y;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      const int adv = (u == 14 && st + 1 == nsteps) ? 0 : 8;       // (the very last pair requests itself again)
+      ha += adv; hb += adv;
+      asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(na), "=&s"(nb) : "s"(ha), "s"(hb) : "memory");
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][s][0] = __builtin_fma(ca[s], cur[u], acc[0][s][0]);
+        acc[0][s][1] = __builtin_fma(ca[s], xprev, acc[0][s][1]);
+        acc[0][s][0] = __builtin_fma(ca[4 + s], cur[u + 1], acc[0][s][0]);
+        acc[0][s][1] = __builtin_fma(ca[4 + s], cur[u], acc[0][s][1]);
+        acc[1][s][0] = __builtin_fma(cb[s], cur[u], acc[1][s][0]);
+        acc[1][s][1] = __builtin_fma(cb[s], xprev, acc[1][s][1]);
+        acc[1][s][0] = __builtin_fma(cb[4 + s], cur[u + 1], acc[1][s][0]);
+        acc[1][s][1] = __builtin_fma(cb[4 + s], cur[u], acc[1][s][1]);
+      }
+      xprev = cur[u + 1];
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
+      ca = na;
+      cb = nb;
+    }
+  }
+  const int64_t V = p.K * p.C;
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    const int64_t c = c0 + a;
+    double xm1 = 0.0, xm2 = 0.0;
+    if (seg == 0) {
+      xm1 = j > 0 ? xrow[-1] : (p.nb[0] > 1 ? p.xh[0][0 * p.C + c] : 0.0);
+      xm2 = j > 0 ? xrow[-2] : (p.nb[0] > 2 ? p.xh[0][1 * p.C + c] : 0.0);
+    }
+    const double *e = edge + c * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        double z = acc[a][s][k];
+        z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
+        z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
+        part[((int64_t)(seg * 8 + 2 * s + k)) * V + c * p.K + j] = z;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_cgemm_reduce(CScanArgs p, const double *__restrict__ part, int split) {
   const int64_t V = p.K * p.C;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -783,6 +883,10 @@ static int cgemm_zero_state_pass(const CScanArgs &p, ScanScratch *scratch, bool 
   }
 #if defined(CGEMM_ASM) && CGEMM_ASM
   hipLaunchKernelGGL((k_cgemm_dot_asm<NS, SPLIT>), dim3((unsigned)(p.K / 64), (unsigned)(p.C / NS), SPLIT), dim3(64), 0, stream, p,
+                     (const double *)g_cgemm.hr, (const double *)g_cgemm.edge, g_cgemm.part);
+#elif defined(CGEMM_LDS) && CGEMM_LDS == 2
+  if (p.L % (16 * SPLIT) != 0) return fail(ALZ_E_UNSUPPORTED, "dot-product zero-state pass (LDS form): shape");
+  hipLaunchKernelGGL((k_cgemm_dot_lds_asm<NS, SPLIT>), dim3((unsigned)(p.K / 64), (unsigned)(p.C / NS), SPLIT), dim3(64), 2 * 8192, stream, p,
                      (const double *)g_cgemm.hr, (const double *)g_cgemm.edge, g_cgemm.part);
 #elif defined(CGEMM_LDS) && CGEMM_LDS
   if (p.L % (16 * SPLIT) != 0) return fail(ALZ_E_UNSUPPORTED, "dot-product zero-state pass (LDS form): shape");
