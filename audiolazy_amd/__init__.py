@@ -12,7 +12,7 @@ from ._ffi import ParCorError, load as load_library, device_count, last_kernel  
 from .stream import (Stream, ControlStream, Streamix, StreamTeeHub, MemoryLeakWarning, blocks, thub, tostream,  # noqa: F401
                      avoid_stream, cycle, repeat, count, chain, zero_pad, rint)
 from .bank import FilterBank, memory_to_hist, sections_of, block_size, mix_tracks, mix_sets  # noqa: F401
-from .poly import Poly, x  # noqa: F401
+from .poly import Poly, x, lagrange, resample  # noqa: F401
 from .strategy import StrategyDict  # noqa: F401
 from .filters import (LinearFilter, LinearFilterProperties, ZFilter, z, FilterList, CascadeFilter, ParallelFilter,  # noqa: F401
                       comb, resonator, lowpass, highpass)

@@ -318,3 +318,77 @@ def _sum_text(parts):
 IGNORED_CLASSES.append(Poly)
 
 x = Poly({1: 1})
+
+
+# ---------------------------------------------------------------------------
+# Waring-Lagrange interpolation and the resampler built on it (reference lazy_poly.py:493-603): host arithmetic, one
+# interpolation per output sample like the reference (not one of the GPU paths).
+# ---------------------------------------------------------------------------
+def _make_lagrange():
+  import functools
+  import operator
+  from .strategy import StrategyDict
+  sd = StrategyDict("lagrange")
+
+  def func(pairs):
+    """The interpolating function of the points ``(x, y)`` in ``pairs``: ``f(k) = sum_j y_j prod_{r != j} (k - x_r) / (x_j - x_r)``,
+    the factors multiplied and the terms added left to right as the reference does (lazy_poly.py:496-516)."""
+    xv, yv = zip(*pairs)
+
+    def interpolator(k):
+      total = 0
+      for j, rj in enumerate(xv):
+        weight = functools.reduce(operator.mul, ((k - rk) / (rj - rk) for rk in xv if rj != rk))
+        total = total + yv[j] * weight
+      return total
+    return interpolator
+
+  def poly(pairs):
+    """The same interpolator as a Poly in ``x`` (lazy_poly.py:519-536)."""
+    return func(pairs)(x)
+
+  sd.strategy("func")(func)
+  sd.strategy("poly")(poly)
+  return sd
+
+
+lagrange = _make_lagrange()
+
+
+def _resample(sig, old=1, new=1, order=3, zero=0.):
+  """Generic resampler: every output is the Waring-Lagrange interpolation of the ``order + 1`` neighbouring input samples
+  at a position that advances by ``old / new`` per output (a number, or an iterable read once per output); the input is
+  thought of as preceded by ``zero`` and is NOT padded at its end (reference lazy_poly.py:538-603).  The stream ends when
+  the input does (the reference's generator dies with a RuntimeError there on Python >= 3.7)."""
+  from collections import deque
+  from .misc import rint
+  sig = Stream(sig)
+  threshold = .5 * (order + 1)
+  step = old / new
+  data = deque([zero] * (order + 1), maxlen=order + 1)
+  data.extend(sig.take(rint(threshold)))
+  idx = int(threshold)
+  source = iter(sig)
+  steps = iter(step) if hasattr(step, "__iter__") else None
+  while True:
+    yield lagrange(enumerate(data))(idx)
+    if steps is None:
+      idx += step
+    else:
+      try:
+        idx += next(steps)
+      except StopIteration:
+        return
+    while idx > threshold:
+      try:
+        data.append(next(source))
+      except StopIteration:
+        return
+      idx -= 1
+
+
+def resample(sig, old=1, new=1, order=3, zero=0.):
+  return Stream(_resample(sig, old=old, new=new, order=order, zero=zero))
+
+
+resample.__doc__ = _resample.__doc__

@@ -381,6 +381,44 @@ def covariance_cases():
   return out
 
 
+def lagrange_cases():
+  """``lagrange.func`` / ``lagrange.poly`` / ``resample`` (lazy_poly.py:493-603) on seeded point sets and signals: values as
+  ``repr`` (ints stay ints, Fractions are not used), Poly terms as sorted (power, value) reprs, resampled items as hex."""
+  from audiolazy import lagrange, resample
+  rnd = random.Random(20260927)
+  out = dict(func=[], poly=[], resample=[])
+  for case in range(120):
+    n = rnd.randint(1, 6)
+    xs = rnd.sample(range(-8, 9), n) if case % 2 else [rnd.uniform(-3, 3) for _ in range(n)]
+    ys = [rnd.choice([rnd.randint(-5, 5), rnd.uniform(-2, 2)]) for _ in range(n)]
+    pairs = [list(pr) for pr in zip(xs, ys)]
+    ks = [0, 1.5, -2, 7, rnd.uniform(-4, 4)]
+
+    def value(k):
+      try:
+        return repr(lagrange([tuple(pr) for pr in pairs])(k))
+      except Exception as exc:
+        return "raises " + type(exc).__name__
+    out["func"].append(dict(pairs=repr(pairs), ks=repr(ks), values=[value(k) for k in ks]))
+    try:
+      terms = repr(sorted(lagrange.poly([tuple(pr) for pr in pairs]).terms()))
+    except Exception as exc:
+      terms = "raises " + type(exc).__name__
+    out["poly"].append(dict(pairs=repr(pairs), terms=terms))
+  for case in range(40):
+    sig = [rnd.uniform(-1, 1) for _ in range(60)]
+    old, new = rnd.choice([(1, 1), (1, 2), (3, 2), (1, 1.7), (2, 1), (1, .5), (44100, 48000)])
+    order = rnd.choice([1, 2, 3, 4, 5])
+    zero = rnd.choice([0., 0, .25])
+    got = resample(list(sig), old=old, new=new, order=order, zero=zero).take(12)
+    out["resample"].append(dict(sig=hx(sig), old=old, new=new, order=order, zero=repr(zero), y=hx(got)))
+  sig = [rnd.uniform(-1, 1) for _ in range(80)]
+  steps = [rnd.choice([.5, 1., 1.25, .75]) for _ in range(30)]
+  got = resample(list(sig), old=Stream(list(steps)), new=1, order=3).take(20)      # a time-varying step, one value per output
+  out["resample"].append(dict(sig=hx(sig), old_series=hx(steps), new=1, order=3, zero=repr(0.), y=hx(got)))
+  return out
+
+
 def generic_item_cases():
   """Items the float64 engine does not take, through the reference's type-generic generator
   (lazy_filters.py:141-264): all-integer calls keep ints (doctest :735-742), complex numbers, Fractions,
@@ -789,6 +827,9 @@ if __name__ == "__main__":
   if len(sys.argv) > 1 and sys.argv[1] == "--only-composition":
     dump("composition.json", composition_cases())
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "--only-lagrange":
+    dump("lagrange.json", lagrange_cases())
+    sys.exit(0)
   if len(sys.argv) > 1 and sys.argv[1] == "--only-covariance":
     dump("covariance.json", covariance_cases())
     sys.exit(0)
@@ -814,3 +855,4 @@ if __name__ == "__main__":
   dump("composition.json", composition_cases())
   dump("surface.json", surface_cases())
   dump("covariance.json", covariance_cases())
+  dump("lagrange.json", lagrange_cases())
