@@ -63,6 +63,10 @@ struct alz_bank {
   double *expand_in = nullptr;          // OUTER bank with few inputs: the input with one column / row per channel
   uint64_t expand_in_bytes = 0;
   int64_t time_parallel = 0;            // 0 off (default), -1 automatic chunk length, > 0 chunk length
+  // every section's input history is its predecessor's output history: true after reset and after every processed
+  // block, and after a set_state whose rows say so (checked there) -- the dot-product zero-state pass of the fused
+  // time-parallel cascade chains chunk 0 like every other chunk and needs it (alz_scan.hip)
+  bool state_consistent = true;
   std::vector<alz::ScanScratch> scan;   // per section: chunk states and the cached transition matrices
   // a first section with a long numerator as TWO sections that compute the same doubles: its numerator alone (feedback-
   // free) and 1 / its denominator (b = [1]), on the section's own state slabs -- for the time-parallel mode (process_dev)
@@ -341,6 +345,8 @@ int alz_bank_destroy(alz_bank_t *h) {
     if (sc.vyh) (void)hipFree(sc.vyh);
     if (sc.power) (void)hipFree(sc.power);
     if (sc.zbuf) (void)hipFree(sc.zbuf);
+    if (sc.hr) (void)hipFree(sc.hr);
+    if (sc.edge) (void)hipFree(sc.edge);
     if (sc.look_err) (void)hipHostFree(sc.look_err);
   }
   delete h;
@@ -356,6 +362,19 @@ int alz_bank_channels(const alz_bank_t *h, int64_t *channels) {
 static int put_state(alz_bank *h, const double *xh_host, const double *yh_host) {
   // host rows [channels][thx] -> per-section device slabs [nb-1][channels]
   const int64_t C = h->channels;
+  // self-consistent: x history of section s + 1 == y history of section s, as far as both are kept (a partial
+  // update -- one of the two arrays missing -- cannot be checked against what the device holds: not consistent)
+  h->state_consistent = true;
+  for (int s = 0; s + 1 < h->n_sections && h->state_consistent; ++s) {
+    const int64_t kx = h->nb[s + 1] - 1, ky = h->na[s] - 1;
+    if (kx <= 0) continue;
+    if (!xh_host || !yh_host || ky < kx) { h->state_consistent = false; break; }
+    for (int64_t c = 0; c < C && h->state_consistent; ++c)
+      for (int64_t k = 0; k < kx; ++k) {
+        const double xv = xh_host[c * h->thx + h->hx_off[s + 1] + k], yv = yh_host[c * h->thy + h->hy_off[s] + k];
+        if (memcmp(&xv, &yv, sizeof(double)) != 0) { h->state_consistent = false; break; }
+      }
+  }
   std::vector<double> tmp;
   for (int s = 0; s < h->n_sections; ++s) {
     const int64_t kx = h->nb[s] - 1, ky = h->na[s] - 1;
@@ -432,8 +451,19 @@ int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host) {
   return ALZ_OK;
 }
 
+static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, int64_t n, int layout,
+                            int64_t ldx, int64_t ldy, void *stream);
+
 int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int64_t n, int layout,
                          int64_t ldx, int64_t ldy, void *stream) {
+  const int rc = process_dev_impl(h, x_dev, y_dev, n, layout, ldx, ldy, stream);
+  // two samples through every section make each section's input history its predecessor's output history
+  if (rc == ALZ_OK && h && n >= 2) h->state_consistent = true;
+  return rc;
+}
+
+static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, int64_t n, int layout,
+                            int64_t ldx, int64_t ldy, void *stream) {
   if (!h || !x_dev || !y_dev) return fail(ALZ_E_ARG, "NULL argument");
   if (n < 0) return fail(ALZ_E_ARG, "negative block length");
   if (layout != ALZ_TIME_MAJOR && layout != ALZ_CHAN_MAJOR) return fail(ALZ_E_ARG, "bad layout");
@@ -496,18 +526,21 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
 
   // opt-in time-parallel mode, whole fused cascade at once (channel-major blocks): the chunks of the time axis
   // become the cascade kernel's channels, read straight from the un-expanded input (alz_scan.hip)
-  if (h->time_parallel != 0 && h->n_sections >= 2 && layout == ALZ_CHAN_MAJOR && x_dev != y_dev) {
+  // (time-major blocks -- the reference's vector-valued samples -- since round 5: their chunks are groups of 64
+  // adjacent channels, so the bank's channels must be a multiple of 64; launch_scan_cascade decides)
+  if (h->time_parallel != 0 && h->n_sections >= 2 && x_dev != y_dev) {
     io.n = n;
     io.x = x_dev; io.y = y_dev;
-    io.sxn = 1; io.sxc = ldx; io.syn = 1; io.syc = ldy;
+    io.sxn = sxn; io.sxc = sxc; io.syn = syn; io.syc = syc;
     io.map_input = h->mode == ALZ_BANK_OUTER;
     io.c_first = 0; io.c_count = h->channels;
     bool taken = false;
     const char *name = "";
     const int rc = alz::launch_scan_cascade(h->sec.data(), h->n_sections, io, st, h->time_parallel < 0 ? 0 : h->time_parallel,
-                                            &h->scan[(size_t)h->n_sections], &taken, &name);
+                                            &h->scan[(size_t)h->n_sections], h->state_consistent, &taken, &name);
     if (rc) return rc;
     if (taken) {
+      h->state_consistent = true;
       note(name);
       return ALZ_OK;
     }
@@ -721,7 +754,7 @@ int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int6
       note(name);
       bool taken = false;
       rc = alz::launch_scan_cascade(h->sec.data() + 1, h->n_sections - 1, io, st, h->time_parallel < 0 ? 0 : h->time_parallel,
-                                    &h->scan[(size_t)h->n_sections + 1], &taken, &name);
+                                    &h->scan[(size_t)h->n_sections + 1], false, &taken, &name);
       if (rc) return rc;
       if (taken) {
         note(name);

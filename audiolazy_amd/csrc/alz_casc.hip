@@ -46,6 +46,11 @@ struct CArgs {
   // and input index follow the real channel; state lives in per-virtual-channel arrays (channels = all vc).
   int64_t kchunks, ldx_outer, ldy_outer;
   int nostore;   // the zero-state pass: run for the end state only
+  // time-major blocks in the time-parallel mode (k_casc only): vc = chunk * creal + real_channel, so a 64-channel group is
+  // 64 adjacent real channels of ONE chunk (creal % 64 == 0) -- whole 512-byte row pieces in x and y, chunk_len rows
+  // further down per chunk; ldx / ldy stay the block's own
+  int chunk_tm;
+  int64_t creal, chunk_len;
 };
 
 // where a group of 64 (virtual) channels starting at c0 finds its rows, set and input
@@ -72,7 +77,7 @@ __device__ __forceinline__ CGroup c_group(const CArgs &p, int64_t c0) {
 }
 // coefficient set of (virtual) channel c
 __device__ __forceinline__ int64_t c_set(const CArgs &p, int64_t c) {
-  const int64_t real = p.kchunks > 0 ? c / p.kchunks : c;
+  const int64_t real = p.kchunks > 0 ? (p.chunk_tm ? c % p.creal : c / p.kchunks) : c;
   return p.mode == ALZ_BANK_OUTER ? real / p.n_inputs : ((p.n_sets == 1) ? 0 : real);
 }
 
@@ -521,9 +526,13 @@ constexpr int nb_of(unsigned pb) {
 
 // CM: channel-major blocks ([C, N]); else time-major.  Section s has pattern (PBs, PAs);
 // PB == 0 && PA == 0 marks "no such section".
-template <bool CM, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
+// BC (time-major only): an OUTER bank on ONE input stream -- the reference's own filterbank shape as vector-valued
+// samples, [N] in and [N, bands] out -- whose 64 lanes all read the same input sample: no input tiles at all, the 16
+// samples of a tile come by wave-uniform loads one tile ahead (the LDS ring then only stages the output).
+template <bool CM, bool BC, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
           unsigned PB3, unsigned PA3>
 __global__ __launch_bounds__(64) void k_casc(CArgs p) {
+  static_assert(!(CM && BC), "broadcast input: time-major instantiations only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 64, T = 16;
   constexpr int NS = (PB3 | PA3) ? 4 : (PB2 | PA2) ? 3 : (PB1 | PA1) ? 2 : 1;
@@ -535,15 +544,23 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   // OUTER: channel = set * n_inputs + input; the 64 channels of a wave share one set
   const bool outer = p.mode == ALZ_BANK_OUTER;
-  const int64_t in0 = (outer && p.map_input) ? c0 % p.n_inputs : c0;
   const int64_t set = c_set(p, c);
   const CGroup grp = c_group(p, c0);
 
   int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
+  const double *xb = p.x;                                // BC: the group's input stream at its chunk's first row
   if (!CM) {
     const int row = lane / 32, cp = lane % 32;           // 2 rows of 64 channels per 1 KiB chunk
-    x_off = (int64_t)row * p.ldx + in0 + 2 * cp;
-    y_off = (int64_t)row * p.ldy + c0 + 2 * cp;
+    int64_t r0 = c0, trow0 = 0;                          // the group's first real channel, its chunk's first row
+    if (p.kchunks > 0) {
+      const int64_t jc = c0 / p.creal;
+      r0 = c0 - jc * p.creal;
+      trow0 = jc * p.chunk_len;
+    }
+    const int64_t in0 = (outer && p.map_input) ? r0 % p.n_inputs : r0;
+    x_off = (trow0 + row) * p.ldx + in0 + 2 * cp;
+    y_off = (trow0 + row) * p.ldy + r0 + 2 * cp;
+    xb = p.x + trow0 * p.ldx + in0;
     x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
     x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
   } else {
@@ -583,9 +600,15 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   const double *xg = p.x + x_off;
   double *yg = p.y + y_off;
   const int64_t nt = p.n_tiles;
-  for (int t = 0; t < kCRing - 1 && t < nt; ++t) {
+  double xcur[16], xnext[16];
+  if constexpr (BC) {
 #pragma unroll
-    for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kCSlot + j * 1040);
+    for (int u = 0; u < 16; ++u) xcur[u] = xb[(int64_t)u * p.ldx];
+  } else {
+    for (int t = 0; t < kCRing - 1 && t < nt; ++t) {
+#pragma unroll
+      for (int j = 0; j < kCChunks; ++j) c_dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kCSlot + j * 1040);
+    }
   }
   // element (sample u, lane) of a slot.  TIME: (u*64 + lane)*8 + (u/2)*16.
   // CHAN: chunk lane/8 (1040 B each), row lane%8 (128 B), piece (u/2) ^ (lane%8), half u&1.
@@ -598,12 +621,16 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   for (int64_t i = 0; i < nt; ++i) {
     const int slot = (int)(i % kCRing);
     const int64_t tn = i + kCRing - 1;
-    if (tn < nt) {
-      const int sn = (int)(tn % kCRing);
+    if constexpr (BC) {
+      const int64_t t1 = i + 1 < nt ? i + 1 : i;           // (the last tile requests itself again)
 #pragma unroll
-      for (int j = 0; j < kCChunks; ++j) c_dma16(xg + tn * x_tile + j * x_chunk, lds0 + sn * kCSlot + j * 1040);
-    }
-    {
+      for (int u = 0; u < 16; ++u) xnext[u] = xb[(t1 * T + u) * p.ldx];
+    } else {
+      if (tn < nt) {
+        const int sn = (int)(tn % kCRing);
+#pragma unroll
+        for (int j = 0; j < kCChunks; ++j) c_dma16(xg + tn * x_tile + j * x_chunk, lds0 + sn * kCSlot + j * 1040);
+      }
       const int64_t loads_after = (nt - 1 - i < kCRing - 1) ? (nt - 1 - i) : (kCRing - 1);
       const int64_t stores_after = p.nostore ? 0 : (i < kCRing - 1) ? i : (kCRing - 1);
       c_wait_vm((int)(loads_after + stores_after) * kCChunks);
@@ -613,7 +640,10 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     for (int h = 0; h < T / 8; ++h) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double *>(tile + ALZ_COFF(h * 8 + u));
+      for (int u = 0; u < 8; ++u) {
+        if constexpr (BC) v[u] = xcur[h * 8 + u];
+        else v[u] = *reinterpret_cast<const double *>(tile + ALZ_COFF(h * 8 + u));
+      }
       section_chunk<8, nb_of(PB0), PB0, PA0>(v, bc[0], na1[0], na2[0], dx[0], m1[0], m2[0]);
       if constexpr (NS > 1) section_chunk<8, nb_of(PB1), PB1, PA1>(v, bc[1], na1[1], na2[1], dx[1], m1[1], m2[1]);
       if constexpr (NS > 2) section_chunk<8, nb_of(PB2), PB2, PA2>(v, bc[2], na1[2], na2[2], dx[2], m1[2], m2[2]);
@@ -633,6 +663,10 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
       for (int j = 0; j < kCChunks; ++j) c_store16(yt + j * y_chunk, w[j]);
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slot is about to be refilled by DMA)
+    }
+    if constexpr (BC) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) xcur[u] = xnext[u];
     }
   }
 #undef ALZ_COFF
@@ -1198,12 +1232,12 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
 
 typedef void (*casc_fn)(CArgs);
 
-template <bool CM>
+template <bool CM, bool BC = false>
 static casc_fn pick_casc(const unsigned *pb, const unsigned *pa, int ns) {
 #define ALZ_CASC(B0, A0, B1, A1, B2, A2, B3, A3, NS_)                                          \
   if (ns == NS_ && pb[0] == B0 && pa[0] == A0 && (NS_ < 2 || (pb[1] == B1 && pa[1] == A1)) && \
       (NS_ < 3 || (pb[2] == B2 && pa[2] == A2)) && (NS_ < 4 || (pb[3] == B3 && pa[3] == A3)))  \
-    return (casc_fn)k_casc<CM, B0, A0, B1, A1, B2, A2, B3, A3>;
+    return (casc_fn)k_casc<CM, BC, B0, A0, B1, A1, B2, A2, B3, A3>;
   ALZ_CASC(3, 3, 3, 3, 3, 3, 3, 3, 4)        // gammatone.slaney
   ALZ_CASC(5, 3, 1, 3, 5, 3, 1, 3, 4)        // gammatone.klapuri
   ALZ_CASC(0xFE, 3, 1, 3, 1, 3, 1, 3, 4)     // gammatone.sampled (8-tap numerator, b0 == 0)
@@ -1230,7 +1264,7 @@ static casc_fn pick_pipe(const unsigned *pb, const unsigned *pa) {
 
 // Whole cascade in one pass when its section patterns are one of the fused combinations.
 // Handles the full 16-sample tiles of the full 64-channel groups; reports what it covered.
-// With `ch` (time-parallel mode, alz_scan.hip): channel-major blocks only; every channel's block is cut into
+// With `ch` (time-parallel mode, alz_scan.hip; time-major blocks: ch->time_major, k_casc only): every channel's block is cut into
 // ch->n_chunks chunks of ch->chunk_len samples which run as n_chunks x channels virtual channels, each from /
 // into its own state slot of ch->vxh[s] / ch->vyh[s]; the launch then covers the whole bank or nothing.
 static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
@@ -1253,35 +1287,51 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   const bool tm = io.sxc == 1 && io.syc == 1;
   if (!cm && !tm) return ALZ_OK;
   const int64_t ldx = cm ? io.sxc : io.sxn, ldy = cm ? io.syc : io.syn;
-  if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
-  if ((ldx | ldy) & 1) return ALZ_OK;
   // OUTER banks that read their input by input index: a workgroup's channels must be adjacent inputs of one band
   const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
+  // (time-parallel mode on time-major blocks: ONE input stream is read by wave-uniform loads, any pitch)
+  bool bcast = ch && ch->time_major && tm && !cm && by_input && io.n_inputs == 1;
+  if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
+  if (((bcast ? 0 : ldx) | ldy) & 1) return ALZ_OK;
   const int g = 64;
   int64_t tiles = io.n / 16, groups = io.channels / g;
   if (ch) {
-    // virtual channels: 64 consecutive chunks of one real channel per group
-    if (!cm || ch->n_chunks % g != 0 || ch->chunk_len % 16 != 0 || (ch->chunk_len & 1)) return ALZ_OK;
+    if (ch->chunk_len % 16 != 0 || (ch->chunk_len & 1)) return ALZ_OK;
     if (ch->n_chunks * ch->chunk_len != io.n) return ALZ_OK;
+    if (ch->time_major) {
+      // virtual channels: the 64 adjacent real channels of a group, in one chunk (k_casc only)
+      if (!tm || cm || io.channels % g != 0) return ALZ_OK;
+      if (!bcast && by_input && (io.n_inputs % g) != 0) return ALZ_OK;
+    } else {
+      // virtual channels: 64 consecutive chunks of one real channel per group
+      if (!cm || ch->n_chunks % g != 0) return ALZ_OK;
+    }
     tiles = ch->chunk_len / 16;
     groups = io.channels * ch->n_chunks / g;
   } else if (by_input && (io.n_inputs % g) != 0) {
     return ALZ_OK;
   }
   if (groups == 0 || tiles == 0) return ALZ_OK;
+  const bool chunk_tm = ch && ch->time_major;
   // Four sections: the wave pipeline (one section per stage wave) while there are fewer 64-channel groups than
   // SIMDs; from 1024 groups up every SIMD has a whole single-wave cascade of its own and the hand-over only
   // costs (256 bands x 256 streams: k_casc 528 - 538 against k_pipe 436 - 472 Gsamples/s, profiles/NOTES_r02.md 14).
   // ALZ_TUNE: a run-time override exists in -DALZ_TUNING builds only (tools/variants).
-  const int pipe_sel = ALZ_TUNE("ALZ_PIPE", groups >= 1024 ? 0 : 1);
+  const int pipe_sel = chunk_tm ? 0 : ALZ_TUNE("ALZ_PIPE", groups >= 1024 ? 0 : 1);
   const bool fma = io.fused != 0;
   casc_fn pipe = nullptr;
   if (nsec == 4 && pipe_sel != 0)
     pipe = fma ? (cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa))
                : (cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa));
   const int pipe_waves = 6;   // four stage waves + loader + storer
-  casc_fn fn = pipe ? pipe : (cm ? pick_casc<true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
+  casc_fn fn = pipe ? pipe : cm ? pick_casc<true>(pb, pa, nsec) : bcast ? pick_casc<false, true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec);
   if (!fn) return ALZ_OK;
+  if (ch && ch->probe) {                  // (would the launch below take the block?)
+    *done_samples = io.n;
+    *done_channels = io.channels;
+    *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : "k_casc";
+    return ALZ_OK;
+  }
   CArgs p;
   p.x = io.x; p.y = io.y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = tiles;
   p.channels = io.channels; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
@@ -1289,13 +1339,16 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   p.kchunks = 0; p.ldx_outer = 0; p.ldy_outer = 0; p.nostore = 0;
+  p.chunk_tm = 0; p.creal = io.channels; p.chunk_len = 0;
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;
   }
   if (ch) {
     p.kchunks = ch->n_chunks; p.ldx_outer = ldx; p.ldy_outer = ldy;
-    p.ldx = p.ldy = ch->chunk_len; p.n_tiles = tiles;
+    if (chunk_tm) { p.chunk_tm = 1; p.chunk_len = ch->chunk_len; }
+    else p.ldx = p.ldy = ch->chunk_len;
+    p.n_tiles = tiles;
     p.channels = io.channels * ch->n_chunks;
     p.nostore = ch->nostore ? 1 : 0;
     for (int s = 0; s < nsec; ++s) { p.xh[s] = ch->vxh[s]; p.yh[s] = ch->vyh[s]; }

@@ -103,6 +103,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
 struct CascChunks {
   int64_t n_chunks, chunk_len;
   bool nostore;
+  bool time_major = false;   // slots j * channels + c and 64-channel groups inside one chunk (time-major blocks) instead of c * n_chunks + j
+  bool probe = false;        // report whether the launch would take the block, launch nothing
   double *vxh[4], *vyh[4];
 };
 int launch_cascade_chunks(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
@@ -140,6 +142,9 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   uint64_t power_bytes = 0;
   int64_t power_len = 0;             // chunk length the cached matrix belongs to (0: none)
   int power_section = -1;
+  double *hr = nullptr, *edge = nullptr;   // k_cdot: the cascade's impulse responses per set and tap, and the edge responses
+  uint64_t hr_bytes = 0, edge_bytes = 0;
+  int64_t tab_len = 0;               // chunk length the tables belong to (0: none)
   double *zbuf = nullptr;            // k_look: published chunk end states
   uint64_t zbuf_bytes = 0;
   int *look_err = nullptr;           // k_look: one word of pinned host memory the kernel sets if a bounded wait ran out
@@ -164,10 +169,12 @@ int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int6
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name);
 constexpr int64_t kLookChunk = 512;
-// time-parallel execution of a whole fused cascade on a channel-major block (see alz_scan.hip); *taken = false
-// when the shape is not covered (nothing written but scratch)
+// time-parallel execution of a whole fused cascade (see alz_scan.hip) on a channel-major block, or a time-major one whose
+// channels come in whole groups of 64; *taken = false when the shape is not covered (nothing written but scratch).
+// state_consistent: every section's input history equals its predecessor's output history (true after reset and after
+// every block) -- what the dot-product zero-state pass needs for chunk 0.
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
-                        ScanScratch *scratch, bool *taken, const char **kernel_name);
+                        ScanScratch *scratch, bool state_consistent, bool *taken, const char **kernel_name);
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
                 int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name);
 

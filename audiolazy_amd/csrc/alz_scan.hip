@@ -278,28 +278,36 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
 // ---------------------------------------------------------------------------
 struct CScanArgs {
   const double *x;
-  int64_t ldx;                 // elements between input rows (channel-major)
+  int64_t ldx;                 // elements between input rows (channel-major) / between samples (time-major)
   int64_t C, n_inputs, n_sets; // C = real channels of the bank
   int mode, map_input, nsec;
   int nb[4], na[4];
   const double *b[4], *a[4];
   double *xh[4], *yh[4];       // the bank's state [taps-1][C]
-  double *vxh[4], *vyh[4];     // per-chunk state [taps-1][C * K], slot real * K + chunk
+  double *vxh[4], *vyh[4];     // per-chunk state [taps-1][C * K]
   int64_t L, K;
   double *power;               // M[r][e] at power[(r * 8 + e) * C + c]
+  int slot_tm;                 // state slot of (real channel c, chunk j): 0 -> c * K + j (channel-major blocks: a 64-lane group of
+                               // the cascade kernel = 64 chunks of one channel), 1 -> j * C + c (time-major: 64 channels of one chunk)
+  int first_is_z;              // slot 0 of vyh holds z_0 (the dot-product zero-state pass): the fix starts at chunk 0 from the bank's state
 };
+
+__device__ __forceinline__ int64_t cs_slot(const CScanArgs &p, int64_t c, int64_t j) { return p.slot_tm ? j * p.C + c : c * p.K + j; }
+// sample t of input row `in`
+__device__ __forceinline__ int64_t cs_xat(const CScanArgs &p, int64_t in, int64_t t) { return p.slot_tm ? t * p.ldx + in : in * p.ldx + t; }
 
 __global__ __launch_bounds__(256) void k_cscan_prep(CScanArgs p) {
   const int64_t vc = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t V = p.K * p.C;
   if (vc >= V) return;
-  const int64_t real = vc / p.K, j = vc - real * p.K;
+  int64_t real, j;
+  if (p.slot_tm) { j = vc / p.C; real = vc - j * p.C; } else { real = vc / p.K; j = vc - real * p.K; }
   const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? real % p.n_inputs : real;
   for (int s = 0; s < p.nsec; ++s) {
     for (int k = 0; k < p.nb[s] - 1; ++k) {
       double v = 0.0;
       if (j == 0) v = p.xh[s][(int64_t)k * p.C + real];
-      else if (s == 0) v = p.x[in * p.ldx + j * p.L - 1 - k];
+      else if (s == 0) v = p.x[cs_xat(p, in, j * p.L - 1 - k)];
       p.vxh[s][(int64_t)k * V + vc] = v;
     }
     for (int k = 0; k < p.na[s] - 1; ++k) p.vyh[s][(int64_t)k * V + vc] = j == 0 ? p.yh[s][(int64_t)k * p.C + real] : 0.0;
@@ -343,85 +351,291 @@ __global__ __launch_bounds__(64) void k_cscan_power(CScanArgs p) {
   }
 }
 
-// S_{j+1} = M S_j + z_j per real channel.  On entry vyh holds the end states of pass 1 (slot 0: the true S_1,
-// slots j > 0: z_j); on exit every slot holds its chunk's true initial state (slot 0: the bank's).
-// Eight lanes per channel, one per state row: lane r keeps row r of M, walks the channel's chunks in order (they are
-// contiguous in memory, [k][channel * K + j]) with the z of the next block of eight chunks in flight, and the eight
-// lanes of a channel exchange their state components through LDS once per chunk.  (One lane per channel with the
-// whole matrix in registers issued 14 scattered stores and 8 scattered loads per chunk from each of 64 lanes: 586 us
-// per call at one chunk of look-ahead, 254 us at eight -- more than either cascade pass; profiles/NOTES_r03.md.)
+// S_{j+1} = M S_j + z_j per real channel, serially over the chunks; S = (y_s[-1], y_s[-2]) of every section (the next
+// section's input history is the same two numbers).  On entry vyh holds the end states of the zero-state pass -- from the
+// cascade pass slot 0 is the true S_1 and slots j > 0 are z_j; from the dot-product pass (first_is_z) every slot is z_j and
+// the recursion starts from the bank's state.  On exit every slot holds its chunk's true initial state (vyh[s], and
+// vxh[s + 1]: the same numbers), and the BANK's state is the state after the last chunk, S_K = M S_{K-1} + z_{K-1} (with
+// section 0's input history from the block's last samples): no separate finish launch, and it equals what the replay of
+// the last chunk will leave to within the rounding every chunk boundary carries.
+//
+// A DPP row of 16 lanes per channel (four channels per wave): lane r < 8 keeps row r of M and component r of S; the
+// product needs every component in every lane -- v_mov_b32_dpp row_newbcast:e, two per component and step, no LDS round
+// trip (round 3's form, eight lanes per channel exchanging through LDS: ~800 cycles per chunk, 96 us for 256 chunks).
+// Lanes 8 .. 15 mirror 0 .. 7 and take the vxh stores off them.  Chunks go in blocks of eight: the z of the next block
+// are in flight while this one is chained, a block's states leave as 16-byte stores where the slots of consecutive
+// chunks are adjacent (channel-major).
+template <int E>
+__device__ __forceinline__ double cs_bcast(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x150 + E, 0xf, 0xf, false);          // row_newbcast:E
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + E, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+template <bool SLOT_TM>
 __global__ __launch_bounds__(64) void k_cscan_fix(CScanArgs p) {
-  __shared__ double xs[64];
-  const int lane = threadIdx.x, r = lane & 7, g = lane >> 3;
-  int64_t c = (int64_t)blockIdx.x * 8 + g;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x, r = lane & 7, g = lane >> 4;
+  const bool mirror = (lane & 8) != 0;
+  int64_t c = (int64_t)blockIdx.x * 4 + g;
   const bool live_c = c < p.C;
-  if (!live_c) c = p.C - 1;                                  // (keeps the wave's LDS exchange uniform; nothing is stored)
-  const int64_t V = p.K * p.C, v0 = c * p.K;
+  if (!live_c) c = p.C - 1;                                  // (keeps EXEC full for the DPP moves; nothing is stored)
+  const int64_t V = p.K * p.C;
   const int ND = 2 * p.nsec;
   constexpr int B = 8;
   const int s = r >> 1, k = r & 1;
-  const bool on = r < ND && k < p.na[s < p.nsec ? s : 0] - 1;
+  const bool row_on = r < ND && k < p.na[s < p.nsec ? s : 0] - 1;
   double M[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) M[e] = (r < ND && e < ND) ? p.power[((int64_t)r * 8 + e) * p.C + c] : 0.0;
-  const double *zsrc = on ? p.vyh[s] + (int64_t)k * V + v0 : p.power;
-  double *ydst = (on && live_c) ? p.vyh[s] + (int64_t)k * V + v0 : nullptr;
-  // the next section's input history is this section's output history
-  double *xdst = (r < ND && live_c && s + 1 < p.nsec && k < p.nb[s + 1] - 1) ? p.vxh[s + 1] + (int64_t)k * V + v0 : nullptr;
-  double S = on ? zsrc[0] : 0.0;                             // end state of chunk 0 = the true S_1 (row r of it)
-  if (ydst) ydst[0] = p.yh[s][(int64_t)k * p.C + c];         // chunk 0 replays from the bank's state
-  auto fetch = [&](int64_t j0, double (&z)[B]) {             // z_r of chunks j0 .. j0 + B - 1 (clamped)
+  const int64_t sj = SLOT_TM ? p.C : 1, base = SLOT_TM ? c : c * p.K;
+  const double *zsrc = row_on ? p.vyh[s] + (int64_t)k * V + base : nullptr;
+  // lanes 0 .. 7 store the chunk's output state, lanes 8 .. 15 the next section's input history (the same numbers)
+  double *dst = nullptr;
+  if (live_c && row_on && !mirror) dst = p.vyh[s] + (int64_t)k * V + base;
+  if (live_c && r < ND && mirror && s + 1 < p.nsec && k < p.nb[s + 1] - 1) dst = p.vxh[s + 1] + (int64_t)k * V + base;
+  const double bank_y = row_on ? p.yh[s][(int64_t)k * p.C + c] : 0.0;
+  // what slot 0 gets: the bank's state.  (After the cascade pass the next section's input history of chunk 0 is the
+  // bank's own x history -- k_cscan_prep put it there for that pass, and a set_state may have made it differ from y.)
+  double first = bank_y;
+  if (!p.first_is_z && mirror && dst) first = p.xh[s + 1][(int64_t)k * p.C + c];
+  double S = bank_y;
+  auto fetch = [&](int64_t j0, double (&z)[B]) {
+    if (j0 >= p.K) j0 = p.K - B;                             // (the look-ahead past the end reads the last block again)
+    if constexpr (!SLOT_TM) {
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      const int64_t j = j0 + u < p.K ? j0 + u : p.K - 1;
-      z[u] = on ? zsrc[j] : 0.0;
+      for (int u = 0; u < B; u += 2) {
+        dbl2 v = {0.0, 0.0};
+        if (zsrc) v = *reinterpret_cast<const dbl2 *>(zsrc + j0 + u);
+        z[u] = v.x; z[u + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < B; ++u) z[u] = zsrc ? zsrc[(j0 + u) * sj] : 0.0;
     }
   };
   auto chain = [&](int64_t j0, const double (&z)[B]) {
+    double out[B];
 #pragma unroll
     for (int u = 0; u < B; ++u) {
-      const int64_t j = j0 + u;
-      if (j < p.K) {                                         // (uniform)
-        if (ydst) ydst[j] = S;
-        if (xdst) xdst[j] = S;
-        xs[lane] = S;
-        __builtin_amdgcn_wave_barrier();
-        double acc = z[u];
+      const bool head = j0 + u == 0;
+      out[u] = head ? first : S;
+      const double s0 = cs_bcast<0>(S), s1 = cs_bcast<1>(S), s2 = cs_bcast<2>(S), s3 = cs_bcast<3>(S);
+      const double s4 = cs_bcast<4>(S), s5 = cs_bcast<5>(S), s6 = cs_bcast<6>(S), s7 = cs_bcast<7>(S);
+      double a0 = __builtin_fma(M[0], s0, z[u]);
+      double a1 = M[1] * s1;
+      a0 = __builtin_fma(M[2], s2, a0);
+      a1 = __builtin_fma(M[3], s3, a1);
+      a0 = __builtin_fma(M[4], s4, a0);
+      a1 = __builtin_fma(M[5], s5, a1);
+      a0 = __builtin_fma(M[6], s6, a0);
+      a1 = __builtin_fma(M[7], s7, a1);
+      const double next = a0 + a1;
+      S = (head && !p.first_is_z) ? z[u] : next;             // (cascade pass: slot 0 already is the true S_1)
+    }
+    if (dst) {
+      if constexpr (!SLOT_TM) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = __builtin_fma(M[e], xs[g * 8 + e], acc);
-        __builtin_amdgcn_wave_barrier();
-        S = acc;
+        for (int u = 0; u < B; u += 2) {
+          dbl2 v = {out[u], out[u + 1]};
+          *reinterpret_cast<dbl2 *>(dst + j0 + u) = v;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < B; ++u) dst[(j0 + u) * sj] = out[u];
       }
     }
   };
-  // chunks 1 .. K - 1 in blocks of B, two register sets
   double za[B], zb[B];
-  fetch(1, za);
-  for (int64_t j0 = 1; j0 < p.K; j0 += 2 * B) {
+  fetch(0, za);
+  for (int64_t j0 = 0; j0 < p.K; j0 += 2 * B) {               // (K is a multiple of 64)
     fetch(j0 + B, zb);
     chain(j0, za);
     fetch(j0 + 2 * B, za);
     chain(j0 + B, zb);
   }
+  // the bank's state after the block
+  if (live_c && row_on && !mirror) p.yh[s][(int64_t)k * p.C + c] = S;
+  if (live_c && r < ND && mirror && s + 1 < p.nsec && k < p.nb[s + 1] - 1) p.xh[s + 1][(int64_t)k * p.C + c] = S;
+  if (live_c && !mirror && r < p.nb[0] - 1 && r < 2) {        // section 0's input history: the block's last samples (exact)
+    const int64_t in = (p.mode == ALZ_BANK_OUTER && p.map_input) ? c % p.n_inputs : c;
+    p.xh[0][(int64_t)r * p.C + c] = p.x[cs_xat(p, in, p.K * p.L - 1 - r)];
+  }
 }
 
-// the last chunk's end state (left by pass 2) is the bank's state after the block
-__global__ __launch_bounds__(256) void k_cscan_finish(CScanArgs p) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.C) return;
-  const int64_t V = p.K * p.C, last = c * p.K + p.K - 1;
-  for (int s = 0; s < p.nsec; ++s) {
-    for (int k = 0; k < p.nb[s] - 1; ++k) p.xh[s][(int64_t)k * p.C + c] = p.vxh[s][(int64_t)k * V + last];
-    for (int k = 0; k < p.na[s] - 1; ++k) p.yh[s][(int64_t)k * p.C + c] = p.vyh[s][(int64_t)k * V + last];
+// ---------------------------------------------------------------------------
+// The zero-state pass as dot products (round 4's experiment, shipped in round 5).  A chunk's zero-state end state is
+// linear in the chunk's input:
+//   z_j[s][k] = y_s[L - 1 - k] = sum_m h_s[L - 1 - k - m] x_j[m] + e1[s][k] x_j[-1] + e2[s][k] x_j[-2],
+// h_s the impulse response of sections 0 .. s, e1 / e2 the responses to a unit sample in section 0's input history --
+// 8 fused multiply-adds per input sample and band where the cascade pass issues ~28 instructions and keeps nothing but
+// its last state.  The tables (one row of 4 doubles per set and tap, 32 B x sets x L) are built once per bank and chunk
+// length by running the cascade's own arithmetic over a unit impulse.  OUTER banks that read their input by input index
+// (the reference's filterbank shape: lazy_auditory.py:158-218 through examples/gammatone_plots.py:47); the bank's state
+// must be self-consistent (section s + 1's input history = section s's output history: true after reset and after every
+// block, not after an arbitrary set_state -- the handle keeps a flag) because chunk 0 goes through S_1 = M S_0 + z_0
+// like every other chunk.
+//
+// k_cdot: lane = chunk (64 consecutive chunks of one input row per wave: every lane reads its own chunk by 16-byte
+// loads), NS bands per workgroup with their responses wave-uniform in SGPRs, the sum over the chunk split over the SPLIT
+// waves of the workgroup, whose partial sums meet in LDS and are added in segment order (deterministic) -- no partial
+// sums in HBM, no reduction launch.  Wave 0 also leaves section 0's input history of every chunk (the block itself:
+// exact) in vxh[0], which was k_cscan_prep's job.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cdot_tables(CScanArgs p, double *__restrict__ hr, double *__restrict__ edge) {
+  const int64_t set = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (set >= p.n_sets) return;
+  double b0[4], b1[4], b2[4], na1[4], na2[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool on = s < p.nsec;
+    b0[s] = (on && p.nb[s] > 0) ? p.b[s][0 * p.n_sets + set] : 0.0;
+    b1[s] = (on && p.nb[s] > 1) ? p.b[s][1 * p.n_sets + set] : 0.0;
+    b2[s] = (on && p.nb[s] > 2) ? p.b[s][2 * p.n_sets + set] : 0.0;
+    na1[s] = (on && p.na[s] > 1) ? -p.a[s][1 * p.n_sets + set] : 0.0;
+    na2[s] = (on && p.na[s] > 2) ? -p.a[s][2 * p.n_sets + set] : 0.0;
+  }
+  for (int run = 0; run < 3; ++run) {       // 0: impulse at n = 0;  1: x[-1] = 1;  2: x[-2] = 1
+    double y1[4] = {0.0, 0.0, 0.0, 0.0}, y2[4] = {0.0, 0.0, 0.0, 0.0};
+    double xa = run == 1 ? 1.0 : 0.0, xb = run == 2 ? 1.0 : 0.0;     // section 0's input history x[n-1], x[n-2]
+    for (int64_t n = 0; n < p.L; ++n) {
+      double xin = (run == 0 && n == 0) ? 1.0 : 0.0, x1 = xa, x2 = xb;
+      xb = xa;
+      xa = xin;
+      double out[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double o1 = y1[s], o2 = y2[s];
+        const double y = b0[s] * xin + b1[s] * x1 + b2[s] * x2 + na1[s] * o1 + na2[s] * o2;
+        y2[s] = o1;
+        y1[s] = y;
+        out[s] = y;
+        xin = y; x1 = o1; x2 = o2;
+      }
+      if (run == 0) {                       // hr[(set L + m) 4 + s] = h_s[L - 1 - m]: the weight of x[m] in y_s[L - 1]
+        double *dst = hr + ((int64_t)set * p.L + (p.L - 1 - n)) * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[s] = s < p.nsec ? out[s] : 0.0;
+      }
+    }
+    if (run > 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        edge[(((int64_t)set * 2 + (run - 1)) * 4 + s) * 2 + 0] = s < p.nsec ? y1[s] : 0.0;
+        edge[(((int64_t)set * 2 + (run - 1)) * 4 + s) * 2 + 1] = s < p.nsec ? y2[s] : 0.0;
+      }
+    }
+  }
+}
+
+template <int NS, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void k_cdot(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge) {
+  extern __shared__ __attribute__((aligned(16))) double cd_part[];   // [SPLIT][NS * 8][64]
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  static_assert((NS * 8) % SPLIT == 0, "the final sums are shared out over the waves");
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ngrp = p.n_sets / NS;
+  const int64_t in = (int64_t)blockIdx.y / ngrp, set0 = ((int64_t)blockIdx.y - in * ngrp) * NS;
+  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls, m1 = m0 + Ls;
+  const double *xrow = p.x + in * p.ldx + j * p.L;            // (channel-major rows, or ONE contiguous time-major column)
+  double acc[NS][4][2];
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
+  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
+  dbl2 v = *reinterpret_cast<const dbl2 *>(xrow + m0);
+  double h[NS][8];
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[a][q] = hr[((set0 + a) * p.L + m0) * 4 + q];
+  for (int64_t m = m0; m < m1; m += 2) {
+    const int64_t mn = m + 2 < m1 ? m + 2 : m;                 // (the last step requests its own pair again)
+    const dbl2 vn = *reinterpret_cast<const dbl2 *>(xrow + mn);
+    double hn[NS][8];
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) hn[a][q] = hr[((set0 + a) * p.L + mn) * 4 + q];
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[a][s][0] = __builtin_fma(h[a][s], v.x, acc[a][s][0]);
+        acc[a][s][1] = __builtin_fma(h[a][s], xprev, acc[a][s][1]);
+        acc[a][s][0] = __builtin_fma(h[a][4 + s], v.y, acc[a][s][0]);
+        acc[a][s][1] = __builtin_fma(h[a][4 + s], v.x, acc[a][s][1]);
+      }
+    }
+    xprev = v.y;
+    v = vn;
+#pragma unroll
+    for (int a = 0; a < NS; ++a)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) h[a][q] = hn[a][q];
+  }
+  const int64_t V = p.K * p.C;
+  if (seg == 0) {
+    // the two samples before the chunk -- from the block, or the bank's input history for chunk 0 -- enter through the
+    // edge responses, and are what the replay of this chunk starts section 0 from
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      const int64_t c = (set0 + a) * p.n_inputs + in;
+      double xm1 = 0.0, xm2 = 0.0;
+      if (p.nb[0] > 1) xm1 = j > 0 ? xrow[-1] : p.xh[0][0 * p.C + c];
+      if (p.nb[0] > 2) xm2 = j > 0 ? xrow[-2] : p.xh[0][1 * p.C + c];
+      const int64_t slot = cs_slot(p, c, j);
+      if (p.nb[0] > 1) p.vxh[0][0 * V + slot] = xm1;
+      if (p.nb[0] > 2) p.vxh[0][1 * V + slot] = xm2;
+      const double *e = edge + (set0 + a) * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          double z = acc[a][s][k];
+          z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
+          z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
+          acc[a][s][k] = z;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) cd_part[((seg * NS + a) * 8 + 2 * s + k) * 64 + lane] = acc[a][s][k];
+  __syncthreads();
+  constexpr int QPW = NS * 8 / SPLIT;                          // sums per wave
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int q = seg * QPW + i, a = q >> 3, s = (q >> 1) & 3, k = q & 1;   // (wave-uniform)
+    if (s >= p.nsec) continue;
+    double z = cd_part[((0 * NS + a) * 8 + 2 * s + k) * 64 + lane];
+#pragma unroll
+    for (int sg = 1; sg < SPLIT; ++sg) z = z + cd_part[((sg * NS + a) * 8 + 2 * s + k) * 64 + lane];
+    const int64_t c = (set0 + a) * p.n_inputs + in;
+    p.vyh[s][(int64_t)k * V + cs_slot(p, c, j)] = z;
   }
 }
 
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
-                        ScanScratch *scratch, bool *taken, const char **kernel_name) {
+                        ScanScratch *scratch, bool state_consistent, bool *taken, const char **kernel_name) {
   *taken = false;
   if (nsec < 2 || nsec > 4) return ALZ_OK;
   const bool cm = io.sxn == 1 && io.syn == 1;
-  if (!cm) return ALZ_OK;
+  // time-major blocks: the 64 lanes of a cascade group are 64 adjacent channels of ONE chunk (rows of 512 contiguous
+  // bytes in the output), so the bank's channels must come in whole groups, and the input either has a column per
+  // group lane (inputs % 64 == 0) or is one stream every band reads (broadcast by scalar loads in k_casc)
+  const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
+  const bool tm = !cm && io.sxc == 1 && io.syc == 1 && io.channels % 64 == 0 &&
+                  (by_input ? (io.n_inputs == 1 || io.n_inputs % 64 == 0) : true);
+  if (!cm && !tm) return ALZ_OK;
   for (int s = 0; s < nsec; ++s) {
     // every section keeps two outputs of state; only the first may look further back into its input
     if (secs[s].na != 3 || secs[s].any_div || !secs[s].uniform) return ALZ_OK;
@@ -431,8 +645,9 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     if (secs[s].nb > 3 || secs[s].nb < 1) return ALZ_OK;
   }
   const int64_t C = io.channels;
-  // chunks: a multiple of 64 per real channel (a 64-lane group = 64 chunks of one channel) that divides the
-  // block into whole 16-sample tiles; by default enough of them to fill the chip (>= 1024 groups of 64)
+  // chunks: a multiple of 64 per real channel (channel-major: a 64-lane group = 64 chunks of one channel; the fix kernel
+  // walks them in blocks of 16) that divides the block into whole 16-sample tiles; by default enough of them to fill
+  // the chip (>= 1024 groups of 64)
   int64_t K = 0;
   if (chunk_len > 0) {
     if (io.n % chunk_len == 0) K = io.n / chunk_len;
@@ -462,9 +677,11 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
 
   CScanArgs p;
   CascChunks ch;
-  ch.n_chunks = K; ch.chunk_len = L;
-  p.x = io.x; p.ldx = io.sxc; p.C = C; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
+  ch.n_chunks = K; ch.chunk_len = L; ch.time_major = !cm;
+  p.x = io.x; p.ldx = cm ? io.sxc : io.sxn; p.C = C; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
   p.mode = io.mode; p.map_input = io.map_input; p.nsec = nsec; p.L = L; p.K = K; p.power = scratch->power;
+  p.slot_tm = cm ? 0 : 1;
+  p.first_is_z = 0;
   double *cur = scratch->vxh;
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
@@ -477,26 +694,58 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     ch.vxh[s] = p.vxh[s]; ch.vyh[s] = p.vyh[s];
   }
   const char *inner = "";
-  hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
-  ch.nostore = true;
   bool ok = false;
-  rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
-  if (rc) return rc;
-  if (!ok) return ALZ_OK;                 // (prep only touched scratch)
-  if (scratch->power_len != L || scratch->power_section != -2) {
+  const bool fresh_power = scratch->power_len != L || scratch->power_section != -2;
+
+  // the zero-state pass: dot products with the cascade's impulse responses where the shape offers them (an OUTER bank
+  // reading by input index from rows of chunks: channel-major, or the one contiguous column of a one-stream time-major
+  // block), else the cascade kernel itself without stores
+  constexpr int NS = 4, SPLIT = 8;
+  const bool dot_pass = state_consistent && by_input && io.x != io.y && io.n_sets % NS == 0 && L % (2 * SPLIT) == 0 &&
+                        (((uintptr_t)io.x) & 15) == 0 && (cm ? (p.ldx % 2 == 0) : (io.n_inputs == 1 && p.ldx == 1)) &&
+                        (uint64_t)(K / 64) <= 65535u && (uint64_t)(io.n_sets / NS) * (uint64_t)io.n_inputs <= 65535u;
+  if (dot_pass) {
+    const uint64_t hr_need = (uint64_t)io.n_sets * L * 4 * sizeof(double), edge_need = (uint64_t)io.n_sets * 16 * sizeof(double);
+    uint64_t have_h = scratch->hr_bytes, have_e = scratch->edge_bytes;
+    rc = grow_scratch(&scratch->hr, &have_h, hr_need);
+    if (rc) return rc;
+    rc = grow_scratch(&scratch->edge, &have_e, edge_need);
+    if (rc) return rc;
+    const bool fresh_tab = have_h != scratch->hr_bytes || have_e != scratch->edge_bytes || scratch->tab_len != L;
+    scratch->hr_bytes = have_h; scratch->edge_bytes = have_e;
+    if (fresh_tab) {
+      hipLaunchKernelGGL(k_cdot_tables, dim3((unsigned)((io.n_sets + 63) / 64)), dim3(64), 0, stream, p, scratch->hr, scratch->edge);
+      scratch->tab_len = L;
+    }
+    const int lds = SPLIT * NS * 8 * 64 * (int)sizeof(double);
+    rc = ensure_dynamic_lds((const void *)k_cdot<NS, SPLIT>, lds);
+    if (rc) return rc;
+    p.first_is_z = 1;
+    hipLaunchKernelGGL((k_cdot<NS, SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
+                       lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
+  } else {
+    hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
+    ch.nostore = true;
+    rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
+    if (rc) return rc;
+    if (!ok) return ALZ_OK;               // (prep only touched scratch)
+  }
+  if (fresh_power) {
     hipLaunchKernelGGL(k_cscan_power, dim3((unsigned)((C * 2 * nsec + 63) / 64)), dim3(64), 0, stream, p);
     scratch->power_len = L;
     scratch->power_section = -2;          // (-2: this slot holds a cascade's matrix)
   }
-  hipLaunchKernelGGL(k_cscan_fix, dim3((unsigned)((C + 7) / 8)), dim3(64), 0, stream, p);
+  if (cm) hipLaunchKernelGGL(k_cscan_fix<false>, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, stream, p);
+  else hipLaunchKernelGGL(k_cscan_fix<true>, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, stream, p);
   ch.nostore = false;
   rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
   if (rc) return rc;
-  if (!ok) return fail(ALZ_E_HIP, "time-parallel cascade: replay launch refused after the zero-state pass");
-  hipLaunchKernelGGL(k_cscan_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, p);
+  if (!ok) return fail(ALZ_E_HIP, dot_pass ? "time-parallel cascade: the fused cascade kernel refused the replay after the dot-product pass"
+                                           : "time-parallel cascade: replay launch refused after the zero-state pass");
   ALZ_HIP_CHECK(hipGetLastError());
   *taken = true;
-  *kernel_name = inner[2] == 'p' ? "k_cscan(k_pipe)" : "k_cscan(k_casc)";
+  *kernel_name = dot_pass ? (inner[2] == 'p' ? "k_cscan(k_cdot+k_pipe)" : "k_cscan(k_cdot+k_casc)")
+                          : (inner[2] == 'p' ? "k_cscan(k_pipe)" : "k_cscan(k_casc)");
   return ALZ_OK;
 }
 

@@ -16,8 +16,8 @@ print("  %.2f %s  n_gpus %d  ms/step %.4f  kernel_ms %.4f  frac %.4f | %s | %s" 
     str(d["config"].get("parity_spot_check"))[:90]))
 for k, v in d.get("secondary", {}).items():
   if "frac" in v:                                   # the compact line (round 4): slim secondary entries
-    print("    %-36s %9.3f %-10s frac %.3f  ms/step %.4f  traffic x%s | %s" % (k, v["value"], v["unit"], v["frac"],
-          v["ms_per_step"], v.get("traffic_ratio"), str(v["parity"])[:90]))
+    print("    %-38s %9.3f %-10s frac %.3f  ms/step %.4f %s %s traffic x%s | %s" % (k, v["value"], v["unit"], v["frac"],
+          v["ms_per_step"], v.get("ms_min_max", ""), v.get("n", ""), v.get("traffic_ratio"), str(v["parity"])[:90]))
   elif "roofline" in v:
     print("    %-36s %9.3f %-10s frac %.3f (step %.3f) %-34s | %s" % (k, v["value"], v["unit"], v["roofline"]["frac"],
           v["roofline"].get("frac_from_ms_per_step", 0), str(v["kernel"])[:34], str(v["parity"])[:80]))
