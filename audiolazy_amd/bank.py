@@ -111,11 +111,13 @@ def stage_memories(memory, nas, zero=0.0):
   return [memory_to_hist(items, na - 1, zero) for na in nas]
 
 
-def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=None, _hists=None):
+def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=None, _hists=None, output_map=None):
   """The filter call protocol for one cascade of LTI sections [(b, a), ...]: ``memory`` is read
   now, the input is not touched until the result is iterated (the reference's generator pulls
   its first sample at the first ``next``); the first item then tells whether samples are scalars
-  or rows of C values (C parallel streams, reference tests/test_filters_extdep.py:49-89)."""
+  or rows of C values (C parallel streams, reference tests/test_filters_extdep.py:49-89).
+  ``input_map`` / ``output_map``: elementwise stages of :mod:`audiolazy_amd.maps` on the device around the
+  filter, per BLOCK ("abs" / "square" in front; "sqrt" behind -- ``envelope``'s root)."""
   from .stream import Stream
   hists = stage_memories(memory, [len(a) for _, a in sections], zero) if _hists is None else \
       [memory_to_hist(h, len(a) - 1, zero) for h, (_, a) in zip(_hists, sections)]
@@ -131,7 +133,7 @@ def call_sections(sections, seq, memory=None, zero=0., block=None, input_map=Non
     if input_map:
       bank.set_input_map(input_map)
     bank.reset(zero=zero, _hists=hists)
-    for out in bank._blocks(itertools.chain([first], it), block):
+    for out in bank._blocks(itertools.chain([first], it), block, post=output_map):
       yield out
   # one Python-level resume per BLOCK, not per sample: the items of a block come out of a list
   return Stream(itertools.chain.from_iterable(blocks_out()))
@@ -488,9 +490,10 @@ class FilterBank(object):
       twin.set_input_map(self._input_map)
     return twin
 
-  def _blocks(self, seq, block=None):
+  def _blocks(self, seq, block=None, post=None):
     """Generator behind the call protocol: pulls ``block`` items, filters them on the GPU and yields
-    the results of the block as a list (scalars for a one-channel bank, rows otherwise)."""
+    the results of the block as a list (scalars for a one-channel bank, rows otherwise).  ``post``:
+    an elementwise op of :mod:`audiolazy_amd.maps` applied to every output block on the device."""
     scalar_out = self.channels == 1
     block = block_size() if block is None else block
     it = iter(seq)
@@ -509,4 +512,7 @@ class FilterBank(object):
       if x.shape[0] == 0:
         return
       y = self.process(x, layout="time")
+      if post:
+        from . import maps
+        y = maps.map_block(post, y, device=self.device)
       yield y[:, 0].tolist() if scalar_out else list(y)

@@ -421,8 +421,11 @@ static int take_look_error(alz_bank_t *h) {
       *sc.look_err = 0;
       bad = true;
     }
-  return bad ? fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel gave up waiting for another workgroup "
-                               "(the block it wrote is invalid; process it again)")
+  // (the kernel had advanced the bank's state by then: the block cannot simply be processed again)
+  return bad ? fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel of an EARLIER process call on this bank gave up "
+                               "waiting for another workgroup: the block that call wrote and the bank's state are invalid, "
+                               "and the call that reports this has processed nothing -- reset() or set_state() the bank, "
+                               "then process from the last good block again")
              : ALZ_OK;
 }
 

@@ -17,6 +17,14 @@ reference's semantics restated:
 * ``memory``: the FIRST ``len(den) - 1`` items are y[-1], y[-2], ...; a short one is LEFT-padded with ``zero``
   (:185-195); a callable is called with the size; ``zero`` is every past input.
 
+* constants reach the reference's generated source as TEXT (``"{value} * d{idx}".format(...)``, :209, :224; the gain
+  :236; ``zero`` of a filter without terms :229-231), so an object that is not its own literal is re-read by the
+  Python parser: ``Fraction(3, 5)`` becomes ``3/5 * d0`` -- float arithmetic --, a ``Fraction`` gain ``a/b`` makes
+  ``(...) / a/b`` (divide by a, then by b), ``-1j`` comes back as ``(-0-1j)`` with a POSITIVE zero real part,
+  ``numpy.float64`` / ``Decimal`` as plain floats, a ``zero`` of ``Fraction(3)`` as the int 3.  Restated here by
+  compiling the same fragments (``_fragment``); plain ``float`` / ``int`` constants are their own literals
+  (``repr`` round-trips) and are used as they are.
+
 This is product code with no GPU in it (slow by nature: it exists so that a pipeline written for the reference
 keeps working when such items reach a filter); it never imports ``oracle/``.
 """
@@ -54,7 +62,7 @@ def all_int_configuration(numlist, denlist, memory, zero):
   """True when no float can enter the arithmetic except through the items: integer coefficients, and integer
   ``zero`` / ``memory`` wherever the filter reads them.  The reference then keeps integer items integers
   (:735-742), so such a call is not the float engine's."""
-  is_int = lambda v: isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+  is_int = lambda v: isinstance(v, (int, np.integer))      # (bools included: True * 3 is the int 3, as in the reference)
   present = lambda c: is_series(c) or not is_engine_scalar(c) or c != 0   # (a zero coefficient contributes no term)
   b, a = list(numlist), list(denlist)
   coefs = [c for c in b + a if not is_series(c) and present(c)]
@@ -103,6 +111,26 @@ def initial_memory(memory, size, zero):
   return [zero] * (size - len(got)) + got
 
 
+def _own_literal(v):
+  """Plain Python floats and ints (not bools, not subclasses) format to a literal of themselves."""
+  return type(v) in (float, int) and v == v and v not in (float("inf"), float("-inf"))
+
+
+def _fragment(template, value):
+  """``lambda _v: <the reference's source fragment with the constant formatted in>``, compiled in an empty namespace
+  like the reference's generated function (lazy_filters.py:98-106): whatever the text means to the parser is what the
+  filter computes.  A constant whose text is not an expression raises here what the reference raises when it
+  defines its generator (SyntaxError / NameError at call time)."""
+  fn = eval("lambda _v: " + template.format(value=value), {})
+  try:
+    fn(0)                     # names are resolved when the fragment runs: fail at call time like the reference
+  except NameError:
+    raise
+  except Exception:
+    pass
+  return fn
+
+
 def df1(numlist, denlist, seq, memory=None, zero=0.):
   """Generator of output items: the difference equation evaluated in Python arithmetic on whatever the items
   are.  ``numlist`` / ``denlist``: coefficients by delay, constants or iterables (one value per output item)."""
@@ -132,7 +160,7 @@ def df1(numlist, denlist, seq, memory=None, zero=0.):
     elif c == -1:
       plan.append(("-x", k, None))
     elif c != 0:
-      plan.append(("x*c", k, c))
+      plan.append(("x*c", k, c) if _own_literal(c) else ("x*t", k, _fragment("{value} * _v", c)))
   for k, c in enumerate(a):
     if k == 0:
       continue
@@ -143,7 +171,12 @@ def df1(numlist, denlist, seq, memory=None, zero=0.):
     elif c == 1:
       plan.append(("-y", k, None))
     elif c != 0:
-      plan.append(("y*c", k, -c))
+      plan.append(("y*c", k, -c) if _own_literal(c) else ("y*t", k, _fragment("-{value} * _v", c)))
+  if not plan:
+    if not _own_literal(zero):
+      zero = eval("{zero}".format(zero=zero), {})          # ``yield {zero}`` (:229-231)
+  elif gain != -1 and gain != 1 and not _own_literal(gain):
+    gain = _fragment("(_v) / {value}", gain)               # ``({expr}) / {gain}`` (:236)
   return _run(plan, gain, iter(seq), mem, zero, lb)
 
 
@@ -168,6 +201,8 @@ def _run(plan, gain, items, mem, zero, lb):
           term = -src
         elif kind in ("x*c", "y*c"):
           term = arg * src
+        elif kind in ("x*t", "y*t"):
+          term = arg(src)
         elif kind == "x*s":
           term = next(arg) * src
         else:
@@ -175,7 +210,9 @@ def _run(plan, gain, items, mem, zero, lb):
         total = term if total is None else total + term
     except StopIteration:            # a coefficient series that ends, ends the output (the reference's generator dies there)
       return
-    if gain == -1:
+    if callable(gain):
+      total = gain(total)
+    elif gain == -1:
       total = -(total)
     elif gain != 1:
       total = (total) / gain

@@ -128,13 +128,25 @@ def _block_fits_engine(blk):
   complex / Fraction / symbolic items never were floats: those run the reference's sums on the host."""
   any_float, biggest = False, 0
   for v in blk:
-    if isinstance(v, (float, np.floating)):
-      any_float = True
+    if isinstance(v, float):          # Python floats and numpy.float64 (a float subclass); numpy.float32 items keep the
+      any_float = True                # reference's per-item arithmetic on the host (their products are float32 there)
     elif type(v) is int:
       biggest = max(biggest, abs(v))
     else:
       return False
   return any_float and biggest * biggest * len(blk) < (1 << 53)
+
+
+# One block is a GPU round trip (allocate, upload, launch, synchronise, download: ~0.3 ms) -- below this many
+# multiply-adds the host's own sum, which IS the reference's arithmetic, is faster (round-4 advisor)
+_HOST_TERMS = 8192
+
+
+def _keep_item_type(blk, values):
+  """The reference's sums of numpy.float64 items are numpy.float64: keep that when the whole block is."""
+  if len(blk) and all(type(v) is np.float64 for v in blk):
+    return [np.float64(v) if isinstance(v, float) else v for v in values]
+  return values
 
 
 def _int_runs(blk):
@@ -152,7 +164,7 @@ def acorr(blk, max_lag=None):
     max_lag = len(blk) - 1
   size = len(blk)
   host_sum = lambda tau: sum(blk[n] * blk[n + tau] for n in range(size - tau))
-  if not _block_fits_engine(blk):
+  if size * (max_lag + 1) <= _HOST_TERMS or not _block_fits_engine(blk):
     return [host_sum(tau) for tau in range(max_lag + 1)]
   lags = acorr_frames([float(v) for v in blk], size, max_lag)[0].tolist()
   all_int = _int_runs(blk)
@@ -161,7 +173,7 @@ def acorr(blk, max_lag=None):
       lags[tau] = host_sum(tau)
   for tau in range(size + 1, max_lag + 1):
     lags[tau] = 0                                       # (no terms at all: sum() of nothing)
-  return lags
+  return _keep_item_type(blk, lags)
 
 
 def lag_matrix(blk, max_lag=None):
@@ -174,7 +186,7 @@ def lag_matrix(blk, max_lag=None):
     raise ValueError("Block length should be higher than order")
   size = len(blk)
   host_sum = lambda i, j: sum(blk[n - i] * blk[n - j] for n in range(max_lag, size))
-  if max_lag < 0 or not _block_fits_engine(blk):
+  if max_lag < 0 or (size - max_lag) * (max_lag + 1) ** 2 <= _HOST_TERMS or not _block_fits_engine(blk):
     return [[host_sum(i, j) for i in range(max_lag + 1)] for j in range(max_lag + 1)]
   phi = lag_matrix_frames([float(v) for v in blk], size, max_lag)[0].tolist()
   all_int = _int_runs(blk)
@@ -182,7 +194,7 @@ def lag_matrix(blk, max_lag=None):
     for i in range(max_lag + 1):
       if all_int(max_lag - i, size - i) and all_int(max_lag - j, size - j):
         phi[j][i] = host_sum(i, j)
-  return phi
+  return [_keep_item_type(blk, row) for row in phi]
 
 
 def toeplitz(vect):

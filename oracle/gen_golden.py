@@ -473,6 +473,26 @@ def generic_item_cases():
   add("mem_cascade_iter_float", CascadeFilter(acc, two, acc)([1., 5., -4., -7., 9.], memory=iter([3., 4., 5., 6., 7., 8., 9.])))
   add("mem_parallel_iter_float", ParallelFilter(acc, two, acc)([1., 5., -4., -7., 9.], memory=iter([3., 4., 5., 6., 7., 8., 9.])))
   add("mem_mutated_after_call", _mutated_memory_case())
+  # constants travel through the generated SOURCE as text (lazy_filters.py:209, 224, 229-231, 236): what is not its own
+  # literal is re-read by the parser -- Fraction(3, 5) -> ``3/5`` (float arithmetic), a Fraction gain a/b -> ``(...) / a/b``,
+  # -1j -> ``(-0-1j)`` (positive zero real part), numpy / Decimal scalars -> plain floats, ``zero`` of a term-less filter
+  # -> the literal of its text (round 5)
+  from decimal import Decimal
+  add("text_fraction_coefficients", ZFilter([Fraction(3, 5), 1], [1, Fraction(-1, 4)])([1, 2, 3], zero=0))
+  add("text_fraction_gain", ZFilter([1, 2], [Fraction(3, 2), -1])([1, 2, 3], zero=0))
+  add("text_fraction_coefficient_fraction_items", ZFilter([Fraction(3, 5)], [1])([Fraction(1, 3), Fraction(2, 7)], zero=0))
+  add("text_negative_fraction_denominator", ZFilter([1], [1, Fraction(-3, 7), Fraction(2, 9)])([1, 2, 3, 4], zero=0))
+  add("text_zero_fraction_whole", ZFilter([0], [1])([1, 2], zero=Fraction(3)))
+  add("text_zero_fraction", ZFilter([0], [1])([1, 2], zero=Fraction(-5, 4)))
+  add("text_zero_complex", ZFilter([0], [1])([1, 2], zero=-2j))
+  add("text_gain_minus_1j", ZFilter([1, 1], [-1j, .5])([1., 2., 3.]))
+  add("text_gain_2j", ZFilter([1, 1], [2j, .5])([1., 2., 3.]))
+  add("text_complex_denominator", ZFilter([1], [1, -2j])([1., 2., 3.]))
+  add("text_bool_coefficient", ZFilter([True, 2], [1])([1, 2, 3], zero=0))
+  add("text_numpy_int_coefficient", ZFilter([np.int64(3), 2], [1])([1, 2, 3], zero=0))
+  add("text_numpy_complex_coefficient", ZFilter([np.complex128(1 + 2j), 2], [1])([1, 2, 3], zero=0))
+  add("text_numpy_float_coefficient_complex_items", ZFilter([np.float64(.1), 2], [1, np.float64(-.5)])([1j, 2, 3 - 1j]))
+  add("text_decimal_coefficient", ZFilter([Decimal("0.1"), 2], [1])([1, 2, 3], zero=0))
   return out
 
 

@@ -1,4 +1,4 @@
-"""The algebra behind the dot-product zero-state pass (tools/experiments/alz_scan_gemm.hip is its HIP form):
+"""The algebra behind the dot-product zero-state pass (its HIP form is k_cdot in audiolazy_amd/csrc/alz_scan.hip since round 5):
 the NumPy prototype must reproduce the cascade's own chunk end states and the serial outputs."""
 import os
 import runpy

@@ -46,6 +46,29 @@ def test_complex_items_and_coefficients():
   check("complex_series", (Stream(itertools.cycle([1j, 2.])) + z ** -1)([1., 2., 3., 4.]))
 
 
+def test_constants_travel_as_text():
+  """The reference formats constant coefficients, the gain and a term-less filter's ``zero`` into generated source
+  (lazy_filters.py:209, 224, 229-231, 236): what is not its own literal is re-read by the parser.  Values AND types
+  from the reference (round 5; all of these stay on the per-sample path)."""
+  from decimal import Decimal
+  from audiolazy_amd import ZFilter
+  check("text_fraction_coefficients", ZFilter([Fraction(3, 5), 1], [1, Fraction(-1, 4)])([1, 2, 3], zero=0))
+  check("text_fraction_gain", ZFilter([1, 2], [Fraction(3, 2), -1])([1, 2, 3], zero=0))
+  check("text_fraction_coefficient_fraction_items", ZFilter([Fraction(3, 5)], [1])([Fraction(1, 3), Fraction(2, 7)], zero=0))
+  check("text_negative_fraction_denominator", ZFilter([1], [1, Fraction(-3, 7), Fraction(2, 9)])([1, 2, 3, 4], zero=0))
+  check("text_zero_fraction_whole", ZFilter([0], [1])([1, 2], zero=Fraction(3)))
+  check("text_zero_fraction", ZFilter([0], [1])([1, 2], zero=Fraction(-5, 4)))
+  check("text_zero_complex", ZFilter([0], [1])([1, 2], zero=-2j))
+  check("text_gain_minus_1j", ZFilter([1, 1], [-1j, .5])([1., 2., 3.]))
+  check("text_gain_2j", ZFilter([1, 1], [2j, .5])([1., 2., 3.]))
+  check("text_complex_denominator", ZFilter([1], [1, -2j])([1., 2., 3.]))
+  check("text_bool_coefficient", ZFilter([True, 2], [1])([1, 2, 3], zero=0))
+  check("text_numpy_int_coefficient", ZFilter([np.int64(3), 2], [1])([1, 2, 3], zero=0))
+  check("text_numpy_complex_coefficient", ZFilter([np.complex128(1 + 2j), 2], [1])([1, 2, 3], zero=0))
+  check("text_numpy_float_coefficient_complex_items", ZFilter([np.float64(.1), 2], [1, np.float64(-.5)])([1j, 2, 3 - 1j]))
+  check("text_decimal_coefficient", ZFilter([Decimal("0.1"), 2], [1])([1, 2, 3], zero=0))
+
+
 def test_matrix_items_with_matrix_coefficient_streams():
   """tests/test_filters_extdep.py:49-89 of the reference: 2x2 matrix coefficient Streams on a 2x3 matrix signal."""
   from audiolazy_amd import Stream, z

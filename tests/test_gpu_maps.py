@@ -106,6 +106,37 @@ def test_envelope_strategies_through_the_stream_protocol(alz):
       assert same_bits(got, unhex(case["r"])), case["lag"]
 
 
+def test_envelope_square_switch(alz, oracle):
+  """``envelope.square = "mul"`` (round 5): an existing Stream pipeline squares as ``x * x`` on the device (input map of
+  the lowpass kernel, the root as a device map per block) instead of the reference's per-sample ``x ** 2``.  Against the
+  reference-generated vectors: within 1e-15 normalised (one ulp in ~8.5e-4 of the squares; contract
+  1e-6); against the ``x * x`` definition itself (the oracle on squared input): bit-identical.  Default "pow" unchanged."""
+  assert alz.envelope.square == "pow"
+  x = np.array(XS)
+  try:
+    alz.envelope.square = "mul"
+    for case in G["callers"]:
+      if case["fn"] not in ("envelope.rms", "envelope.squared"):
+        continue
+      strat, cutoff = case["fn"].split(".")[1], unhex(case["cutoff"])
+      got = np.array(list(getattr(alz.envelope, strat)(XS, cutoff)))
+      want = np.array(unhex(case["r"]))
+      assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-15 * np.max(np.abs(want)), strat
+      f = alz.lowpass(cutoff)
+      ref = oracle.bank([len(f.numlist)], [len(f.denlist)], np.array(f.numlist), np.array(f.denlist), (x * x)[:, None])[:, 0]
+      assert same_bits(got, np.sqrt(ref) if strat == "rms" else ref), strat
+    # the abs strategy does not depend on the switch
+    case = [c for c in G["callers"] if c["fn"] == "envelope.abs"][0]
+    assert same_bits(list(alz.envelope.abs(XS, unhex(case["cutoff"]))), unhex(case["r"]))
+    alz.envelope.square = "cube"
+    with pytest.raises(ValueError):
+      alz.envelope.rms(XS, .02)
+  finally:
+    alz.envelope.square = "pow"
+  case = [c for c in G["callers"] if c["fn"] == "envelope.rms"][0]
+  assert same_bits(list(alz.envelope.rms(XS, unhex(case["cutoff"]))), unhex(case["r"]))
+
+
 @pytest.mark.parametrize("layout", ["time", "chan"])
 @pytest.mark.parametrize("C", [4096, 16384, 100])
 def test_fused_abs_in_front_of_the_lowpass_bank(alz, oracle, layout, C):

@@ -145,7 +145,9 @@ def test_fused_time_parallel_cascade(alz, oracle, strategy, streams, bands, n):
   y = bank.process(torch.from_numpy(x).cuda(), layout="chan").cpu().numpy()
   # (sampled: +-1e3 numerator taps with heavy cancellation, SURVEY.md 8a -- carried through the fused chunk-state
   # recursion they measured 2e-6, so that strategy's first section is split: its numerator runs feedback-free and
-  # exact (k_fir_cm), its denominator joins the fused cascade as one more biquad-class section: the bar there is 1e-8)
+  # exact (k_fir_cm), its recursion SERIALLY and exactly over that output (launch_section; chunked it still measured
+  # 2e-6), and only sections 1 .. 3 run fused and chunked, in place over the result (csrc/alz_api.hip): the bar there
+  # is 1e-8)
   fused_mode = True
   assert ("k_cscan" in bank.last_kernel) == fused_mode, bank.last_kernel
   if strategy == "sampled":
@@ -164,6 +166,32 @@ def test_fused_time_parallel_cascade(alz, oracle, strategy, streams, bands, n):
   y3 = bank.process(torch.from_numpy(x3).cuda(), layout="chan").cpu().numpy()
   ref3 = gammatone_reference(alz, oracle, fcs, Hz, np.concatenate([x, x2, x3], axis=1), strategy)[:, n + (1 << 14):]
   assert norm_err(y3, ref3, 1) <= tol
+
+
+def test_split_first_section_followed_by_full_biquads(alz, oracle):
+  """The split form is not gammatone.sampled's alone: ANY cascade whose first section has more than three numerator taps
+  (and two poles) takes it in the time-parallel mode.  Here the sections behind it are full biquads (three numerator
+  taps: their chunks need two samples of input history each), and they run IN PLACE over the first section's output
+  (x == y in the fused replay) -- the round-4 advisor's untested path.  Bar: 1e-8, as for gammatone.sampled."""
+  import torch
+  B, n = 64, 1 << 15
+  rng = np.random.default_rng(21)
+  r, th = rng.uniform(0.9, 0.995, (3, B)), rng.uniform(0.05, 2.5, (3, B))
+  secs = []
+  for s in range(3):
+    nb = 5 if s == 0 else 3
+    b = rng.uniform(-1, 1, (B, nb))
+    a = np.stack([np.ones(B), -2 * r[s] * np.cos(th[s]), r[s] ** 2], axis=1)
+    secs.append((b, a))
+  bank = alz.FilterBank(secs, n_inputs=1, mode="outer").set_time_parallel(True)
+  bank.reset()
+  x = rng.uniform(-1, 1, (1, 2 * n))
+  bcat, acat = np.concatenate([b for b, _ in secs], axis=1), np.concatenate([a for _, a in secs], axis=1)
+  ref = oracle.bank([5, 3, 3], [3, 3, 3], bcat, acat, np.tile(x, (B, 1)), layout="chan")
+  for k in range(2):                # the second block continues from the state the first one left
+    y = bank.process(torch.from_numpy(np.ascontiguousarray(x[:, k * n:(k + 1) * n])).cuda(), layout="chan").cpu().numpy()
+    assert "k_fir" in bank.last_kernel and "k_cscan" in bank.last_kernel, bank.last_kernel
+    assert norm_err(y, ref[:, k * n:(k + 1) * n], 1) <= 1e-8
 
 
 def test_fused_time_parallel_cascade_explicit_chunks_and_fallback(alz, oracle):
