@@ -488,10 +488,24 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
   // do that for free (one biquad-class section, the streaming kernels and k_small); anything else
   // gets the mapped block from one streaming pass (16 B/sample more traffic)
   int pre_fused = 0;
+  bool map_pass = false;
   if (h->input_map) {
     const alz::SectionDev &s0 = h->sec[0];
-    const bool fusable = h->input_map == ALZ_MAP_ABS && h->n_sections == 1 && s0.nb <= 3 && s0.na <= 3 &&
-                         s0.uniform && (s0.present_b | s0.present_a) != 0 && h->time_parallel == 0 && !h->fused;
+    bool fusable = h->input_map == ALZ_MAP_ABS && h->n_sections == 1 && s0.nb <= 3 && s0.na <= 3 &&
+                   s0.uniform && (s0.present_b | s0.present_a) != 0 && !h->fused;
+    if (fusable && h->time_parallel != 0) {
+      // time-parallel mode: only the one-pass kernel reads through the map (alz_look.hip); where the three-launch form
+      // will run, the mapped block comes from a streaming pass as before
+      alz::BlockIO probe;
+      probe.n = n; probe.pre_op = ALZ_MAP_ABS; probe.channels = h->channels; probe.n_inputs = h->n_inputs; probe.n_sets = h->n_sets;
+      probe.mode = h->mode; probe.zero = h->zero; probe.fused = h->fused; probe.stream_once = 0;
+      probe.x = x_dev; probe.y = y_dev;
+      probe.sxn = layout == ALZ_TIME_MAJOR ? ldx : 1; probe.sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
+      probe.syn = layout == ALZ_TIME_MAJOR ? ldy : 1; probe.syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
+      probe.map_input = (h->mode == ALZ_BANK_OUTER && (h->n_inputs % 64) == 0) ? 1 : 0;
+      probe.c_first = 0; probe.c_count = h->channels;
+      fusable = h->mode != ALZ_BANK_OUTER && alz::scan_takes_one_pass(s0, probe, h->time_parallel);
+    }
     if (fusable) {
       pre_fused = ALZ_MAP_ABS;
     } else {
@@ -502,6 +516,7 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
       rc = alz::launch_map(h->input_map, x_dev, nullptr, 0.0, 0.0, (int64_t)extent, h->map_in, nullptr, st);
       if (rc) return rc;
       x_dev = h->map_in;
+      map_pass = true;
     }
   }
 
@@ -526,6 +541,7 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
     if (!h->last_kernels.empty()) h->last_kernels += "+";
     h->last_kernels += k;
   };
+  if (map_pass) note("k_map");          // (the input map as a streaming pass of its own)
 
   // opt-in time-parallel mode, whole fused cascade at once (channel-major blocks): the chunks of the time axis
   // become the cascade kernel's channels, read straight from the un-expanded input (alz_scan.hip)

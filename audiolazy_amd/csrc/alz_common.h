@@ -169,6 +169,10 @@ int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int6
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name);
 constexpr int64_t kLookChunk = 512;
+// whether launch_look would take this section and block (shape only; `cus` = the device's CU count)
+bool look_takes(const SectionDev &sec, const BlockIO &io, int cus);
+// whether launch_scan would send this section and block to the one-pass form for the handle's chunk-length setting
+bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk_len);
 // time-parallel execution of a whole fused cascade (see alz_scan.hip) on a channel-major block, or a time-major one whose
 // channels come in whole groups of 64; *taken = false when the shape is not covered (nothing written but scratch).
 // state_consistent: every section's input history equals its predecessor's output history (true after reset and after

@@ -37,10 +37,21 @@
 //
 // Every output sample is still the reference's DF-I statement (lazy_filters.py:197-257) in the kernels' own order;
 // only the chunk-start states carry a different rounding -- the same numerics as the three-launch mode (1e-10 ..
-// 1e-9 on the configs[1] resonators).  Time-major blocks, a0 == 1, channels % 16 == 0, blocks of whole 512-sample
-// chunks; everything else stays on the three-launch mode.
+// 1e-9 on the configs[1] resonators).  a0 == 1, channels % 16 == 0, blocks of whole 512-sample chunks; everything else
+// stays on the three-launch mode.
+//
+// Round 5: both layouts, the |x| input map, in place.  CM (channel-major blocks [C, N]): a tile arrives as eight 1 KiB
+// transfers of two channel rows each (k_duo's channel-major DMA layout) and LOAD's feed-forward pass -- which reads the
+// whole tile into registers before it writes anything -- leaves p in rows of one CHANNEL (528-byte pitch: the replay's
+// four skewed copies then read and write eight bytes apart, conflict-free per half-wave), from which HELP stores 16-byte
+// pieces of a channel's row.  PRE = 1: |x| on LOAD's reads (the bank's input history is kept mapped, as k_duo keeps it).
+// In place (x == y): a tile is stored long after it was read, and by the workgroup that read it; only the two rows in
+// front of a chunk belong to another workgroup, so a small launch saves those for every chunk first (k_look_hsave).
 #include "alz_common.h"
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace alz {
 
@@ -88,6 +99,8 @@ struct LArgs {
   double *xh, *yh;             // the bank's state [taps-1][channels]
   const double *power;         // M = A^512 per channel: [4][channels] (M11 M12 M21 M22)
   unsigned long long *z;       // [groups][n_chunks][2][16] published zero-state end states
+  const double *hsave;         // in place: the two input rows in front of every chunk, [groups][n_chunks][32] in the
+                               // history transfer's own order (time-major [2][16], channel-major [16][2]); else nullptr
   int *err;                    // set when a spin ran into its cap
   int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no replay arithmetic,
                                // 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain,
@@ -139,10 +152,10 @@ __device__ __forceinline__ void store16(double *gdst, dbl2 v) {
 //   k1..k3  p of the previous tile's last three rows (the lagging copies' first steps; the replay has overwritten
 //           them by now), replaced by this tile's for the next call
 struct LookState { double m1, m2, t2, k1, k2, k3; };
-template <unsigned PA, bool CS>
+template <unsigned PA, bool CS, int kStep>
 __device__ __forceinline__ void look_tile(char *cur, const char *nxt, int q, double s1, double s2, double na1,
                                           double na2, LookState &st, double (&pr)[4][8]) {
-  constexpr int T = 64, kStep = 128, NCH = T / 8;
+  constexpr int T = 64, NCH = T / 8;
   double m1 = st.m1, m2 = st.m2, t2 = st.t2;
   double n1 = 0.0, n2 = 0.0, n3 = 0.0;
 #pragma unroll
@@ -248,11 +261,20 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 #define ALZ_LOOK_MARK(k)
 #endif
 
-template <unsigned PB, unsigned PA>
+constexpr int kChanPitch = 64 * 8 + 16;       // channel-major p / y rows in a tile slot
+constexpr int kSlotCM = 16 * kChanPitch;      // 8448 bytes (the DMA layout's 8 x 1040 fits inside)
+template <int PRE>
+__device__ __forceinline__ double look_pre(double v) {
+  if constexpr (PRE == 1) return __builtin_fabs(v);
+  return v;
+}
+
+template <unsigned PB, unsigned PA, bool CM, int PRE>
 __global__ __launch_bounds__(256) void k_look(LArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64, NT = kNT;
-  constexpr int kStep = G * 8;
+  constexpr int kStep = CM ? 8 : G * 8;        // bytes from a channel's sample to its next in the p / y image of a tile
+  constexpr int kSlot = CM ? kSlotCM : alz::kSlot;
   // The four waves each run their own loop over this workgroup's tile sequence and meet only through progress
   // counters (no barrier after the first: a barrier per tile made every wave wait for the slowest of each interval,
   // memory stalls included).  In its iteration i
@@ -284,8 +306,10 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   int *flags = reinterpret_cast<int *>(sbuf + 512);           // [F_COUNT] progress counters
   int cap = 1 << 22;                                          // (~0.3 s of polling)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const int lane_off = cl * 8;
-#define ALZ_EOFF(u) ((u) * G * 8 + (((u) * G) >> 7) * 16)
+  const int lane_off = CM ? cl * kChanPitch : cl * 8;        // the lane's channel in the p / y image of a tile
+  // the same channel in the tile as the DMA leaves it (channel-major: transfer cl / 2, its first or second 512 bytes)
+  const int xlane_off = CM ? (cl >> 1) * (1024 + 16) + (cl & 1) * 512 : cl * 8;
+#define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
   // global row of tile t's first sample: chunk (w + (t / NT) W), tile t % NT of it
   auto tile_row = [&](int t) -> int64_t { return ((int64_t)w + (int64_t)(t / NT) * W) * (NT * T) + (t % NT) * T; };
   unsigned long long *zg = p.z + group * K * 32;              // this group's [K][2][16]
@@ -298,8 +322,10 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   if (wave == 1) {
     // ------------------------------ LOAD ------------------------------
     const int row = lane / 8, cp = lane % 8;
-    const double *xg = p.x + (int64_t)row * p.ldx + c0 + 2 * cp;
-    const int64_t x_chunk = 8 * p.ldx;
+    // time-major: transfer j = rows 8 j .. 8 j + 7 of the tile, 128 bytes (16 channels) each;
+    // channel-major: transfer j = channels 2 j, 2 j + 1, the tile's 512 bytes of each
+    const double *xg = CM ? p.x + (c0 + (lane >> 5)) * p.ldx + 2 * (lane & 31) : p.x + (int64_t)row * p.ldx + c0 + 2 * cp;
+    const int64_t x_chunk = CM ? 2 * p.ldx : 8 * p.ldx;
     double b0 = 0, b1 = 0, b2 = 0;
     if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
     if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
@@ -312,40 +338,49 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
     auto queue_tile = [&](int t) {
       const int s = t % kSlots;
       const int64_t r0 = tile_row(t);
-      const double *src = xg + r0 * p.ldx;
+      const double *src = CM ? xg + r0 : xg + r0 * p.ldx;
 #pragma unroll
       for (int j = 0; j < kChunks; ++j) dma16(src + j * x_chunk, lds0 + s * kSlot + j * (1024 + 16));
-      // rows r0 - 2, r0 - 1 (clamped to row 0 for the very first tile, which uses the bank's history instead)
+      // rows r0 - 2, r0 - 1 (clamped to row 0 for the very first tile, which uses the bank's history instead):
+      // time-major [2][16] -- lane l: row l / 8, channels 2 (l % 8), + 1; channel-major [16][2] -- lane l: channel l.
+      // In place, the rows in front of a CHUNK are another workgroup's to overwrite: those come from the saved copy.
       const int64_t rh = r0 >= 2 ? r0 - 2 : 0;
-      const double *hsrc = p.x + (rh + (lane >> 3 & 1)) * p.ldx + c0 + 2 * (lane & 7);
+      const double *hsrc = CM ? p.x + (c0 + (lane & 15)) * p.ldx + rh : p.x + (rh + (lane >> 3 & 1)) * p.ldx + c0 + 2 * (lane & 7);
+      if (p.hsave && (t % NT) == 0 && r0 > 0) hsrc = p.hsave + (group * K + r0 / (NT * T)) * 32 + 2 * (lane & 15);
       if (lane < 16) dma16(hsrc, lds0 + (unsigned)(hist - smem) + s * kHist);
     };
     auto prepare_tile = [&](int t) {
-      char *xs = smem + (t % kSlots) * kSlot + lane_off;
-      const char *hs = hist + (t % kSlots) * kHist + cl * 8;
-      const int adj1 = (q == 0) ? 16 : 0, adj2 = (q < 2) ? 16 : 0;
-      const char *x_d0 = xs + q * kStep;
-      const char *x_d1[2] = {xs + (q - 1) * kStep - adj1, xs + (q - 1) * kStep};   // [j odd]
-      const char *x_d2[2] = {xs + (q - 2) * kStep - adj2, xs + (q - 2) * kStep};
+      char *ps = smem + (t % kSlots) * kSlot + lane_off;            // where the lane's p goes
+      const char *xs = smem + (t % kSlots) * kSlot + xlane_off;     // where its x lies (time-major: the same column)
+      const char *hs = hist + (t % kSlots) * kHist + (CM ? cl * 16 : cl * 8);
+      // (time-major: 16 bytes of pad after every eighth row of the landed tile; sample 4 j + q - 1 / - 2 lies before the
+      // pad of sample 4 j + q's block when j is even and q is small)
+      const int adj1 = (!CM && q == 0) ? 16 : 0, adj2 = (!CM && q < 2) ? 16 : 0;
+      constexpr int kXStep = CM ? 8 : G * 8;
+      const char *x_d0 = xs + q * kXStep;
+      const char *x_d1[2] = {xs + (q - 1) * kXStep - adj1, xs + (q - 1) * kXStep};   // [j odd]
+      const char *x_d2[2] = {xs + (q - 2) * kXStep - adj2, xs + (q - 2) * kXStep};
       double x0[16], x1[16], x2[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if constexpr (PB & 1u) x0[j] = *reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j));
+        if constexpr (PB & 1u) x0[j] = look_pre<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
         if constexpr (PB & 2u) {
-          if (j > 0) x1[j] = *reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j));
+          if (j > 0) x1[j] = look_pre<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
         }
         if constexpr (PB & 4u) {
-          if (j > 0) x2[j] = *reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j));
+          if (j > 0) x2[j] = look_pre<PRE>(*reinterpret_cast<const double *>(x_d2[j & 1] + ALZ_EOFF(4 * j)));
         }
       }
       if constexpr ((PB & 6u) != 0) {
         // x[-2], x[-1] relative to this tile: the landed history rows, or the bank's history at the start of the stream
+        // (which the bank keeps MAPPED, like k_duo)
         const bool stream_start = tile_row(t) == 0;
-        const double q2 = *reinterpret_cast<const double *>(hs), q1 = *reinterpret_cast<const double *>(hs + 128);
+        const double q2 = look_pre<PRE>(*reinterpret_cast<const double *>(hs));
+        const double q1 = look_pre<PRE>(*reinterpret_cast<const double *>(hs + (CM ? 8 : 128)));
         const double pm1 = stream_start ? hh1 : q1, pm2 = stream_start ? hh2 : q2;
-        const double s0 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(0));
-        const double s1 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(1));
-        const double s2 = *reinterpret_cast<const double *>(xs + ALZ_EOFF(2));
+        const double s0 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(0)));
+        const double s1 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(1)));
+        const double s2 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(2)));
         if constexpr (PB & 2u) x1[0] = q == 0 ? pm1 : q == 1 ? s0 : q == 2 ? s1 : s2;
         if constexpr (PB & 4u) x2[0] = q == 0 ? pm2 : q == 1 ? pm1 : q == 2 ? s0 : s1;
       }
@@ -359,10 +394,11 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         if constexpr (PB & 4u) { const double t2 = bb2 * x2[j]; v = first ? t2 : v + t2; first = false; }
         acc[j] = v;
       }
-      // in place: every read of the tile is done (one wave, program order), p goes to unpadded rows of the same slot
+      // in place: every read of the tile is done (one wave, program order: the whole tile is in registers), p goes to
+      // unpadded rows of the same slot (channel-major: to rows of one channel each, a different image than the DMA's)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int j = 0; j < 16; ++j) *reinterpret_cast<double *>(xs + (4 * j + q) * kStep) = acc[j];
+      for (int j = 0; j < 16; ++j) *reinterpret_cast<double *>(ps + (4 * j + q) * kStep) = acc[j];
     };
     // the input history the bank keeps for the next block: the last two x rows of the block (owner of the last chunk)
     const bool owns_last = ((K - 1) % W) == w;
@@ -388,9 +424,9 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (i + 1 < TOT) {
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
-          const char *xs = smem + ((i + 1) % kSlots) * kSlot + lane_off;
-          if (p.nb > 1) p.xh[0 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1));
-          if (p.nb > 2) p.xh[1 * p.channels + c] = *reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2));
+          const char *xs = smem + ((i + 1) % kSlots) * kSlot + xlane_off;
+          if (p.nb > 1) p.xh[0 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
+          if (p.nb > 2) p.xh[1 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
         }
         ALZ_LOOK_MARK(2)
         if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
@@ -407,8 +443,9 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   } else if (wave == 2) {
     // ------------------------------ HELP ------------------------------
     const int row = lane / 8, cp = lane % 8;
-    double *yg = p.y + (int64_t)row * p.ldy + c0 + 2 * cp;
-    const int64_t y_chunk = 8 * p.ldy;
+    // store j of a tile -- time-major: rows 8 j .. 8 j + 7 (128 bytes each); channel-major: 512 bytes of channels 2 j, 2 j + 1
+    double *yg = CM ? p.y + (c0 + (lane >> 5)) * p.ldy + 2 * (lane & 31) : p.y + (int64_t)row * p.ldy + c0 + 2 * cp;
+    const int64_t y_chunk = CM ? 2 * p.ldy : 8 * p.ldy;
     // The zero-state end state of a tile is a dot product, not a recurrence: with h the impulse response of 1/A(z),
     // (y[63], y[62]) = sum_r (h[63-r], h[62-r]) p[r].  This lane takes rows 4 j + q: its 2 x 16 weights, and
     // A^64 = [[h64, -a2 h63], [h63, -a2 h62]] to carry the sum from tile to tile, come from 65 steps of h's own
@@ -447,16 +484,17 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       if (zs_on) {
         const char *zsrc = smem + (i % kSlots) * kSlot + lane_off + q * kStep;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) zp[j] = *reinterpret_cast<const double *>(zsrc + j * 512);
+        for (int j = 0; j < 16; ++j) zp[j] = *reinterpret_cast<const double *>(zsrc + j * 4 * kStep);
       }
       if (i < TOT) publish(flags + F_ZDONE, i + 1, lane);    // (behind the reads in the LDS's order: the replay may overwrite)
       // the tile the replay has finished
       if (st_on) {
         const char *ys = smem + (ts % kSlots) * kSlot;
-        double *yt = yg + tile_row(ts) * p.ldy;
+        double *yt = CM ? yg + tile_row(ts) : yg + tile_row(ts) * p.ldy;
         dbl2 v[kChunks];
 #pragma unroll
-        for (int j = 0; j < kChunks; ++j) v[j] = *reinterpret_cast<const dbl2 *>(ys + j * 1024 + lane * 16);
+        for (int j = 0; j < kChunks; ++j)
+          v[j] = *reinterpret_cast<const dbl2 *>(CM ? ys + (2 * j + (lane >> 5)) * kChanPitch + (lane & 31) * 16 : ys + j * 1024 + lane * 16);
         publish(flags + F_STORED, ts + 1, lane);             // (behind the reads in the LDS's order: the slot is free)
         if (!ALZ_DBG(p, 8)) {
 #pragma unroll
@@ -596,10 +634,10 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         if (!ALZ_DBG(p, 2)) {
           const double s1 = *reinterpret_cast<const double *>(sbuf + (seq & 1) * 256 + cl * 8);
           const double s2 = *reinterpret_cast<const double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8);
-          look_tile<PA, true>(cur, nxt, q, s1, s2, na1, na2, st, pr);
+          look_tile<PA, true, kStep>(cur, nxt, q, s1, s2, na1, na2, st, pr);
         }
       } else if (!ALZ_DBG(p, 2)) {
-        look_tile<PA, false>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
+        look_tile<PA, false, kStep>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
       }
       ALZ_LOOK_MARK(0)
       publish(flags + F_REPLAYED, t + 1, lane);              // (behind the tile's writes in the LDS's order)
@@ -625,45 +663,98 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 #undef ALZ_LOOK_MARK
 
 typedef void (*look_fn)(LArgs);
-static look_fn pick_look(unsigned pb, unsigned pa) {
-#define ALZ_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) return (look_fn)k_look<PB_, PA_>;
+template <bool CM, int PRE>
+static look_fn pick_look_in(unsigned pb, unsigned pa) {
+#define ALZ_PAT(PB_, PA_) if (pb == PB_ && pa == PA_) return (look_fn)k_look<PB_, PA_, CM, PRE>;
   ALZ_PAT(1, 1) ALZ_PAT(3, 1) ALZ_PAT(1, 3) ALZ_PAT(3, 3) ALZ_PAT(5, 3) ALZ_PAT(7, 3) ALZ_PAT(1, 2)
 #undef ALZ_PAT
   return nullptr;
 }
+static look_fn pick_look(unsigned pb, unsigned pa, bool cm, int pre) {
+  if (pre == 0) return cm ? pick_look_in<true, 0>(pb, pa) : pick_look_in<false, 0>(pb, pa);
+  if (pre == ALZ_MAP_ABS) return cm ? pick_look_in<true, 1>(pb, pa) : pick_look_in<false, 1>(pb, pa);
+  return nullptr;
+}
 
-// One-pass time-parallel run of a biquad-class section over whole 512-sample chunks of a time-major block.
-// `power` = the section's M = A^512 per channel ([4][channels], alz_scan.hip); `zbuf` (>= groups * chunks * 32 doubles)
-// and `err` are scratch of the handle.  *done_samples: the whole chunks covered (0: not this kernel's shape).
+// in place: the two input rows in front of every chunk, saved before any workgroup overwrites them (LArgs::hsave)
+__global__ __launch_bounds__(256) void k_look_hsave(const double *x, int64_t ldx, int cm, int64_t groups, int64_t K, double *hsave) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= groups * K * 32) return;
+  const int64_t gk = i >> 5, g = gk / K, j = gk - g * K;
+  const int e = (int)(i & 31);
+  if (j == 0) return;                                   // (chunk 0 starts from the bank's own history)
+  const int r = cm ? (e & 1) : (e >> 4), ch = cm ? (e >> 1) : (e & 15);
+  const int64_t t = j * kLookChunk - 2 + r, c = g * 16 + ch;
+  hsave[i] = cm ? x[c * ldx + t] : x[t * ldx + c];
+}
+
+// The shape test of the one-pass form, without side effects: what launch_look itself checks before it touches anything
+// (the caller uses it to decide whether an input map may ride on the kernel's reads).
+bool look_takes(const SectionDev &sec, const BlockIO &io, int cus) {
+  if (!(sec.nb <= 3 && sec.na <= 3 && sec.na >= 2 && sec.uniform) || sec.any_div || io.fused) return false;
+  const bool cm = io.sxn == 1 && io.syn == 1, tm = io.sxc == 1 && io.syc == 1;
+  if (!(cm || tm) || io.map_input) return false;
+  const int64_t C = io.channels, L = kNT * 64;
+  if (C % 16 || io.c_first != 0 || io.c_count != C) return false;
+  if (io.x == io.y && (io.sxn != io.syn || io.sxc != io.syc)) return false;
+  const int64_t ldx = (cm && !tm) ? io.sxc : io.sxn, ldy = (cm && !tm) ? io.syc : io.syn;
+  if ((((uintptr_t)io.x | (uintptr_t)io.y) & 15) || ((ldx | ldy) & 1)) return false;
+  const int64_t K = io.n / L, groups = C / 16;
+  int64_t W = groups > 0 ? cus / groups : 0;
+  if (W > K) W = K;
+  if (W > kMaxW) W = kMaxW;
+  if (W < 2 || K < 4) return false;
+  return pick_look(sec.present_b, sec.present_a, cm && !tm, io.pre_op) != nullptr;
+}
+
+// One-pass time-parallel run of a biquad-class section over whole 512-sample chunks of a block (either layout, also in
+// place, optionally with |x| on the input reads).  `power` = the section's M = A^512 per channel ([4][channels],
+// alz_scan.hip); `zbuf` (>= 2 x groups * chunks * 32 doubles: the published states, then the saved history rows of an
+// in-place run) and `err` are scratch of the handle.  *done_samples: the whole chunks covered (0: not this kernel's shape).
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name) {
   *done_samples = 0;
-  if (!(sec.nb <= 3 && sec.na <= 3 && sec.na >= 2 && sec.uniform) || sec.any_div || io.fused) return ALZ_OK;
-  const bool tm = io.sxc == 1 && io.syc == 1;
-  if (!tm || io.map_input || io.pre_op) return ALZ_OK;
-  const int64_t C = io.channels, L = kNT * 64;
-  if (C % 16 || io.c_first != 0 || io.c_count != C || io.x == io.y) return ALZ_OK;
-  if ((((uintptr_t)io.x | (uintptr_t)io.y) & 15) || ((io.sxn | io.syn) & 1)) return ALZ_OK;
-  const int64_t K = io.n / L, groups = C / 16;
   // every workgroup of the launch must be resident (one per CU: 137 KiB of LDS each)
-  int dev = 0, cus = 0;
+  int dev = 0;
   ALZ_HIP_CHECK(hipGetDevice(&dev));
-  ALZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // device attributes and the kernel's occupancy are constants of (device, kernel): asked once (round-4 advisor)
+  struct DevInfo { int cus = 0, coop = -1; };
+  static std::mutex mu;
+  static std::map<int, DevInfo> devs;
+  static std::map<std::pair<int, const void *>, int> per_cu_of;
+  DevInfo di;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    DevInfo &d = devs[dev];
+    if (d.coop < 0) {
+      ALZ_HIP_CHECK(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
+      ALZ_HIP_CHECK(hipDeviceGetAttribute(&d.coop, hipDeviceAttributeCooperativeLaunch, dev));
+    }
+    di = d;
+  }
+  const int cus = di.cus;
+  if (!look_takes(sec, io, cus)) return ALZ_OK;
+  const bool cm = io.sxn == 1 && io.syn == 1 && !(io.sxc == 1 && io.syc == 1);
+  const int64_t C = io.channels, L = kNT * 64;
+  const int64_t K = io.n / L, groups = C / 16;
   int W = (int)(cus / groups);
   if (W > K) W = (int)K;
   if (W > kMaxW) W = kMaxW;
-  if (W < 2 || K < 4) return ALZ_OK;
-  if ((uint64_t)groups * K * 32 * sizeof(double) > zbuf_bytes) return ALZ_OK;
-  look_fn fn = pick_look(sec.present_b, sec.present_a);
+  const bool inplace = io.x == io.y;
+  const uint64_t zdoubles = (uint64_t)groups * K * 32;
+  if ((inplace ? 2 : 1) * zdoubles * sizeof(double) > zbuf_bytes) return ALZ_OK;
+  look_fn fn = pick_look(sec.present_b, sec.present_a, cm, io.pre_op);
   if (!fn) return ALZ_OK;
   LArgs p;
-  p.x = io.x; p.y = io.y; p.ldx = io.sxn; p.ldy = io.syn; p.n_chunks = K; p.channels = C;
+  p.x = io.x; p.y = io.y; p.ldx = cm ? io.sxc : io.sxn; p.ldy = cm ? io.syc : io.syn; p.n_chunks = K; p.channels = C;
   p.n_inputs = io.mode == ALZ_BANK_OUTER ? io.n_inputs : 0; p.n_sets = io.n_sets; p.workers = W;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   p.power = power; p.z = (unsigned long long *)zbuf; p.err = err;
+  p.hsave = inplace ? zbuf + zdoubles : nullptr;
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
-  const size_t lds = (size_t)kSlots * kSlot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
+  const size_t slot = cm ? (size_t)kSlotCM : (size_t)kSlot;
+  const size_t lds = (size_t)kSlots * slot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
   // Every workgroup of the launch waits on others: they must all be resident at once.  The runtime is asked to
@@ -673,14 +764,26 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   // promise is that OTHER work leaves the CUs free in time: a workgroup that starts late only delays its neighbours,
   // and one that starts later than the spin cap allows makes the kernel give up -- which every entry point of the
   // handle reports (alz_api.hip take_look_error), never a silently bad block.
-  int coop = 0, per_cu = 0;
-  ALZ_HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
-  if (!coop) return ALZ_OK;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 256, lds) != hipSuccess || (int64_t)per_cu * cus < groups * W) {
-    (void)hipGetLastError();
-    return ALZ_OK;
+  if (!di.coop) return ALZ_OK;
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_cu_of.find({dev, (const void *)fn});
+    if (it == per_cu_of.end()) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 256, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+      }
+      per_cu_of[{dev, (const void *)fn}] = per_cu;
+    } else {
+      per_cu = it->second;
+    }
   }
-  ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)groups * K * 32 * sizeof(double), stream));
+  if ((int64_t)per_cu * cus < groups * W) return ALZ_OK;     // (not co-resident: the three-launch form takes the block)
+  if (inplace)
+    hipLaunchKernelGGL(k_look_hsave, dim3((unsigned)((zdoubles + 255) / 256)), dim3(256), 0, stream, io.x, p.ldx, cm ? 1 : 0, groups, K,
+                       zbuf + zdoubles);
+  ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)zdoubles * sizeof(double), stream));
   void *args[] = {(void *)&p};
   if (ALZ_TUNE("ALZ_LOOK_COOP", 1) == 0) {       // (tuning builds: the plain launch of round 3, for A/B timing)
     hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);

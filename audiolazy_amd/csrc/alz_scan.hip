@@ -126,6 +126,41 @@ static int grow_scratch(double **ptr, uint64_t *have, uint64_t need) {
   return ALZ_OK;
 }
 
+// One pass where the shape allows it (a recursive section, whole 512-sample chunks, either layout since round 5):
+// 512-sample chunks resident in LDS, the block read once (alz_look.hip) -- 260 Gsamples/s with 16 B/sample of traffic at
+// 512 channels x 2^20 against 228 with 24 for the three-launch form (profiles/NOTES_r03.md).  ALZ_TP_ONE_PASS asks for
+// it; ALZ_TP_AUTO takes it when its workgroups (one per CU: 16 channels x up to 16 chunks in flight) fill most of the
+// chip, i.e. from about 200 channels up; narrower banks fill the chip better as chunks x channels lanes of the
+// three-launch form.
+static int device_cus() {
+  static int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cached_dev) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cached = cus;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
+bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk_len) {
+  if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform) || sec.any_div || sec.na < 2) return false;
+  if (io.c_first != 0 || io.c_count != io.channels || io.channels % 16) return false;
+  if (io.n < 4 * kLookChunk) return false;
+  const int cus = device_cus();
+  bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
+  if (chunk_len == ALZ_TP_AUTO) {
+    const int64_t groups = io.channels / 16, Kl = io.n / kLookChunk;
+    int64_t wk = groups > 0 ? cus / groups : 0;
+    wk = wk > 16 ? 16 : wk;
+    wk = wk > Kl ? Kl : wk;
+    one_pass = wk >= 2 && 4 * groups * wk >= 3 * (int64_t)cus;
+  }
+  return one_pass && look_takes(sec, io, cus);
+}
+
 int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hipStream_t stream,
                 int64_t chunk_len, ScanScratch *scratch, int64_t *done_samples, const char **kernel_name) {
   *done_samples = 0;
@@ -134,24 +169,9 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
   if (io.c_first != 0 || io.c_count != io.channels) return ALZ_OK;
   const int64_t C = io.channels;
   if (C % 16) return ALZ_OK;
-  // One pass where the shape allows it (time-major block, a recursive section): 512-sample chunks resident in LDS, the
-  // block read once (alz_look.hip) -- 260 Gsamples/s with 16 B/sample of traffic at 512 channels x 2^20 against 228
-  // with 24 for the three-launch form below (profiles/NOTES_r03.md).  ALZ_TP_ONE_PASS asks for it; ALZ_TP_AUTO takes
-  // it when its workgroups (one per CU: 16 channels x up to 16 chunks in flight) fill most of the chip, i.e. from
-  // about 200 channels up; narrower banks fill the chip better as chunks x channels lanes of the three-launch form.
-  bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
-  if (chunk_len == ALZ_TP_AUTO && sec.na > 1 && io.sxc == 1 && io.syc == 1) {
-    int dev = 0, cus = 0;
-    ALZ_HIP_CHECK(hipGetDevice(&dev));
-    ALZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t groups = C / 16, Kl = io.n / kLookChunk;
-    int64_t wk = groups > 0 ? cus / groups : 0;
-    wk = wk > 16 ? 16 : wk;
-    wk = wk > Kl ? Kl : wk;
-    one_pass = wk >= 2 && 4 * groups * wk >= 3 * (int64_t)cus;
-  }
+  const bool one_pass = scan_takes_one_pass(sec, io, chunk_len);
   if (chunk_len < 0) chunk_len = 0;
-  if (one_pass && sec.na > 1 && io.n >= 4 * kLookChunk && io.sxc == 1 && io.syc == 1) {
+  if (one_pass) {
     const int64_t groups = C / 16, Kl = io.n / kLookChunk;
     // (a wait that ran out in an earlier launch is reported by alz_api.hip's take_look_error at every entry point)
     if (!scratch->look_err) {
@@ -159,7 +179,7 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
         return fail(ALZ_E_NOMEM, "hipHostMalloc failed (time-parallel scratch)");
       *scratch->look_err = 0;
     }
-    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double);
+    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) * (io.x == io.y ? 2 : 1);   // (+ the saved history rows of an in-place run)
     uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;
     int rc2 = grow_scratch(&scratch->zbuf, &have_z, zneed);
     if (rc2) return rc2;
@@ -188,6 +208,9 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
       return ALZ_OK;
     }
   }
+  // (the three-launch form below reads the block as it is: an input map fused into the reads is the one-pass kernel's and
+  // the serial kernels' only -- the caller then finishes the section with those)
+  if (io.pre_op) return ALZ_OK;
   // chunk length: a multiple of the longest tile (64 samples); by default short enough that
   // chunks x channels fill the chip (>= 65536 lanes: one 64-lane wave per SIMD)
   int64_t L = chunk_len;
@@ -624,6 +647,108 @@ __global__ __launch_bounds__(64 * SPLIT) void k_cdot(CScanArgs p, const double *
   }
 }
 
+// k_cdot with both operand streams requested one step ahead BY HAND (ALZ_CDOT_V2 builds: A/B against k_cdot).  hipcc rotates
+// a C-level "load next, compute current" loop back into "load, wait, compute" (the k_cdot loop above waits for its four
+// s_load_dwordx16 and its row load in the iteration that issues them: only the other wave of the SIMD hides them), so the
+// responses of the NEXT pair of samples go to a second set of SGPRs and the next 16 bytes of the row to a second VGPR pair
+// through asm statements the scheduler cannot move, with the waits behind the 32 FMAs.  Two bands per workgroup (2 x 16
+// SGPRs per set), so twice the workgroups: 64 KiB of LDS each, two per CU.
+template <int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void k_cdot2(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge) {
+  extern __shared__ __attribute__((aligned(16))) double cd_part2[];  // [SPLIT][16][64]
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef double dbl8 __attribute__((ext_vector_type(8)));
+  constexpr int NS = 2;
+  static_assert((NS * 8) % SPLIT == 0 || SPLIT % (NS * 8) == 0, "the final sums are shared out over the waves");
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ngrp = p.n_sets / NS;
+  const int64_t in = (int64_t)blockIdx.y / ngrp, set0 = ((int64_t)blockIdx.y - in * ngrp) * NS;
+  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls, m1 = m0 + Ls;
+  const double *xrow = p.x + in * p.ldx + j * p.L;
+  double acc[NS][4][2];
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
+  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
+  const double *ha = hr + ((set0 + 0) * p.L + m0) * 4, *hb = hr + ((set0 + 1) * p.L + m0) * 4;   // (wave-uniform)
+  dbl8 ca, cb, na, nb;
+  dbl2 v, vn;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(ca), "=&s"(cb) : "s"(ha), "s"(hb) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(xrow + m0) : "memory");
+  // (consumed here: hipcc then waits for the load of xprev now and puts no s_waitcnt vmcnt(0) of its own into the loop,
+  // where it would wait for the row request just issued)
+  asm volatile("" : "+v"(xprev));
+  for (int64_t m = m0; m < m1; m += 2) {
+    const int64_t step = m + 2 < m1 ? 8 : 0;                    // (the last step requests its own pair again)
+    ha += step; hb += step;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(na), "=&s"(nb) : "s"(ha), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vn) : "v"(xrow + (m + 2 < m1 ? m + 2 : m)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);                          // (the machine scheduler would hoist the FMAs above the requests)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0][s][0] = __builtin_fma(ca[s], v.x, acc[0][s][0]);
+      acc[0][s][1] = __builtin_fma(ca[s], xprev, acc[0][s][1]);
+      acc[0][s][0] = __builtin_fma(ca[4 + s], v.y, acc[0][s][0]);
+      acc[0][s][1] = __builtin_fma(ca[4 + s], v.x, acc[0][s][1]);
+      acc[1][s][0] = __builtin_fma(cb[s], v.x, acc[1][s][0]);
+      acc[1][s][1] = __builtin_fma(cb[s], xprev, acc[1][s][1]);
+      acc[1][s][0] = __builtin_fma(cb[4 + s], v.y, acc[1][s][0]);
+      acc[1][s][1] = __builtin_fma(cb[4 + s], v.x, acc[1][s][1]);
+    }
+    xprev = v.y;
+    __builtin_amdgcn_sched_barrier(0);
+    // the requested operands have landed; tying the buffers to the wait keeps their copies behind it
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(na), "+s"(nb), "+v"(vn) : : "memory");
+    ca = na;
+    cb = nb;
+    v = vn;
+  }
+  const int64_t V = p.K * p.C;
+  if (seg == 0) {
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      const int64_t c = (set0 + a) * p.n_inputs + in;
+      double xm1 = 0.0, xm2 = 0.0;
+      if (p.nb[0] > 1) xm1 = j > 0 ? xrow[-1] : p.xh[0][0 * p.C + c];
+      if (p.nb[0] > 2) xm2 = j > 0 ? xrow[-2] : p.xh[0][1 * p.C + c];
+      const int64_t slot = cs_slot(p, c, j);
+      if (p.nb[0] > 1) p.vxh[0][0 * V + slot] = xm1;
+      if (p.nb[0] > 2) p.vxh[0][1 * V + slot] = xm2;
+      const double *e = edge + (set0 + a) * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          double z = acc[a][s][k];
+          z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
+          z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
+          acc[a][s][k] = z;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) cd_part2[((seg * NS + a) * 8 + 2 * s + k) * 64 + lane] = acc[a][s][k];
+  __syncthreads();
+  for (int q = seg; q < NS * 8; q += SPLIT) {                  // (wave-uniform)
+    const int a = q >> 3, s = (q >> 1) & 3, k = q & 1;
+    if (s >= p.nsec) continue;
+    double z = cd_part2[((0 * NS + a) * 8 + 2 * s + k) * 64 + lane];
+#pragma unroll
+    for (int sg = 1; sg < SPLIT; ++sg) z = z + cd_part2[((sg * NS + a) * 8 + 2 * s + k) * 64 + lane];
+    const int64_t c = (set0 + a) * p.n_inputs + in;
+    p.vyh[s][(int64_t)k * V + cs_slot(p, c, j)] = z;
+  }
+}
+
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
                         ScanScratch *scratch, bool state_consistent, bool *taken, const char **kernel_name) {
   *taken = false;
@@ -700,7 +825,13 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
   // the zero-state pass: dot products with the cascade's impulse responses where the shape offers them (an OUTER bank
   // reading by input index from rows of chunks: channel-major, or the one contiguous column of a one-stream time-major
   // block), else the cascade kernel itself without stores
-  constexpr int NS = 4, SPLIT = 8;
+#ifndef ALZ_CDOT_V2
+#define ALZ_CDOT_V2 0
+#endif
+#ifndef ALZ_CDOT_SPLIT
+#define ALZ_CDOT_SPLIT 8
+#endif
+  constexpr int NS = ALZ_CDOT_V2 ? 2 : 4, SPLIT = ALZ_CDOT_SPLIT;
   const bool dot_pass = state_consistent && by_input && io.x != io.y && io.n_sets % NS == 0 && L % (2 * SPLIT) == 0 &&
                         (((uintptr_t)io.x) & 15) == 0 && (cm ? (p.ldx % 2 == 0) : (io.n_inputs == 1 && p.ldx == 1)) &&
                         (uint64_t)(K / 64) <= 65535u && (uint64_t)(io.n_sets / NS) * (uint64_t)io.n_inputs <= 65535u;
@@ -718,11 +849,18 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
       scratch->tab_len = L;
     }
     const int lds = SPLIT * NS * 8 * 64 * (int)sizeof(double);
+    p.first_is_z = 1;
+#if ALZ_CDOT_V2
+    rc = ensure_dynamic_lds((const void *)k_cdot2<SPLIT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_cdot2<SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
+                       lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
+#else
     rc = ensure_dynamic_lds((const void *)k_cdot<NS, SPLIT>, lds);
     if (rc) return rc;
-    p.first_is_z = 1;
     hipLaunchKernelGGL((k_cdot<NS, SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
                        lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
+#endif
   } else {
     hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
     ch.nostore = true;

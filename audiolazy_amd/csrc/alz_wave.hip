@@ -142,6 +142,10 @@ __device__ __forceinline__ double wave_step(double d0, double d1, double d2, dou
   return acc;
 }
 
+// ALZ_WAVE_NT (variant builds, A/B only): the single-wave kernel's tile DMA and stores with the non-temporal policy
+#ifndef ALZ_WAVE_NT
+#define ALZ_WAVE_NT 0
+#endif
 // G: channels per wave (16, 32 or 64).  CM: channel-major layout.
 // NOSTORE: pass 1 of the time-parallel mode -- the recurrence runs for its end state only; no output
 // tile and no input history is written.
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   for (int t = 0; t < kRing - 1 && t < nt && !ALZ_DBG(p, 1); ++t) {
 #pragma unroll
     for (int j = 0; j < kChunks; ++j)
-      dma16(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
+      dma16<ALZ_WAVE_NT != 0>(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
   }
 
   for (int64_t i = 0; i < nt; ++i) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
       const int sn = (int)(tn % kRing);
 #pragma unroll
       for (int j = 0; j < kChunks; ++j)
-        dma16(xg + tn * x_tile + j * x_chunk, lds0 + sn * kSlotBytes + j * 1040);
+        dma16<ALZ_WAVE_NT != 0>(xg + tn * x_tile + j * x_chunk, lds0 + sn * kSlotBytes + j * 1040);
     }
     // operations issued after tile i's DMA: the DMA of the following tiles plus the
     // stores of the preceding ones (completion is in issue order)
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
       for (int j = 0; j < kChunks; ++j)
         v[j] = *reinterpret_cast<const dbl2 *>(tile + j * 1040 + lane * 16);
 #pragma unroll
-      for (int j = 0; j < kChunks; ++j) store16(yt + j * y_chunk, v[j]);
+      for (int j = 0; j < kChunks; ++j) store16<ALZ_WAVE_NT != 0>(yt + j * y_chunk, v[j]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the asm stores are invisible to hipcc

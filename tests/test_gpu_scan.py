@@ -181,6 +181,56 @@ def test_one_pass_mode(alz, oracle, C, n, pattern):
   assert norm_err(y2, ref[n:], 0) <= 1e-8
 
 
+@pytest.mark.parametrize("layout", ["time", "chan"])
+@pytest.mark.parametrize("mode", ["plain", "abs", "inplace", "abs+inplace"])
+@pytest.mark.parametrize("C,n,pattern", [(512, 40 * 512, "resonator"), (256, 21 * 512 + 300, "biquad"), (64, 1 << 15, "onepole"),
+                                          (1024, 16 * 512, "lowpass2")])
+def test_one_pass_layouts_maps_in_place(alz, oracle, layout, mode, C, n, pattern):
+  """Round 5: the one-pass form takes channel-major blocks [C, N] as well as time-major rows, reads through the |x| input
+  map (``set_input_map("abs")``: no streaming pre-pass) and runs in place (x == y: the two rows in front of every chunk are
+  saved first).  Every combination must report the one-pass kernel and hold the mode's 1e-8 bar against the oracle, block
+  after block (ragged tails go to the serial kernels, which read through the same map)."""
+  import torch
+  rng = np.random.default_rng(C + n + len(mode))
+  if pattern == "resonator":
+    b, a = resonators(4096)
+    pick = np.linspace(0, 4095, C).astype(int)
+    b, a, nb, na = b[pick].copy(), a[pick].copy(), 3, 3
+  elif pattern == "lowpass2":
+    pole = rng.uniform(0.5, 0.999, C)
+    b, a, nb, na = ((1 - pole) ** 2)[:, None], np.stack([np.ones(C), -2 * pole, pole * pole], axis=1), 1, 3
+  elif pattern == "biquad":
+    r, w = rng.uniform(0.8, 0.9995, C), rng.uniform(0.01, 3.0, C)
+    b = rng.uniform(-1, 1, (C, 3))
+    a, nb, na = np.stack([np.ones(C), -2 * r * np.cos(w), r * r], axis=1), 3, 3
+  else:
+    pole = rng.uniform(0.5, 0.9999, C)
+    b, a, nb, na = (1 - pole)[:, None], np.stack([np.ones(C), -pole], axis=1), 1, 2
+  tm = layout == "time"
+  ax = 0 if tm else 1
+  shape = lambda m: (m, C) if tm else (C, m)
+  x1, x2 = rng.uniform(-1, 1, shape(n)), rng.uniform(-1, 1, shape(6 * 512 + 5))
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
+  if "abs" in mode:
+    bank.set_input_map("abs")
+  bank.reset()
+  xin = np.concatenate([x1, x2], axis=ax)
+  ref = oracle.bank([nb], [na], b, a, np.abs(xin) if "abs" in mode else xin, layout=layout)
+  at = 0
+  for x in (x1, x2):
+    xd = torch.from_numpy(x).cuda()
+    y = bank.process(xd, layout=layout, out=xd if "inplace" in mode else None)
+    assert "k_look" in bank.last_kernel, bank.last_kernel
+    if "abs" in mode:
+      assert "k_map" not in bank.last_kernel, bank.last_kernel      # no separate pass over the block
+    m = x.shape[ax]
+    want = ref[at:at + m] if tm else ref[:, at:at + m]
+    assert norm_err(y.cpu().numpy(), want, ax) <= 1e-8, (layout, mode)
+    if "inplace" in mode:
+      assert y.data_ptr() == xd.data_ptr()
+    at += m
+
+
 def test_one_pass_is_deterministic_and_agrees_with_three_launches(alz):
   """The one-pass form synchronises its waves and workgroups through counters and published states only: the same block
   twelve times over must give the same BITS every time (the chain order is fixed), and agree with the three-launch form
