@@ -647,108 +647,6 @@ __global__ __launch_bounds__(64 * SPLIT) void k_cdot(CScanArgs p, const double *
   }
 }
 
-// k_cdot with both operand streams requested one step ahead BY HAND (ALZ_CDOT_V2 builds: A/B against k_cdot).  hipcc rotates
-// a C-level "load next, compute current" loop back into "load, wait, compute" (the k_cdot loop above waits for its four
-// s_load_dwordx16 and its row load in the iteration that issues them: only the other wave of the SIMD hides them), so the
-// responses of the NEXT pair of samples go to a second set of SGPRs and the next 16 bytes of the row to a second VGPR pair
-// through asm statements the scheduler cannot move, with the waits behind the 32 FMAs.  Two bands per workgroup (2 x 16
-// SGPRs per set), so twice the workgroups: 64 KiB of LDS each, two per CU.
-template <int SPLIT>
-__global__ __launch_bounds__(64 * SPLIT) void k_cdot2(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge) {
-  extern __shared__ __attribute__((aligned(16))) double cd_part2[];  // [SPLIT][16][64]
-  typedef double dbl2 __attribute__((ext_vector_type(2)));
-  typedef double dbl8 __attribute__((ext_vector_type(8)));
-  constexpr int NS = 2;
-  static_assert((NS * 8) % SPLIT == 0 || SPLIT % (NS * 8) == 0, "the final sums are shared out over the waves");
-  const int lane = threadIdx.x & 63;
-  const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t ngrp = p.n_sets / NS;
-  const int64_t in = (int64_t)blockIdx.y / ngrp, set0 = ((int64_t)blockIdx.y - in * ngrp) * NS;
-  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls, m1 = m0 + Ls;
-  const double *xrow = p.x + in * p.ldx + j * p.L;
-  double acc[NS][4][2];
-#pragma unroll
-  for (int a = 0; a < NS; ++a)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
-  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
-  const double *ha = hr + ((set0 + 0) * p.L + m0) * 4, *hb = hr + ((set0 + 1) * p.L + m0) * 4;   // (wave-uniform)
-  dbl8 ca, cb, na, nb;
-  dbl2 v, vn;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(ca), "=&s"(cb) : "s"(ha), "s"(hb) : "memory");
-  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(xrow + m0) : "memory");
-  // (consumed here: hipcc then waits for the load of xprev now and puts no s_waitcnt vmcnt(0) of its own into the loop,
-  // where it would wait for the row request just issued)
-  asm volatile("" : "+v"(xprev));
-  for (int64_t m = m0; m < m1; m += 2) {
-    const int64_t step = m + 2 < m1 ? 8 : 0;                    // (the last step requests its own pair again)
-    ha += step; hb += step;
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(na), "=&s"(nb) : "s"(ha), "s"(hb) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vn) : "v"(xrow + (m + 2 < m1 ? m + 2 : m)) : "memory");
-    __builtin_amdgcn_sched_barrier(0);                          // (the machine scheduler would hoist the FMAs above the requests)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc[0][s][0] = __builtin_fma(ca[s], v.x, acc[0][s][0]);
-      acc[0][s][1] = __builtin_fma(ca[s], xprev, acc[0][s][1]);
-      acc[0][s][0] = __builtin_fma(ca[4 + s], v.y, acc[0][s][0]);
-      acc[0][s][1] = __builtin_fma(ca[4 + s], v.x, acc[0][s][1]);
-      acc[1][s][0] = __builtin_fma(cb[s], v.x, acc[1][s][0]);
-      acc[1][s][1] = __builtin_fma(cb[s], xprev, acc[1][s][1]);
-      acc[1][s][0] = __builtin_fma(cb[4 + s], v.y, acc[1][s][0]);
-      acc[1][s][1] = __builtin_fma(cb[4 + s], v.x, acc[1][s][1]);
-    }
-    xprev = v.y;
-    __builtin_amdgcn_sched_barrier(0);
-    // the requested operands have landed; tying the buffers to the wait keeps their copies behind it
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(na), "+s"(nb), "+v"(vn) : : "memory");
-    ca = na;
-    cb = nb;
-    v = vn;
-  }
-  const int64_t V = p.K * p.C;
-  if (seg == 0) {
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      const int64_t c = (set0 + a) * p.n_inputs + in;
-      double xm1 = 0.0, xm2 = 0.0;
-      if (p.nb[0] > 1) xm1 = j > 0 ? xrow[-1] : p.xh[0][0 * p.C + c];
-      if (p.nb[0] > 2) xm2 = j > 0 ? xrow[-2] : p.xh[0][1 * p.C + c];
-      const int64_t slot = cs_slot(p, c, j);
-      if (p.nb[0] > 1) p.vxh[0][0 * V + slot] = xm1;
-      if (p.nb[0] > 2) p.vxh[0][1 * V + slot] = xm2;
-      const double *e = edge + (set0 + a) * 16;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          double z = acc[a][s][k];
-          z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
-          z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
-          acc[a][s][k] = z;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < NS; ++a)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) cd_part2[((seg * NS + a) * 8 + 2 * s + k) * 64 + lane] = acc[a][s][k];
-  __syncthreads();
-  for (int q = seg; q < NS * 8; q += SPLIT) {                  // (wave-uniform)
-    const int a = q >> 3, s = (q >> 1) & 3, k = q & 1;
-    if (s >= p.nsec) continue;
-    double z = cd_part2[((0 * NS + a) * 8 + 2 * s + k) * 64 + lane];
-#pragma unroll
-    for (int sg = 1; sg < SPLIT; ++sg) z = z + cd_part2[((sg * NS + a) * 8 + 2 * s + k) * 64 + lane];
-    const int64_t c = (set0 + a) * p.n_inputs + in;
-    p.vyh[s][(int64_t)k * V + cs_slot(p, c, j)] = z;
-  }
-}
-
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
                         ScanScratch *scratch, bool state_consistent, bool *taken, const char **kernel_name) {
   *taken = false;
@@ -825,13 +723,10 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
   // the zero-state pass: dot products with the cascade's impulse responses where the shape offers them (an OUTER bank
   // reading by input index from rows of chunks: channel-major, or the one contiguous column of a one-stream time-major
   // block), else the cascade kernel itself without stores
-#ifndef ALZ_CDOT_V2
-#define ALZ_CDOT_V2 0
-#endif
-#ifndef ALZ_CDOT_SPLIT
-#define ALZ_CDOT_SPLIT 8
-#endif
-  constexpr int NS = ALZ_CDOT_V2 ? 2 : 4, SPLIT = ALZ_CDOT_SPLIT;
+  // (measured and not kept, profiles/NOTES_r05.md 2: two bands per workgroup with both operand streams requested one step
+  // ahead by hand-placed s_load / global_load and sched_barriers -- 305 against 353 Gsamples/s: half the bands per wave is
+  // twice the row loads, and those cost the vector cache a line access per lane)
+  constexpr int NS = 4, SPLIT = 8;
   const bool dot_pass = state_consistent && by_input && io.x != io.y && io.n_sets % NS == 0 && L % (2 * SPLIT) == 0 &&
                         (((uintptr_t)io.x) & 15) == 0 && (cm ? (p.ldx % 2 == 0) : (io.n_inputs == 1 && p.ldx == 1)) &&
                         (uint64_t)(K / 64) <= 65535u && (uint64_t)(io.n_sets / NS) * (uint64_t)io.n_inputs <= 65535u;
@@ -850,17 +745,10 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     }
     const int lds = SPLIT * NS * 8 * 64 * (int)sizeof(double);
     p.first_is_z = 1;
-#if ALZ_CDOT_V2
-    rc = ensure_dynamic_lds((const void *)k_cdot2<SPLIT>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_cdot2<SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
-                       lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
-#else
     rc = ensure_dynamic_lds((const void *)k_cdot<NS, SPLIT>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((k_cdot<NS, SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
                        lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
-#endif
   } else {
     hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
     ch.nostore = true;

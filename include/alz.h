@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 310 /* 0.3.1: + alz_lag_matrix_dev; 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
+#define ALZ_VERSION 311 /* 0.3.2: time-parallel mode for time-major cascades, one-pass form in both layouts / in place / with the |x| map (same entry points); 0.3.1: + alz_lag_matrix_dev; 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
@@ -126,11 +126,23 @@ int alz_bank_set_fused(alz_bank_t *h, int on);
  * the DF-I statement, but the chunk states carry a different rounding: results are NOT
  * bit-identical (<= 1e-6 normalised by contract, ~1e-12 typical, ~1e-9 for poles at radius
  * 0.9999).  Sections the mode does not cover run as usual.
- * The engine's choice (ALZ_TP_AUTO) includes the ONE-PASS form for a biquad-class section on time-major blocks:
- * 512-sample chunks stay in LDS between the zero-state sums and the replay, so the block is read once (16 bytes of
- * HBM traffic per sample instead of 24; same numerics).  It is taken when its workgroups fill most of the chip (from
- * about 200 channels up to 2048); ALZ_TP_ONE_PASS (-2) asks for it on any shape it covers, a positive chunk_len
- * always means the three-launch form.                                                                            */
+ * The engine's choice (ALZ_TP_AUTO) includes the ONE-PASS form for a biquad-class section (either layout, in place,
+ * and with the ALZ_MAP_ABS input map read through the kernel -- round 5; time-major only before): 512-sample chunks
+ * stay in LDS between the zero-state sums and the replay, so the block is read once (16 bytes of HBM traffic per
+ * sample instead of 24; same numerics).  It is taken when its workgroups fill most of the chip (from about 200
+ * channels up to 2048); ALZ_TP_ONE_PASS (-2) asks for it on any shape it covers, a positive chunk_len always means
+ * the three-launch form.
+ * Cascades of 2 - 4 sections with two poles and at most three numerator taps each (gammatone.slaney / klapuri,
+ * lazy_auditory.py:184-218) run FUSED in this mode: the chunks of the time axis become the fused cascade kernel's
+ * channels; the zero-state pass is a dot product of every chunk with the cascade's impulse responses when the bank is
+ * an OUTER bank reading by input index and its state is self-consistent (every section's input history = its
+ * predecessor's output history: after reset, after any processed block, after a set_state whose rows say so --
+ * otherwise the cascade kernel itself makes that pass).  Channel-major blocks, and time-major ones (the reference's
+ * vector-valued samples) when the bank's channels are a multiple of 64 and its inputs are one stream or a multiple of
+ * 64.  Measured <= 3e-11 against the oracle (tests: 1e-9).  A cascade whose FIRST section has more than three
+ * numerator taps (gammatone.sampled: eight taps of +-1e3 that cancel) is split -- numerator exact and time-parallel,
+ * its recursion serial and exact, the remaining sections fused and chunked in place: measured 1e-8 at a 50 Hz band,
+ * which is that form's bar (tests/test_gpu_outer_narrow.py).                                                       */
 #define ALZ_TP_AUTO (-1)
 #define ALZ_TP_ONE_PASS (-2)
 int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len);

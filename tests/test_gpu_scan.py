@@ -130,10 +130,10 @@ def test_cascade_sections_one_after_the_other(alz, oracle):
 
 
 def test_engine_choice_of_form(alz, oracle):
-  """ALZ_TP_AUTO takes the one-pass form where its workgroups fill the chip (>= 256 channels on time-major blocks), the
-  three-launch form for narrower banks, channel-major blocks and explicit chunk lengths."""
+  """ALZ_TP_AUTO takes the one-pass form where its workgroups fill the chip (>= 256 channels, either layout since round
+  5), the three-launch form for narrower banks and explicit chunk lengths."""
   import torch
-  for C, layout, chunk, one_pass in ((512, "time", True, True), (64, "time", True, False), (512, "chan", True, False),
+  for C, layout, chunk, one_pass in ((512, "time", True, True), (64, "time", True, False), (512, "chan", True, True),
                                      (512, "time", 2048, False), (64, "time", "one-pass", True)):
     b, a = resonators(C)
     n = 1 << 14
@@ -209,7 +209,7 @@ def test_one_pass_layouts_maps_in_place(alz, oracle, layout, mode, C, n, pattern
   tm = layout == "time"
   ax = 0 if tm else 1
   shape = lambda m: (m, C) if tm else (C, m)
-  x1, x2 = rng.uniform(-1, 1, shape(n)), rng.uniform(-1, 1, shape(6 * 512 + 5))
+  x1, x2 = rng.uniform(-1, 1, shape(n)), rng.uniform(-1, 1, shape(6 * 512 + 6))      # (even lengths: 16-byte rows in [C, N])
   bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
   if "abs" in mode:
     bank.set_input_map("abs")
