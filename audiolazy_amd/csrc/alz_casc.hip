@@ -46,9 +46,10 @@ struct CArgs {
   // and input index follow the real channel; state lives in per-virtual-channel arrays (channels = all vc).
   int64_t kchunks, ldx_outer, ldy_outer;
   int nostore;   // the zero-state pass: run for the end state only
-  // time-major blocks in the time-parallel mode (k_casc only): vc = chunk * creal + real_channel, so a 64-channel group is
-  // 64 adjacent real channels of ONE chunk (creal % 64 == 0) -- whole 512-byte row pieces in x and y, chunk_len rows
-  // further down per chunk; ldx / ldy stay the block's own
+  // chunk-major virtual channels (k_casc only): vc = chunk * creal + real_channel, so a 64-channel group is 64 adjacent
+  // real channels of ONE chunk (creal % 64 == 0).  Time-major blocks: whole 512-byte row pieces in x and y, chunk_len
+  // rows further down per chunk.  Channel-major blocks with ONE input stream (BC): 64 output rows, chunk_len samples in.
+  // ldx / ldy stay the block's own in both.
   int chunk_tm;
   int64_t creal, chunk_len;
 };
@@ -61,7 +62,15 @@ struct CGroup {
 __device__ __forceinline__ CGroup c_group(const CArgs &p, int64_t c0) {
   CGroup g;
   const bool outer = p.mode == ALZ_BANK_OUTER;
-  if (p.kchunks > 0) {
+  if (p.kchunks > 0 && p.chunk_tm) {
+    // chunk-major virtual channels on a channel-major block: the group's 64 lanes are 64 adjacent real channels (rows
+    // ldy apart) of chunk jc, chunk_len samples into every row; the ONE input row is read by wave-uniform loads (BC)
+    const int64_t jc = c0 / p.creal, real = c0 - jc * p.creal;
+    const int64_t in = (outer && p.map_input) ? real % p.n_inputs : real;
+    g.xbase = in * p.ldx_outer + jc * p.chunk_len;
+    g.ybase = real * p.ldy_outer + jc * p.chunk_len;
+    g.creal0 = real;
+  } else if (p.kchunks > 0) {
     const int64_t real = c0 / p.kchunks, j0 = c0 - real * p.kchunks;
     const int64_t in = (outer && p.map_input) ? real % p.n_inputs : real;
     g.xbase = in * p.ldx_outer + j0 * p.ldx;
@@ -532,7 +541,6 @@ constexpr int nb_of(unsigned pb) {
 template <bool CM, bool BC, unsigned PB0, unsigned PA0, unsigned PB1, unsigned PA1, unsigned PB2, unsigned PA2,
           unsigned PB3, unsigned PA3>
 __global__ __launch_bounds__(64) void k_casc(CArgs p) {
-  static_assert(!(CM && BC), "broadcast input: time-major instantiations only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 64, T = 16;
   constexpr int NS = (PB3 | PA3) ? 4 : (PB2 | PA2) ? 3 : (PB1 | PA1) ? 2 : 1;
@@ -572,7 +580,9 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     y_off = grp.ybase + ch * p.ldy + 2 * sp;
     x_chunk = 8 * p.ldx; y_chunk = 8 * p.ldy;
     x_tile = T; y_tile = T;
+    xb = p.x + grp.xbase;
   }
+  const int64_t xstep = CM ? 1 : p.ldx;                  // BC: elements between consecutive samples of the input stream
 
   // coefficients and state of every section, in registers
   double bc[4][8], na1[4], na2[4], dx[4][7], m1[4], m2[4];
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   double xcur[16], xnext[16];
   if constexpr (BC) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) xcur[u] = xb[(int64_t)u * p.ldx];
+    for (int u = 0; u < 16; ++u) xcur[u] = xb[(int64_t)u * xstep];
   } else {
     for (int t = 0; t < kCRing - 1 && t < nt; ++t) {
 #pragma unroll
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     if constexpr (BC) {
       const int64_t t1 = i + 1 < nt ? i + 1 : i;           // (the last tile requests itself again)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) xnext[u] = xb[(t1 * T + u) * p.ldx];
+      for (int u = 0; u < 16; ++u) xnext[u] = xb[(t1 * T + u) * xstep];
     } else {
       if (tn < nt) {
         const int sn = (int)(tn % kCRing);
@@ -1290,7 +1300,7 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   // OUTER banks that read their input by input index: a workgroup's channels must be adjacent inputs of one band
   const bool by_input = io.mode == ALZ_BANK_OUTER && io.map_input;
   // (time-parallel mode on time-major blocks: ONE input stream is read by wave-uniform loads, any pitch)
-  bool bcast = ch && ch->time_major && tm && !cm && by_input && io.n_inputs == 1;
+  bool bcast = ch && ch->chunk_major && by_input && io.n_inputs == 1;
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return ALZ_OK;
   if (((bcast ? 0 : ldx) | ldy) & 1) return ALZ_OK;
   const int g = 64;
@@ -1298,9 +1308,11 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   if (ch) {
     if (ch->chunk_len % 16 != 0 || (ch->chunk_len & 1)) return ALZ_OK;
     if (ch->n_chunks * ch->chunk_len != io.n) return ALZ_OK;
-    if (ch->time_major) {
-      // virtual channels: the 64 adjacent real channels of a group, in one chunk (k_casc only)
-      if (!tm || cm || io.channels % g != 0) return ALZ_OK;
+    if (ch->chunk_major) {
+      // virtual channels: the 64 adjacent real channels of a group, in one chunk (k_casc only); channel-major blocks
+      // only with the one-stream broadcast input
+      if (io.channels % g != 0) return ALZ_OK;
+      if (cm && !bcast) return ALZ_OK;
       if (!bcast && by_input && (io.n_inputs % g) != 0) return ALZ_OK;
     } else {
       // virtual channels: 64 consecutive chunks of one real channel per group
@@ -1312,7 +1324,7 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
     return ALZ_OK;
   }
   if (groups == 0 || tiles == 0) return ALZ_OK;
-  const bool chunk_tm = ch && ch->time_major;
+  const bool chunk_tm = ch && ch->chunk_major;
   // Four sections: the wave pipeline (one section per stage wave) while there are fewer 64-channel groups than
   // SIMDs; from 1024 groups up every SIMD has a whole single-wave cascade of its own and the hand-over only
   // costs (256 bands x 256 streams: k_casc 528 - 538 against k_pipe 436 - 472 Gsamples/s, profiles/NOTES_r02.md 14).
@@ -1324,12 +1336,14 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
     pipe = fma ? (cm ? pick_pipe<true, 1, 64, true>(pb, pa) : pick_pipe<false, 1, 64, true>(pb, pa))
                : (cm ? pick_pipe<true, 1>(pb, pa) : pick_pipe<false, 1>(pb, pa));
   const int pipe_waves = 6;   // four stage waves + loader + storer
-  casc_fn fn = pipe ? pipe : cm ? pick_casc<true>(pb, pa, nsec) : bcast ? pick_casc<false, true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec);
+  casc_fn fn = pipe ? pipe
+               : cm ? (bcast ? pick_casc<true, true>(pb, pa, nsec) : pick_casc<true>(pb, pa, nsec))
+                    : (bcast ? pick_casc<false, true>(pb, pa, nsec) : pick_casc<false>(pb, pa, nsec));
   if (!fn) return ALZ_OK;
   if (ch && ch->probe) {                  // (would the launch below take the block?)
     *done_samples = io.n;
     *done_channels = io.channels;
-    *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : "k_casc";
+    *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : bcast ? "k_casc<bc>" : "k_casc";
     return ALZ_OK;
   }
   CArgs p;
@@ -1363,7 +1377,7 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = ch ? io.n : tiles * 16;
   *done_channels = ch ? io.channels : groups * g;
-  *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : "k_casc";
+  *kernel_name = pipe ? (fma ? "k_pipe<fma>" : "k_pipe") : bcast ? "k_casc<bc>" : "k_casc";
   return ALZ_OK;
 }
 

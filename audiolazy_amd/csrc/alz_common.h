@@ -103,7 +103,8 @@ int launch_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStrea
 struct CascChunks {
   int64_t n_chunks, chunk_len;
   bool nostore;
-  bool time_major = false;   // slots j * channels + c and 64-channel groups inside one chunk (time-major blocks) instead of c * n_chunks + j
+  bool chunk_major = false;  // slots j * channels + c and 64-channel groups inside ONE chunk (always for time-major blocks; for
+                             // channel-major ones with a single input stream) instead of c * n_chunks + j
   bool probe = false;        // report whether the launch would take the block, launch nothing
   double *vxh[4], *vyh[4];
 };

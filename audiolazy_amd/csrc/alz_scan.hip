@@ -310,14 +310,16 @@ struct CScanArgs {
   double *vxh[4], *vyh[4];     // per-chunk state [taps-1][C * K]
   int64_t L, K;
   double *power;               // M[r][e] at power[(r * 8 + e) * C + c]
-  int slot_tm;                 // state slot of (real channel c, chunk j): 0 -> c * K + j (channel-major blocks: a 64-lane group of
-                               // the cascade kernel = 64 chunks of one channel), 1 -> j * C + c (time-major: 64 channels of one chunk)
+  int slot_tm;                 // state slot of (real channel c, chunk j): 0 -> c * K + j (a 64-lane group of the cascade kernel =
+                               // 64 chunks of one channel), 1 -> j * C + c (chunk-major: 64 channels of one chunk -- time-major
+                               // blocks, and channel-major ones whose single input stream is broadcast)
+  int x_tm;                    // the block is time-major (x[t * ldx + in]) rather than channel-major (x[in * ldx + t])
   int first_is_z;              // slot 0 of vyh holds z_0 (the dot-product zero-state pass): the fix starts at chunk 0 from the bank's state
 };
 
 __device__ __forceinline__ int64_t cs_slot(const CScanArgs &p, int64_t c, int64_t j) { return p.slot_tm ? j * p.C + c : c * p.K + j; }
 // sample t of input row `in`
-__device__ __forceinline__ int64_t cs_xat(const CScanArgs &p, int64_t in, int64_t t) { return p.slot_tm ? t * p.ldx + in : in * p.ldx + t; }
+__device__ __forceinline__ int64_t cs_xat(const CScanArgs &p, int64_t in, int64_t t) { return p.x_tm ? t * p.ldx + in : in * p.ldx + t; }
 
 __global__ __launch_bounds__(256) void k_cscan_prep(CScanArgs p) {
   const int64_t vc = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -700,10 +702,13 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
 
   CScanArgs p;
   CascChunks ch;
-  ch.n_chunks = K; ch.chunk_len = L; ch.time_major = !cm;
+  ch.n_chunks = K; ch.chunk_len = L;
+  // chunk-major virtual channels: always for time-major blocks; for channel-major ones when ONE input stream feeds every
+  // band (then no input tiles travel at all: k_casc<bc>) and the chunks fill the chip with single-wave cascades
+  ch.chunk_major = !cm || (by_input && io.n_inputs == 1 && C % 64 == 0 && V >= 65536);
   p.x = io.x; p.ldx = cm ? io.sxc : io.sxn; p.C = C; p.n_inputs = io.n_inputs; p.n_sets = io.n_sets;
   p.mode = io.mode; p.map_input = io.map_input; p.nsec = nsec; p.L = L; p.K = K; p.power = scratch->power;
-  p.slot_tm = cm ? 0 : 1;
+  p.x_tm = cm ? 0 : 1;
   p.first_is_z = 0;
   double *cur = scratch->vxh;
   for (int s = 0; s < 4; ++s) {
@@ -718,6 +723,21 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
   }
   const char *inner = "";
   bool ok = false;
+  // will the fused cascade kernel take the replay?  Asked before anything is launched: the fix kernel writes the bank's
+  // state ahead of the replay, and a pattern without a fused instantiation must leave the block to the other paths
+  // untouched (round 5's fuzzer found the missing question: tools/fuzz_timeparallel.py)
+  ch.nostore = false;
+  ch.probe = true;
+  rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
+  if (rc) return rc;
+  if (!ok && cm && ch.chunk_major) {      // (no broadcast instantiation for this pattern: the chunks of a channel as lanes)
+    ch.chunk_major = false;
+    rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
+    if (rc) return rc;
+  }
+  if (!ok) return ALZ_OK;
+  ch.probe = false;
+  p.slot_tm = ch.chunk_major ? 1 : 0;
   const bool fresh_power = scratch->power_len != L || scratch->power_section != -2;
 
   // the zero-state pass: dot products with the cascade's impulse responses where the shape offers them (an OUTER bank
@@ -761,7 +781,7 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     scratch->power_len = L;
     scratch->power_section = -2;          // (-2: this slot holds a cascade's matrix)
   }
-  if (cm) hipLaunchKernelGGL(k_cscan_fix<false>, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, stream, p);
+  if (!p.slot_tm) hipLaunchKernelGGL(k_cscan_fix<false>, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, stream, p);
   else hipLaunchKernelGGL(k_cscan_fix<true>, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, stream, p);
   ch.nostore = false;
   rc = launch_cascade_chunks(secs, nsec, io, stream, ch, &ok, &inner);
@@ -770,8 +790,9 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
                                            : "time-parallel cascade: replay launch refused after the zero-state pass");
   ALZ_HIP_CHECK(hipGetLastError());
   *taken = true;
-  *kernel_name = dot_pass ? (inner[2] == 'p' ? "k_cscan(k_cdot+k_pipe)" : "k_cscan(k_cdot+k_casc)")
-                          : (inner[2] == 'p' ? "k_cscan(k_pipe)" : "k_cscan(k_casc)");
+  const bool bc = inner[2] == 'c' && inner[6] == '<';       // "k_casc<bc>": the broadcast-input instantiation
+  *kernel_name = dot_pass ? (inner[2] == 'p' ? "k_cscan(k_cdot+k_pipe)" : bc ? "k_cscan(k_cdot+k_casc<bc>)" : "k_cscan(k_cdot+k_casc)")
+                          : (inner[2] == 'p' ? "k_cscan(k_pipe)" : bc ? "k_cscan(k_casc<bc>)" : "k_cscan(k_casc)");
   return ALZ_OK;
 }
 

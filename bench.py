@@ -824,7 +824,7 @@ def wl_collective(ctx, args, C, n):
 _PMC = None
 
 
-PMC_TABLES = ("r04_pmc_traffic_table.json", "r03_pmc_traffic_table.json")     # newest first
+PMC_TABLES = ("r05_pmc_traffic_table.json", "r04_pmc_traffic_table.json", "r03_pmc_traffic_table.json")     # newest first
 
 
 def fill_traffic(roof, key):
@@ -941,12 +941,13 @@ def compact_line(full):
         continue
       r = e["roofline"]
       slim[k] = {"value": round(e["value"], 4), "unit": e["unit"], "ms_per_step": round(e["ms_per_step"], 5),
-                 "frac": round(r["frac"], 4), "traffic_ratio": r.get("traffic_ratio"), "parity": short_parity(e["parity"])}
+                 "frac": round(r["frac"], 4), "traffic_ratio": None if r.get("traffic_ratio") is None else round(r["traffic_ratio"], 4),
+                 "parity": short_parity(e["parity"])}
       if "per_rank_frac" in e:
         slim[k]["per_rank_frac"] = e["per_rank_frac"]
       if "timing" in e:                # median of `batches` batches; the spread beside it
         t = e["timing"]
-        slim[k]["ms_min_max"] = [round(t["ms_per_step_min"], 5), round(t["ms_per_step_max"], 5)]
+        slim[k]["ms_min_max"] = [round(t["ms_per_step_min"], 4), round(t["ms_per_step_max"], 4)]
         slim[k]["n"] = "%dx%d" % (t["batches"], t["steps_per_batch"])
     line["secondary"] = slim
   return line

@@ -120,6 +120,14 @@ def test_compact_line_fits_a_truncating_record_and_ends_with_the_baseline_config
     assert len(e["parity"]) <= 100 and e["parity"].split()[0] in ("bit-exact", "err<=1e-06", "MISMATCH") or e["parity"].startswith("err<="), e
   assert list(sec)[-5:] == ["fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical"]
   assert text.index('"secondary"') > text.index('"cpu_baseline"')      # the secondaries close the line
+  # round 5's record: two more workloads, and the batch timer's spread (`ms_min_max`, `n`) per entry -- still under the cut
+  full5 = json.load(open(os.path.join(root, "profiles", "r05_bench_first_process.json")))
+  line5 = bench.compact_line(full5)
+  assert len(json.dumps(line5)) < 6144, len(json.dumps(line5))
+  for k, e in line5["secondary"].items():
+    assert set(e) == {"value", "unit", "ms_per_step", "frac", "traffic_ratio", "parity", "ms_min_max", "n"}, k
+    assert e["ms_min_max"][0] <= e["ms_per_step"] <= e["ms_min_max"][1]
+  assert list(line5["secondary"])[-5:] == ["fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical"]
   # statuses survive the shortening
   assert bench.short_parity("MISMATCH on the full extent: x").startswith("MISMATCH")
   assert bench.short_parity("bit-exact vs oracle, 8192 channels x 512 samples; full extent: 64 strided channels x 262144 "

@@ -140,6 +140,26 @@ def test_time_major_blocks(alz, oracle, strategy, streams, bands, n, dot):
   assert norm_err(y2, ref[n:], 0) <= 1e-9
 
 
+def test_one_stream_channel_major_takes_the_broadcast_replay(alz, oracle):
+  """[1, N] -> [bands, N]: when the chunks fill the chip (>= 1024 groups of 64 virtual channels) the virtual channels are
+  chunk-major in this layout too -- 64 adjacent BANDS of one chunk per wave, the one input row read by wave-uniform
+  loads (k_casc<bc>: no input tiles travel); with fewer groups the chunks of a channel stay the lanes (k_pipe)."""
+  import torch
+  bank, fcs, Hz = make_bank(alz, 256, 1)
+  nbs, nas, b, a = band_tables(alz, fcs, Hz, "slaney", 1)
+  rng = np.random.default_rng(77)
+  x = rng.uniform(-1, 1, (1, 3 << 16))
+  ref = oracle.bank(nbs, nas, b, a, np.tile(x, (256, 1)), layout="chan")
+  for tp, n0, n1, want in ((True, 0, 1 << 16, "k_cscan(k_cdot+k_casc<bc>)"), (True, 1 << 16, 2 << 16, "k_cscan(k_cdot+k_casc<bc>)"),
+                           (4096, 2 << 16, 3 << 16, "k_cscan(k_cdot+k_pipe)")):
+    bank.set_time_parallel(tp)
+    if n0 == 0:
+      bank.reset()
+    y = bank.process(torch.from_numpy(np.ascontiguousarray(x[:, n0:n1])).cuda(), layout="chan").cpu().numpy()
+    assert bank.last_kernel == want, bank.last_kernel
+    assert norm_err(y, ref[:, n0:n1], 1) <= 1e-9
+
+
 def test_time_major_matches_channel_major(alz):
   """The same one-stream block in both layouts: the chunk states come out of the same kernels (k_cdot, k_cscan_fix) and
   the replay of every chunk is the same arithmetic, so the two results are the same doubles."""

@@ -34,7 +34,7 @@ for case in range(cases):
   if cascade:
     B = int(rng.choice([4, 8, 16, 64, 128, 256]))
     S = int(rng.choice([1, 1, 1, 2, 64, 128]))
-    while B * S > 16384:
+    while B * S > 4096:                                  # (the oracle is one CPU thread: keep a case under a second or two)
       B //= 2
     nsec = int(rng.choice([2, 3, 4, 4]))
     pats = [NUM[int(rng.integers(0, 4))] for _ in range(nsec)]
@@ -79,6 +79,8 @@ for case in range(cases):
         oy += 2
     bank.set_state(xh[:, :thx] if thx else xh, yh)
   lens = [int(rng.choice([1 << 13, 1 << 14, 3 << 12, 40 * 512, 1 << 15, (1 << 14) + 64])) for _ in range(int(rng.integers(2, 4)))]
+  if C * nsec >= 4096:
+    lens = [min(m, 1 << 14) for m in lens[:2]]
   xs = [rng.uniform(-1, 1, (n_in, m)) for m in lens]
   xall = np.concatenate(xs, axis=1)
   xin = np.abs(xall) if use_abs else xall

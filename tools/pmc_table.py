@@ -7,7 +7,8 @@ d = sys.argv[1]
 ALG = {  # algorithmic bytes per step, as bench.py defines them
   "headline": 16.0 * 4096 * 2 ** 20, "fir256_bit_exact": 16.0 * 8192 * 2 ** 18, "fir256_fma": 16.0 * 8192 * 2 ** 18,
   "gammatone": (8 + 8 / 256.) * 256 * 64 * 2 ** 16, "gammatone_one_stream": (8 + 8 / 256.) * 256 * 2 ** 20,
-  "gammatone_one_stream_time_parallel": (8 + 8 / 256.) * 256 * 2 ** 20, "lpc": 3984.0 * 65536, "lpc_bit_identical": 3984.0 * 65536,
+  "gammatone_one_stream_time_parallel": (8 + 8 / 256.) * 256 * 2 ** 20,
+  "gammatone_one_stream_time_parallel_tm": (8 + 8 / 256.) * 256 * 2 ** 20, "narrow512_time_parallel_chan": 16.0 * 512 * 2 ** 20, "lpc": 3984.0 * 65536, "lpc_bit_identical": 3984.0 * 65536,
   "lpc_fma": 3984.0 * 65536, "lpc_1m": 3984.0 * 2 ** 20, "lpc_1m_bit_identical": 3984.0 * 2 ** 20,
   "gammatone_fma": (8 + 8 / 256.) * 256 * 64 * 2 ** 16, "envelope_abs": 16.0 * 4096 * 2 ** 20, "timevar_shared": 16.0 * 4096 * 2 ** 18,
   "timevar_per_channel": 40.0 * 4096 * 2 ** 18, "narrow512_bit_exact": 16.0 * 512 * 2 ** 20, "narrow512_time_parallel": 16.0 * 512 * 2 ** 20,

@@ -28,6 +28,7 @@ run gammatone --workload gammatone
 run gammatone_fma --workload gammatone --fused
 run gammatone_one_stream --workload gammatone --streams 1
 run gammatone_one_stream_time_parallel --workload gammatone --streams 1 --time-parallel 1
+run gammatone_one_stream_time_parallel_tm --workload gammatone --streams 1 --time-parallel 1 --bank-layout time
 run lpc --workload lpc
 run lpc_bit_identical --workload lpc --lpc-exact
 run lpc_fma --workload lpc --fused
@@ -38,4 +39,5 @@ run timevar_shared --workload timevar
 run timevar_per_channel --workload timevar --streams 0
 run narrow512_bit_exact --channels 512 --time-parallel 0
 run narrow512_time_parallel --channels 512 --time-parallel 1
+run narrow512_time_parallel_chan --channels 512 --time-parallel 1 --layout chan
 run narrow512_time_parallel_three_launch --channels 512 --time-parallel 8192
