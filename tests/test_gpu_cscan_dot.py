@@ -151,7 +151,7 @@ def test_one_stream_channel_major_takes_the_broadcast_replay(alz, oracle):
   x = rng.uniform(-1, 1, (1, 3 << 16))
   ref = oracle.bank(nbs, nas, b, a, np.tile(x, (256, 1)), layout="chan")
   for tp, n0, n1, want in ((True, 0, 1 << 16, "k_cscan(k_cdot+k_casc<bc>)"), (True, 1 << 16, 2 << 16, "k_cscan(k_cdot+k_casc<bc>)"),
-                           (4096, 2 << 16, 3 << 16, "k_cscan(k_cdot+k_pipe)")):
+                           (1024, 2 << 16, 3 << 16, "k_cscan(k_cdot+k_pipe)")):
     bank.set_time_parallel(tp)
     if n0 == 0:
       bank.reset()
