@@ -628,8 +628,11 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   for (int k = 0; k < 8; ++k) swz[k] = CM ? ((k ^ lane) & 7) * 16 : 0;
 #define ALZ_COFF(u) (CM ? swz[((u) >> 1) & 7] + ((u) & 1) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
 
+  // (BC: no input tiles -- the ring only stages the output, two slots in turn; the smaller footprint lets a CU hold two
+  // of these one-wave workgroups per SIMD when the launch has them)
+  constexpr int kOutRing = BC ? 2 : kCRing;
   for (int64_t i = 0; i < nt; ++i) {
-    const int slot = (int)(i % kCRing);
+    const int slot = (int)(i % kOutRing);
     const int64_t tn = i + kCRing - 1;
     if constexpr (BC) {
       const int64_t t1 = i + 1 < nt ? i + 1 : i;           // (the last tile requests itself again)
@@ -1368,7 +1371,7 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
     for (int s = 0; s < nsec; ++s) { p.xh[s] = ch->vxh[s]; p.yh[s] = ch->vyh[s]; }
   }
   const size_t pipe_slot = (size_t)g * 128 + (size_t)(g / 8) * 16;
-  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)kCRing * kCSlot;
+  const size_t lds = pipe ? (size_t)(kPXRing + (pipe_waves - 3) * 2 + 2) * pipe_slot : (size_t)(bcast ? 2 : kCRing) * kCSlot;
   if (pipe) {
     const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
     if (rc) return rc;

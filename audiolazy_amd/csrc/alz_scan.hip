@@ -554,6 +554,57 @@ __global__ __launch_bounds__(64) void k_cdot_tables(CScanArgs p, double *__restr
   }
 }
 
+// what both forms of the dot pass do with a wave's sums: segment 0 adds the edge terms (the two samples before the chunk,
+// which it also leaves in vxh[0] for the replay), the workgroup's partial sums meet in LDS and are added in segment order
+template <int NS, int SPLIT>
+__device__ __forceinline__ void cdot_finish(const CScanArgs &p, const double *__restrict__ edge, double (&acc)[NS][4][2], double *cd_part,
+                                            int lane, int seg, int64_t j, int64_t in, int64_t set0, const double *xrow) {
+  const int64_t V = p.K * p.C;
+  if (seg == 0) {
+    // the two samples before the chunk -- from the block, or the bank's input history for chunk 0 -- enter through the
+    // edge responses, and are what the replay of this chunk starts section 0 from
+#pragma unroll
+    for (int a = 0; a < NS; ++a) {
+      const int64_t c = (set0 + a) * p.n_inputs + in;
+      double xm1 = 0.0, xm2 = 0.0;
+      if (p.nb[0] > 1) xm1 = j > 0 ? xrow[-1] : p.xh[0][0 * p.C + c];
+      if (p.nb[0] > 2) xm2 = j > 0 ? xrow[-2] : p.xh[0][1 * p.C + c];
+      const int64_t slot = cs_slot(p, c, j);
+      if (p.nb[0] > 1) p.vxh[0][0 * V + slot] = xm1;
+      if (p.nb[0] > 2) p.vxh[0][1 * V + slot] = xm2;
+      const double *e = edge + (set0 + a) * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          double z = acc[a][s][k];
+          z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
+          z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
+          acc[a][s][k] = z;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NS; ++a)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) cd_part[((seg * NS + a) * 8 + 2 * s + k) * 64 + lane] = acc[a][s][k];
+  __syncthreads();
+  constexpr int QPW = NS * 8 / SPLIT;                          // sums per wave
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int q = seg * QPW + i, a = q >> 3, s = (q >> 1) & 3, k = q & 1;   // (wave-uniform)
+    if (s >= p.nsec) continue;
+    double z = cd_part[((0 * NS + a) * 8 + 2 * s + k) * 64 + lane];
+#pragma unroll
+    for (int sg = 1; sg < SPLIT; ++sg) z = z + cd_part[((sg * NS + a) * 8 + 2 * s + k) * 64 + lane];
+    const int64_t c = (set0 + a) * p.n_inputs + in;
+    p.vyh[s][(int64_t)k * V + cs_slot(p, c, j)] = z;
+  }
+}
+
 template <int NS, int SPLIT>
 __global__ __launch_bounds__(64 * SPLIT) void k_cdot(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge) {
   extern __shared__ __attribute__((aligned(16))) double cd_part[];   // [SPLIT][NS * 8][64]
@@ -603,51 +654,122 @@ __global__ __launch_bounds__(64 * SPLIT) void k_cdot(CScanArgs p, const double *
 #pragma unroll
       for (int q = 0; q < 8; ++q) h[a][q] = hn[a][q];
   }
-  const int64_t V = p.K * p.C;
-  if (seg == 0) {
-    // the two samples before the chunk -- from the block, or the bank's input history for chunk 0 -- enter through the
-    // edge responses, and are what the replay of this chunk starts section 0 from
-#pragma unroll
-    for (int a = 0; a < NS; ++a) {
-      const int64_t c = (set0 + a) * p.n_inputs + in;
-      double xm1 = 0.0, xm2 = 0.0;
-      if (p.nb[0] > 1) xm1 = j > 0 ? xrow[-1] : p.xh[0][0 * p.C + c];
-      if (p.nb[0] > 2) xm2 = j > 0 ? xrow[-2] : p.xh[0][1 * p.C + c];
-      const int64_t slot = cs_slot(p, c, j);
-      if (p.nb[0] > 1) p.vxh[0][0 * V + slot] = xm1;
-      if (p.nb[0] > 2) p.vxh[0][1 * V + slot] = xm2;
-      const double *e = edge + (set0 + a) * 16;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          double z = acc[a][s][k];
-          z = __builtin_fma(e[(0 * 4 + s) * 2 + k], xm1, z);
-          z = __builtin_fma(e[(1 * 4 + s) * 2 + k], xm2, z);
-          acc[a][s][k] = z;
-        }
-      }
-    }
-  }
+  cdot_finish<NS, SPLIT>(p, edge, acc, cd_part, lane, seg, j, in, set0, xrow);
+}
+
+// k_cdot3 (round 5, second form): the same sums in the same order -- identical doubles -- with the operand streams laid
+// out for the memory system instead of for the compiler.  k_cdot's counters (profiles/r05_cdot_pmc.txt): its waves WAIT 69 %
+// of their cycles (VALU active 22 %), every 16-byte row load is a vector-cache miss of its own (TCP_TCC_READ_REQ =
+// TCP_TOTAL_CACHE_ACCESSES: the eight loads that share a 128-byte line are eight L2 requests, iterations apart), and the
+// four s_load_dwordx16 of a pair of samples are waited for where they are issued.  Here
+//   * a lane reads its row a whole 128-byte line at a time: eight 16-byte loads issued together for 16 samples, the next
+//     16 samples' loads in flight while this step's 512 FMAs run (two register sets);
+//   * the responses come in HALF steps -- bands 0 - 1 of a pair, then bands 2 - 3 -- through two sets of 32 SGPRs: while
+//     one half's 32 FMAs run, the other half's two s_load_dwordx16 are in flight (a full double buffer of the 64 SGPRs
+//     a pair of samples needs for four bands does not fit the SGPR file);
+//   * hipcc's scheduler would hoist the FMAs above the requests (and wait at once): sched_barriers pin the order.
+#define ALZ_SLOAD2(d0, d1, p0, p1) \
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0" : "=&s"(d0), "=&s"(d1) : "s"(p0), "s"(p1) : "memory")
+#define ALZ_SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1) : : "memory")
+#define ALZ_XLOAD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=&v"(dst) : "v"(ptr) : "memory")
+template <int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void k_cdot3(CScanArgs p, const double *__restrict__ hr, const double *__restrict__ edge) {
+  extern __shared__ __attribute__((aligned(16))) double cd_part3[];  // [SPLIT][NS * 8][64]
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef double dbl8 __attribute__((ext_vector_type(8)));
+  constexpr int NS = 4;
+  static_assert((NS * 8) % SPLIT == 0, "the final sums are shared out over the waves");
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ngrp = p.n_sets / NS;
+  const int64_t in = (int64_t)blockIdx.y / ngrp, set0 = ((int64_t)blockIdx.y - in * ngrp) * NS;
+  const int64_t Ls = p.L / SPLIT, m0 = seg * Ls;
+  const int nsteps = (int)(Ls / 16);
+  const double *xrow = p.x + in * p.ldx + j * p.L;
+  double acc[NS][4][2];
 #pragma unroll
   for (int a = 0; a < NS; ++a)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) cd_part[((seg * NS + a) * 8 + 2 * s + k) * 64 + lane] = acc[a][s][k];
-  __syncthreads();
-  constexpr int QPW = NS * 8 / SPLIT;                          // sums per wave
-#pragma unroll
-  for (int i = 0; i < QPW; ++i) {
-    const int q = seg * QPW + i, a = q >> 3, s = (q >> 1) & 3, k = q & 1;   // (wave-uniform)
-    if (s >= p.nsec) continue;
-    double z = cd_part[((0 * NS + a) * 8 + 2 * s + k) * 64 + lane];
-#pragma unroll
-    for (int sg = 1; sg < SPLIT; ++sg) z = z + cd_part[((sg * NS + a) * 8 + 2 * s + k) * 64 + lane];
-    const int64_t c = (set0 + a) * p.n_inputs + in;
-    p.vyh[s][(int64_t)k * V + cs_slot(p, c, j)] = z;
+    for (int s = 0; s < 4; ++s) acc[a][s][0] = acc[a][s][1] = 0.0;
+  double xprev = seg > 0 ? xrow[m0 - 1] : 0.0;
+  asm volatile("" : "+v"(xprev));                               // (waited for here: no vmcnt wait of hipcc's inside the loop)
+  // the responses of bands set0 .. set0 + 3 at sample m0: 8 doubles (64 bytes) per pair of samples and band
+  const double *h0 = hr + ((set0 + 0) * p.L + m0) * 4, *h1 = hr + ((set0 + 1) * p.L + m0) * 4;
+  const double *h2 = hr + ((set0 + 2) * p.L + m0) * 4, *h3 = hr + ((set0 + 3) * p.L + m0) * 4;
+  dbl8 a0, a1, b0, b1;                                          // bands 0 - 1 / bands 2 - 3 of the pair in work
+  dbl2 xa[8], xb[8];
+  auto load_line = [&](dbl2 (&d)[8], const double *src) {
+    ALZ_XLOAD(d[0], src, 0); ALZ_XLOAD(d[1], src, 16); ALZ_XLOAD(d[2], src, 32); ALZ_XLOAD(d[3], src, 48);
+    ALZ_XLOAD(d[4], src, 64); ALZ_XLOAD(d[5], src, 80); ALZ_XLOAD(d[6], src, 96); ALZ_XLOAD(d[7], src, 112);
+  };
+  auto landed = [&](dbl2 (&d)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]) : : "memory");
+  };
+#define ALZ_HALF(A, C0, C1, V)                                                     \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                  \
+    acc[A][s][0] = __builtin_fma(C0[s], V.x, acc[A][s][0]);                        \
+    acc[A][s][1] = __builtin_fma(C0[s], xprev, acc[A][s][1]);                      \
+    acc[A][s][0] = __builtin_fma(C0[4 + s], V.y, acc[A][s][0]);                    \
+    acc[A][s][1] = __builtin_fma(C0[4 + s], V.x, acc[A][s][1]);                    \
+    acc[A + 1][s][0] = __builtin_fma(C1[s], V.x, acc[A + 1][s][0]);                \
+    acc[A + 1][s][1] = __builtin_fma(C1[s], xprev, acc[A + 1][s][1]);              \
+    acc[A + 1][s][0] = __builtin_fma(C1[4 + s], V.y, acc[A + 1][s][0]);            \
+    acc[A + 1][s][1] = __builtin_fma(C1[4 + s], V.x, acc[A + 1][s][1]);            \
   }
+  // (hipcc may sink a half's FMAs below the requests that follow them -- nothing but data flow orders arithmetic against
+  // an asm statement -- and then keeps the OLD response buffers alive in spilled copies: first build, 579 SGPR spills.  An
+  // empty asm that "uses" the half's sixteen sums pins the FMAs in front of it.)
+#define ALZ_PIN(A)                                                                 \
+  asm volatile("" : "+v"(acc[A][0][0]), "+v"(acc[A][0][1]), "+v"(acc[A][1][0]), "+v"(acc[A][1][1]), "+v"(acc[A][2][0]),       \
+               "+v"(acc[A][2][1]), "+v"(acc[A][3][0]), "+v"(acc[A][3][1]), "+v"(acc[A + 1][0][0]), "+v"(acc[A + 1][0][1]),    \
+               "+v"(acc[A + 1][1][0]), "+v"(acc[A + 1][1][1]), "+v"(acc[A + 1][2][0]), "+v"(acc[A + 1][2][1]),               \
+               "+v"(acc[A + 1][3][0]), "+v"(acc[A + 1][3][1]));
+  // 16 samples from the register set CUR (the table has one spare pair behind its end: the last pair's look-ahead)
+#define ALZ_STEP(CUR)                                                              \
+  _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                  \
+    const dbl2 v = CUR[q];                                                         \
+    ALZ_SWAIT2(a0, a1);                      /* bands 0 - 1 of this pair have landed */ \
+    ALZ_SLOAD2(b0, b1, h2, h3);              /* bands 2 - 3 of this pair */        \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    ALZ_HALF(0, a0, a1, v)                                                         \
+    ALZ_PIN(0)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    h0 += 8; h1 += 8;                                                              \
+    ALZ_SWAIT2(b0, b1);                      /* bands 2 - 3 have landed */         \
+    ALZ_SLOAD2(a0, a1, h0, h1);              /* bands 0 - 1 of the NEXT pair */    \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    ALZ_HALF(2, b0, b1, v)                                                         \
+    ALZ_PIN(2)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    h2 += 8; h3 += 8;                                                              \
+    xprev = v.y;                                                                   \
+  }
+  load_line(xa, xrow + m0);
+  ALZ_SLOAD2(a0, a1, h0, h1);
+  landed(xa);
+  for (int t = 0; t < nsteps; t += 2) {
+    // (an odd step count re-reads the last line into the spare set: loaded, never used)
+    load_line(xb, xrow + m0 + 16 * (int64_t)(t + 1 < nsteps ? t + 1 : t));
+    __builtin_amdgcn_sched_barrier(0);
+    ALZ_STEP(xa)
+    landed(xb);
+    if (t + 1 < nsteps) {
+      load_line(xa, xrow + m0 + 16 * (int64_t)(t + 2 < nsteps ? t + 2 : t + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      ALZ_STEP(xb)
+      landed(xa);
+    }
+  }
+  ALZ_SWAIT2(a0, a1);                                           // (the request that was issued behind the last pair)
+  cdot_finish<NS, SPLIT>(p, edge, acc, cd_part3, lane, seg, j, in, set0, xrow);
 }
+#undef ALZ_HALF
+#undef ALZ_PIN
+#undef ALZ_STEP
+#undef ALZ_SLOAD2
+#undef ALZ_SWAIT2
+#undef ALZ_XLOAD
 
 int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream, int64_t chunk_len,
                         ScanScratch *scratch, bool state_consistent, bool *taken, const char **kernel_name) {
@@ -751,7 +873,8 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
                         (((uintptr_t)io.x) & 15) == 0 && (cm ? (p.ldx % 2 == 0) : (io.n_inputs == 1 && p.ldx == 1)) &&
                         (uint64_t)(K / 64) <= 65535u && (uint64_t)(io.n_sets / NS) * (uint64_t)io.n_inputs <= 65535u;
   if (dot_pass) {
-    const uint64_t hr_need = (uint64_t)io.n_sets * L * 4 * sizeof(double), edge_need = (uint64_t)io.n_sets * 16 * sizeof(double);
+    // (+ one pair of samples: k_cdot3 requests the responses one pair ahead, also behind the last set's last pair)
+    const uint64_t hr_need = ((uint64_t)io.n_sets * L + 2) * 4 * sizeof(double), edge_need = (uint64_t)io.n_sets * 16 * sizeof(double);
     uint64_t have_h = scratch->hr_bytes, have_e = scratch->edge_bytes;
     rc = grow_scratch(&scratch->hr, &have_h, hr_need);
     if (rc) return rc;
@@ -765,10 +888,20 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     }
     const int lds = SPLIT * NS * 8 * 64 * (int)sizeof(double);
     p.first_is_z = 1;
-    rc = ensure_dynamic_lds((const void *)k_cdot<NS, SPLIT>, lds);
+#ifndef ALZ_CDOT_V3
+#define ALZ_CDOT_V3 0
+#endif
+    // (k_cdot3 wants whole 128-byte lines per lane and step: segments of a multiple of 16 samples, 128-byte aligned chunks)
+    const bool lines = ALZ_TUNE("ALZ_CDOT_V3", ALZ_CDOT_V3) != 0 && L % (16 * SPLIT) == 0 && (((uintptr_t)io.x) & 127) == 0 && (io.n_inputs == 1 || p.ldx % 16 == 0);
+    const void *dot_fn = lines ? (const void *)k_cdot3<SPLIT> : (const void *)k_cdot<NS, SPLIT>;
+    rc = ensure_dynamic_lds(dot_fn, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_cdot<NS, SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
-                       lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
+    if (lines)
+      hipLaunchKernelGGL((k_cdot3<SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
+                         lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
+    else
+      hipLaunchKernelGGL((k_cdot<NS, SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
+                         lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
   } else {
     hipLaunchKernelGGL(k_cscan_prep, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, stream, p);
     ch.nostore = true;
