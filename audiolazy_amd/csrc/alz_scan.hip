@@ -889,7 +889,7 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     const int lds = SPLIT * NS * 8 * 64 * (int)sizeof(double);
     p.first_is_z = 1;
 #ifndef ALZ_CDOT_V3
-#define ALZ_CDOT_V3 0
+#define ALZ_CDOT_V3 1
 #endif
     // (k_cdot3 wants whole 128-byte lines per lane and step: segments of a multiple of 16 samples, 128-byte aligned chunks)
     const bool lines = ALZ_TUNE("ALZ_CDOT_V3", ALZ_CDOT_V3) != 0 && L % (16 * SPLIT) == 0 && (((uintptr_t)io.x) & 127) == 0 && (io.n_inputs == 1 || p.ldx % 16 == 0);
