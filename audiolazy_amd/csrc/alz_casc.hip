@@ -21,6 +21,10 @@
 
 namespace alz {
 
+// the channel-major broadcast form stores two tiles at a time (256-byte pieces per row); 0: tile by tile (A/B)
+#ifndef ALZ_CASC_PAIRSTORE
+#define ALZ_CASC_PAIRSTORE 1
+#endif
 static constexpr int kCRing = 4;
 static constexpr int kCChunks = 8;
 static constexpr int kCSlot = 8192 + kCChunks * 16;
@@ -666,7 +670,25 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
         for (int u = 0; u < 8; ++u) *reinterpret_cast<double *>(tile + ALZ_COFF(h * 8 + u)) = v[u];
       }
     }
-    if (!p.nostore) {
+    if (!p.nostore && CM && BC && ALZ_CASC_PAIRSTORE && ((i & 1) || i + 1 < nt)) {
+      // Channel-major broadcast form: a channel's row takes 128 bytes per tile -- stored tile by tile the output leaves as
+      // 128-byte pieces of 64 different rows, where the time-major form writes 512-byte pieces (458 against 393
+      // Gsamples/s).  The two output slots hold an even tile and the odd one behind it: stored together, every channel
+      // gets 256 contiguous bytes -- lane l of store J: channel 4 J + l / 16, piece l % 16 of its 32 samples (pieces 0 - 7
+      // in the even tile's slot, 8 - 15 in the odd one's; the slots keep the compute phase's XOR swizzle).
+      if (i & 1) {
+        const int c4 = lane >> 4, p16 = lane & 15, hsel = p16 >> 3, piece = p16 & 7;
+        cdbl2 w[2 * kCChunks];
+#pragma unroll
+        for (int J = 0; J < 2 * kCChunks; ++J) {
+          const int ch64 = 4 * J + c4;
+          w[J] = *reinterpret_cast<const cdbl2 *>(smem + hsel * kCSlot + (ch64 >> 3) * 1040 + (ch64 & 7) * 128 + ((piece ^ (ch64 & 7)) * 16));
+        }
+        double *yp = p.y + grp.ybase + (int64_t)c4 * p.ldy + (i - 1) * T + 2 * p16;
+#pragma unroll
+        for (int J = 0; J < 2 * kCChunks; ++J) c_store16(yp + (int64_t)(4 * J) * p.ldy, w[J]);
+      }
+    } else if (!p.nostore) {
       double *yt = yg + i * y_tile;
       const char *ts = smem + slot * kCSlot;
       cdbl2 w[kCChunks];

@@ -55,7 +55,8 @@ def make_bank(alz, bands, streams, strategy="slaney", fs=48000, lo=50., hi=20000
 
 
 @pytest.mark.parametrize("strategy,streams,bands,n", [("slaney", 1, 256, 1 << 16), ("klapuri", 1, 64, 1 << 16),
-                                                         ("slaney", 3, 128, 3 << 14), ("slaney", 2, 8, 1 << 15)])
+                                                         ("slaney", 3, 128, 3 << 14), ("slaney", 2, 8, 1 << 15),
+                                                         ("slaney", 1, 256, 272 * 256)])   # 17 tiles per chunk: an odd tile behind the stored pairs, segments that are not whole lines (k_cdot)
 def test_dot_product_zero_state_pass(alz, oracle, strategy, streams, bands, n):
   """After reset the bank's state is self-consistent: the zero-state pass is k_cdot; block after block (the fix kernel
   leaves the bank's state itself), then a serial continuation from that state."""
