@@ -21,9 +21,12 @@
 
 namespace alz {
 
-// the channel-major broadcast form stores two tiles at a time (256-byte pieces per row); 0: tile by tile (A/B)
+// 1: the channel-major broadcast form stores two tiles at a time (256-byte pieces per row instead of 128).  Measured
+// against tile-by-tile stores on the same box, three alternating pairs of runs (profiles/r05_pairstore_ab.log): 396.0 /
+// 393.5 / 394.0 against 396.1 / 394.1 / 395.2 Gsamples/s -- nothing; the distance to the time-major form (446 - 458) is
+// not the piece size (the 64 rows of a wave's store lie 8 MiB apart in [bands, 2^20] doubles: one HBM channel).  Off.
 #ifndef ALZ_CASC_PAIRSTORE
-#define ALZ_CASC_PAIRSTORE 1
+#define ALZ_CASC_PAIRSTORE 0
 #endif
 static constexpr int kCRing = 4;
 static constexpr int kCChunks = 8;
