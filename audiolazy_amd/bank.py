@@ -424,12 +424,25 @@ class FilterBank(object):
                                              n, lay, ldx, ldy))
     return y
 
+  @staticmethod
+  def _row_pitch(t, what):
+    """Leading dimension (elements between consecutive rows) of a 2-D float64 CUDA tensor whose rows are contiguous:
+    a contiguous tensor, or a view of a wider one (``base[:, :cols]``: rows padded -- the C ABI's ldx / ldy).  A row
+    pitch that is a large power of two (rows of 2^18 .. 2^20 doubles) maps consecutive rows onto the same HBM channel:
+    channel-major blocks with such rows gain 3 - 16 % from a pad of 32 doubles (profiles/r05_pitch_probe.log)."""
+    import torch
+    if not t.is_cuda or t.dtype != torch.float64 or t.dim() != 2:
+      raise ValueError("torch %s must be a 2-D float64 CUDA tensor" % what)
+    rows, cols = t.shape
+    if t.is_contiguous():
+      return cols
+    if (cols > 1 and t.stride(1) != 1) or (rows > 1 and t.stride(0) < cols):
+      raise ValueError("torch %s must have contiguous rows (a contiguous tensor or a column-sliced view of one)" % what)
+    return t.stride(0) if rows > 1 else cols
+
   def _process_torch(self, x, lay, out):
     import torch
-    if not x.is_cuda or x.dtype != torch.float64 or not x.is_contiguous():
-      raise ValueError("torch input must be a contiguous float64 CUDA tensor")
-    if x.dim() != 2:
-      raise ValueError("torch input must be 2-D")
+    ldx = self._row_pitch(x, "input")
     n, cin = (tuple(x.shape) if lay == _ffi.TIME_MAJOR else tuple(x.shape)[::-1])
     if cin != self.n_inputs:
       raise ValueError("block has %d input channels, bank expects %d" % (cin, self.n_inputs))
@@ -437,8 +450,9 @@ class FilterBank(object):
     y = torch.empty(shape, dtype=torch.float64, device=x.device) if out is None else out
     if n == 0:
       return y
-    ldx = self.n_inputs if lay == _ffi.TIME_MAJOR else n
-    ldy = self.channels if lay == _ffi.TIME_MAJOR else n
+    if tuple(y.shape) != shape or y.device != x.device:
+      raise ValueError("out must be a %s float64 CUDA tensor on the input's device" % (shape,))
+    ldy = self._row_pitch(y, "out")
     stream = torch.cuda.current_stream(x.device).cuda_stream
     _ffi.check(self._L.alz_bank_process_dev(self._h, x.data_ptr(), y.data_ptr(), n, lay, ldx, ldy,
                                             ctypes.c_void_p(stream)))

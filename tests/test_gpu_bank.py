@@ -573,3 +573,35 @@ def test_fir_narrow_and_long(alz, oracle):
   assert y.shape == ref.shape
   same = y.view(np.uint64) == ref.view(np.uint64)
   assert same.all(), "first differing row %d of %d" % (int(np.argmin(same.all(axis=1))), n)
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_row_padded_torch_tensors(alz, oracle, layout):
+  """``process`` takes 2-D CUDA tensors whose rows are contiguous but padded (a column-sliced view of a wider
+  allocation): the C ABI's ldx / ldy.  Round 5 measured what the pitch is worth -- channel-major blocks whose rows are a
+  large power of two apart (2^18 .. 2^20 doubles) land consecutive rows on the same HBM channel and gain 3 - 16 % from 32
+  doubles of padding (profiles/r05_pitch_probe.log) -- so a caller must be able to choose it.  Same doubles as the
+  contiguous call; a view whose rows are not contiguous is refused."""
+  import torch
+  C, n = 256, 4096 + 64
+  rng = np.random.default_rng(31)
+  r, th = rng.uniform(.8, .999, C), rng.uniform(.02, 3., C)
+  b = rng.uniform(-1, 1, (C, 3))
+  a = np.stack([np.ones(C), -2 * r * np.cos(th), r * r], axis=1)
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  x = rng.uniform(-1, 1, (n, C) if layout == "time" else (C, n))
+  ref = oracle.bank([3], [3], b, a, x, layout=layout)
+  rows, cols = x.shape
+  for pad_x, pad_y in ((0, 32), (18, 0), (34, 34)):
+    xw = torch.zeros((rows, cols + pad_x), dtype=torch.float64, device="cuda")
+    yw = torch.full((rows, cols + pad_y), -7.0, dtype=torch.float64, device="cuda")
+    xv, yv = xw[:, :cols], yw[:, :cols]
+    xv.copy_(torch.from_numpy(x))
+    bank.reset()
+    out = bank.process(xv, layout=layout, out=yv)
+    assert out.data_ptr() == yw.data_ptr()
+    assert same_bits(yv.cpu().numpy(), ref), (layout, pad_x, pad_y, bank.last_kernel)
+    if pad_y:
+      assert bool((yw[:, cols:] == -7.0).all())            # the padding is not written
+  with pytest.raises(ValueError):
+    bank.process(torch.zeros((rows, 2 * cols), dtype=torch.float64, device="cuda")[:, ::2], layout=layout)
