@@ -28,11 +28,6 @@
 #define ALZ_TUNE(name, dflt) (dflt)
 #endif
 
-// channel-major tile DMA of k_duo / k_look: rotate the odd channel's pieces by 128 bytes (see alz_wave.hip)
-#ifndef ALZ_CM_ROT
-#define ALZ_CM_ROT 0
-#endif
-
 namespace alz {
 
 // thread-local last-error message (alz_last_error)

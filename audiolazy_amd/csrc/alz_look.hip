@@ -324,12 +324,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
     const int row = lane / 8, cp = lane % 8;
     // time-major: transfer j = rows 8 j .. 8 j + 7 of the tile, 128 bytes (16 channels) each;
     // channel-major: transfer j = channels 2 j, 2 j + 1, the tile's 512 bytes of each
-    // (ALZ_CM_ROT: the odd channel of a transfer fetches piece (l & 31) ^ 8 -- its samples sit at byte (8 u) ^ 128 of its row,
-    // 32 banks away from the even channel's)
-    const double *xg = CM ? p.x + (c0 + (lane >> 5)) * p.ldx + 2 * ((ALZ_CM_ROT && (lane >> 5)) ? ((lane & 31) ^ 8) : (lane & 31))
-                          : p.x + (int64_t)row * p.ldx + c0 + 2 * cp;
-    const int xrot = (CM && ALZ_CM_ROT && (cl & 1)) ? 128 : 0;
-#define ALZ_XPOS(o) ((CM && ALZ_CM_ROT) ? ((o) ^ xrot) : (o))
+    const double *xg = CM ? p.x + (c0 + (lane >> 5)) * p.ldx + 2 * (lane & 31) : p.x + (int64_t)row * p.ldx + c0 + 2 * cp;
     const int64_t x_chunk = CM ? 2 * p.ldx : 8 * p.ldx;
     double b0 = 0, b1 = 0, b2 = 0;
     if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
@@ -368,16 +363,6 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       double x0[16], x1[16], x2[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if constexpr (CM && ALZ_CM_ROT) {
-          if constexpr (PB & 1u) x0[j] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * q)));
-          if constexpr (PB & 2u) {
-            if (j > 0) x1[j] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * (q - 1))));
-          }
-          if constexpr (PB & 4u) {
-            if (j > 0) x2[j] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * (q - 2))));
-          }
-          continue;
-        }
         if constexpr (PB & 1u) x0[j] = look_pre<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
         if constexpr (PB & 2u) {
           if (j > 0) x1[j] = look_pre<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
@@ -393,9 +378,9 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         const double q2 = look_pre<PRE>(*reinterpret_cast<const double *>(hs));
         const double q1 = look_pre<PRE>(*reinterpret_cast<const double *>(hs + (CM ? 8 : 128)));
         const double pm1 = stream_start ? hh1 : q1, pm2 = stream_start ? hh2 : q2;
-        const double s0 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(0))));
-        const double s1 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(1))));
-        const double s2 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(2))));
+        const double s0 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(0)));
+        const double s1 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(1)));
+        const double s2 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(2)));
         if constexpr (PB & 2u) x1[0] = q == 0 ? pm1 : q == 1 ? s0 : q == 2 ? s1 : s2;
         if constexpr (PB & 4u) x2[0] = q == 0 ? pm2 : q == 1 ? pm1 : q == 2 ? s0 : s1;
       }
@@ -440,8 +425,8 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       if (i + 1 < TOT) {
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
           const char *xs = smem + ((i + 1) % kSlots) * kSlot + xlane_off;
-          if (p.nb > 1) p.xh[0 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(T - 1))));
-          if (p.nb > 2) p.xh[1 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(T - 2))));
+          if (p.nb > 1) p.xh[0 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
+          if (p.nb > 2) p.xh[1 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
         }
         ALZ_LOOK_MARK(2)
         if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
@@ -673,7 +658,6 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 #endif
   }
 #undef ALZ_EOFF
-#undef ALZ_XPOS
 }
 #undef ALZ_LOOK_CLOCK
 #undef ALZ_LOOK_MARK

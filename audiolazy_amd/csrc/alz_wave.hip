@@ -389,11 +389,6 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
-// ALZ_CM_ROT 1 (channel-major): the two channel rows of a 1 KiB DMA transfer land 512 bytes apart -- the same banks, so
-// every read of the feed-forward pass is 2-way conflicted (k_look's counters, profiles/r05_look_lds_pmc.txt: 44 % of the
-// LDS's active cycles).  Rotating the ODD channel's sixteen-byte pieces by 128 bytes on the global side of the DMA
-// (lane l >= 32 fetches piece (l & 31) ^ 8) puts the pair 32 banks apart: sample u of an odd channel then sits at byte
-// (8 u) ^ 128 of its row.
 #ifndef ALZ_DUO_CMPAD
 #define ALZ_DUO_CMPAD 16
 #endif
@@ -459,14 +454,11 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTO
       x_tile = (int64_t)T * p.ldx; y_tile = (int64_t)T * p.ldy;
     } else {
       const int ch = lane / 32, sp = lane % 32;
-      x_off = (in0 + ch) * p.ldx + 2 * ((ALZ_CM_ROT && ch) ? (sp ^ 8) : sp);
+      x_off = (in0 + ch) * p.ldx + 2 * sp;
       y_off = (c0 + ch) * p.ldy + 2 * sp;
       x_chunk = 2 * p.ldx; y_chunk = 2 * p.ldy;
       x_tile = T; y_tile = T;
     }
-    // (ALZ_CM_ROT) byte position of sample-offset o (= 8 u) in this lane's channel row of the x ring
-    const int xrot = (CM && ALZ_CM_ROT && (cl & 1)) ? 128 : 0;
-#define ALZ_XPOS(o) ((CM && ALZ_CM_ROT) ? ((o) ^ xrot) : (o))
     double b0 = 0, b1 = 0, b2 = 0;
     if (PB & 1u) b0 = p.b[0 * p.n_sets + set];
     if (PB & 2u) b1 = p.b[1 * p.n_sets + set];
@@ -491,7 +483,6 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTO
       const char *xp = xring + (int)((t + kXRing - 1) % kXRing) * kDuoSlot + lane_off;  // tile t-1
       char *ps = pring + (int)(t % kPRing) * kPYSlot + lane_off_p;
       auto xat = [&](int u) -> double {       // x[u] of this tile; u = -1, -2 reach into tile t-1
-        if constexpr (CM && ALZ_CM_ROT) return pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(8 * u)));
         return pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(u)));
       };
       // sample 4j + q - d sits q - d steps after sample 4j; in TIME layout the 16-byte pad after
@@ -504,16 +495,6 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTO
       auto read_rows = [&](int j0, int j1) {
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
-          if constexpr (CM && ALZ_CM_ROT) {
-            if constexpr (PB & 1u) x0[j] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * q)));
-            if constexpr (PB & 2u) {
-              if (j > 0) x1[j] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * (q - 1))));
-            }
-            if constexpr (PB & 4u) {
-              if (j > 0) x2[j] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(32 * j + 8 * (q - 2))));
-            }
-            continue;
-          }
           if constexpr (PB & 1u) x0[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d0 + ALZ_EOFF(4 * j)));
           if constexpr (PB & 2u) {
             if (j > 0) x1[j] = pre_in<PRE>(*reinterpret_cast<const double *>(x_d1[j & 1] + ALZ_EOFF(4 * j)));
@@ -547,8 +528,8 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTO
         if constexpr ((PB & 6u) != 0) {
           double pm1, pm2;                        // x[-1], x[-2] relative to this tile
           if (t > 0) {
-            pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_XPOS(ALZ_EOFF(T - 1))));
-            pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_XPOS(ALZ_EOFF(T - 2))));
+            pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1)));
+            pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2)));
           } else {
             pm1 = d1;
             pm2 = d2;
@@ -647,10 +628,9 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTO
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
     if (!NOSTORE && q == 3) {
       const char *xs = xring + (int)((nt - 1) % kXRing) * kDuoSlot + lane_off;
-      if (p.nb > 1) p.xh[0 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(T - 1))));
-      if (p.nb > 2) p.xh[1 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_XPOS(ALZ_EOFF(T - 2))));
+      if (p.nb > 1) p.xh[0 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
+      if (p.nb > 2) p.xh[1 * p.channels + sc] = pre_in<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
     }
-#undef ALZ_XPOS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // ------------------------------ REC ------------------------------
