@@ -621,10 +621,6 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   if constexpr (BC) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) xcur[u] = xb[(int64_t)u * xstep];
-    // (consumed here: hipcc waits for these loads now and carries no pending-load state into the tile loop, where its
-    // conservative s_waitcnt vmcnt(0) would drain the asm requests and the stores every iteration)
-#pragma unroll
-    for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xcur[u]));
   } else {
     for (int t = 0; t < kCRing - 1 && t < nt; ++t) {
 #pragma unroll
@@ -646,15 +642,9 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
     const int slot = (int)(i % kOutRing);
     const int64_t tn = i + kCRing - 1;
     if constexpr (BC) {
-      // The next tile's 16 samples, requested now and waited for behind this tile's stores.  By asm statements hipcc does
-      // not see: as plain loads they made it put its own s_waitcnt vmcnt(6 .. 4) at the top of the next tile -- counted
-      // as if nothing else were in flight, so the wave stood until most of the eight STORES it had just issued had
-      // retired, every tile (k_casc<bc>'s counters: waiting 31 % of its cycles; profiles/NOTES_r05.md 2).
       const int64_t t1 = i + 1 < nt ? i + 1 : i;           // (the last tile requests itself again)
-      const double *src = xb + t1 * T * xstep;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(xnext[u]) : "v"(src + (int64_t)u * xstep) : "memory");
+      for (int u = 0; u < 16; ++u) xnext[u] = xb[(t1 * T + u) * xstep];
     } else {
       if (tn < nt) {
         const int sn = (int)(tn % kCRing);
@@ -713,15 +703,6 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slot is about to be refilled by DMA)
     }
     if constexpr (BC) {
-      // the 16 requests were issued before this tile's eight stores: all but the eight newest operations done = landed
-      if (p.nostore || ALZ_CASC_PAIRSTORE)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xnext[0]), "+v"(xnext[1]), "+v"(xnext[2]), "+v"(xnext[3]), "+v"(xnext[4]), "+v"(xnext[5]),
-                     "+v"(xnext[6]), "+v"(xnext[7]), "+v"(xnext[8]), "+v"(xnext[9]), "+v"(xnext[10]), "+v"(xnext[11]), "+v"(xnext[12]),
-                     "+v"(xnext[13]), "+v"(xnext[14]), "+v"(xnext[15]) : : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(xnext[0]), "+v"(xnext[1]), "+v"(xnext[2]), "+v"(xnext[3]), "+v"(xnext[4]), "+v"(xnext[5]),
-                     "+v"(xnext[6]), "+v"(xnext[7]), "+v"(xnext[8]), "+v"(xnext[9]), "+v"(xnext[10]), "+v"(xnext[11]), "+v"(xnext[12]),
-                     "+v"(xnext[13]), "+v"(xnext[14]), "+v"(xnext[15]) : : "memory");
 #pragma unroll
       for (int u = 0; u < 16; ++u) xcur[u] = xnext[u];
     }
