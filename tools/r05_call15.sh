@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5, last GPU call: HEAD as the driver will find it -- the gpu suite, smoke(), the driver's command with its full record.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05o
+mkdir -p $O
+cd $R
+rocm-smi --showuniqueid 2>/dev/null | grep "GPU\[" | head -1 | tee $O/smi.log
+timeout 1200 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed" $O/pytest_gpu.log | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-json $O/bench_driver_full.json > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench rc=$?"; python tools/show_line.py $O/bench_driver.json | cut -c1-170
