@@ -222,6 +222,19 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// the same with the non-temporal policy (NT instantiations: batches far larger than the Infinity Cache, read exactly once)
+__device__ __forceinline__ void lpc_dma16_nt(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 
 // LEV = 1: Levinson-Durbin runs right away on the lane's P lags (still in registers) and the
 // kernel writes coefficients / error / status instead of the lags: lpc.kautocor in one launch.
@@ -241,7 +254,12 @@ __device__ __forceinline__ void lpc_dma16(const void *gsrc, unsigned lds_dst) {
 // RING: chunk slots in LDS (RING - 1 chunks of DMA ahead of the one being summed).  Two: 16 KiB instead of 24 put ten
 // one-wave workgroups on a CU instead of six (+7 .. 23 % at 2^20 frames, +3 % at configs[4]'s 65 536; deeper rings are
 // slower still: NOTES_r03.md 10).
-template <int P, int LEV, bool FMA = false, int kLpcRing = 3>
+// NT (round 5): the tile DMA with the non-temporal policy, for batches of >= 512 MiB -- a read-only stream moves 6.9 TB/s
+// that way against 6.1 (profiles/r05_copy_ceiling.log): 2^20 frames +2.3 % (+1.4 % with the dense Levinson-Durbin).  A
+// COMPILE-TIME choice: as a wave-uniform branch around the two asm statements it cost configs[4]'s own 65 536-frame launch
+// 2 % (profiles/r05_lpc_nt_ab.log; k_duo's lesson).  The three-slot instantiations it replaces in the shipped library are
+// reachable in -DALZ_TUNING builds only (two slots have been the measured choice since round 3).
+template <int P, int LEV, bool FMA = false, int kLpcRing = 3, bool NT = false>
 __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ sig, int64_t n_frames,
                                                      int frame_len, int64_t hop, double *__restrict__ r_out,
                                                      double *__restrict__ coefs, double *__restrict__ err,
@@ -266,7 +284,10 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
   auto queue = [&](int c) {
     const unsigned slot = lds0 + (unsigned)(c % kLpcRing) * 8192u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) lpc_dma16(src_of(j, c), slot + j * 1024);
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (NT) lpc_dma16_nt(src_of(j, c), slot + j * 1024);
+      else lpc_dma16(src_of(j, c), slot + j * 1024);
+    }
   };
   const int64_t f = f0 + lane;
   const bool live = f < n_frames;
@@ -458,32 +479,40 @@ static lag_rows_fn pick_lag_rows(int P) {
 
 typedef void (*acorr_lane_fn)(const double *, int64_t, int, int64_t, double *);
 typedef void (*acorr_stage_fn)(const double *, int64_t, int, int64_t, double *, double *, double *, int *);
-template <int LEV, bool FMA = false, int RING = 3>
+template <int LEV, bool FMA = false, int RING = 3, bool NT = false>
 static acorr_stage_fn pick_acorr_stage(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9, LEV, FMA, RING>;
-    case 11: return k_acorr_stage<11, LEV, FMA, RING>;
-    case 13: return k_acorr_stage<13, LEV, FMA, RING>;
-    case 17: return k_acorr_stage<17, LEV, FMA, RING>;
-    case 21: return k_acorr_stage<21, LEV, FMA, RING>;
-    case 25: return k_acorr_stage<25, LEV, FMA, RING>;
-    case 33: return k_acorr_stage<33, LEV, FMA, RING>;
+    case 9: return k_acorr_stage<9, LEV, FMA, RING, NT>;
+    case 11: return k_acorr_stage<11, LEV, FMA, RING, NT>;
+    case 13: return k_acorr_stage<13, LEV, FMA, RING, NT>;
+    case 17: return k_acorr_stage<17, LEV, FMA, RING, NT>;
+    case 21: return k_acorr_stage<21, LEV, FMA, RING, NT>;
+    case 25: return k_acorr_stage<25, LEV, FMA, RING, NT>;
+    case 33: return k_acorr_stage<33, LEV, FMA, RING, NT>;
     default: return nullptr;
   }
 }
 
 // the bit-identical one-launch form for the orders the dense Levinson-Durbin is unrolled for (alz_lev.hip has
 // the same list); other orders run the two-launch form
-template <int RING = 3>
+template <int RING = 3, bool NT = false>
 static acorr_stage_fn pick_acorr_stage_dense(int P) {
   switch (P) {
-    case 9: return k_acorr_stage<9, 2, false, RING>;
-    case 11: return k_acorr_stage<11, 2, false, RING>;
-    case 13: return k_acorr_stage<13, 2, false, RING>;
-    case 17: return k_acorr_stage<17, 2, false, RING>;
+    case 9: return k_acorr_stage<9, 2, false, RING, NT>;
+    case 11: return k_acorr_stage<11, 2, false, RING, NT>;
+    case 13: return k_acorr_stage<13, 2, false, RING, NT>;
+    case 17: return k_acorr_stage<17, 2, false, RING, NT>;
     default: return nullptr;
   }
 }
+// three chunk slots: tuning builds only (see k_acorr_stage)
+#ifdef ALZ_TUNING
+#define ALZ_LPC_RING3(expr) (expr)
+#else
+#define ALZ_LPC_RING3(expr) ((alz::acorr_stage_fn) nullptr)
+#endif
+// a batch of >= 512 MiB of signal is read exactly once and does not fit the Infinity Cache: non-temporal tiles
+static bool stage_nt(int64_t n_frames, int frame_len) { return n_frames * (int64_t)frame_len >= (INT64_C(1) << 26); }
 
 // two chunk slots (one chunk of DMA ahead): same-box pairs 1.04 / 1.06 against 1.01 / 1.02 Gframes/s at 65 536 frames,
 // 1.01 against 0.94 at 2^20 (profiles/r03_lpc_ring.log); the three-slot instantiations stay selectable in tuning builds
@@ -557,8 +586,10 @@ static bool launch_acorr_dense(const double *sig, int64_t n_frames, int frame_le
   const int P = max_lag + 1;
   // lane-per-frame form for the usual orders when there are enough frames to fill the chip
   const bool ring2 = stage_ring2(n_frames);
+  const bool nt = stage_nt(n_frames, frame_len);
   if (acorr_stage_fn st_fn = !stage_ok(sig, n_frames, frame_len, hop) ? nullptr
-                             : ring2 ? pick_acorr_stage<0, false, 2>(P) : pick_acorr_stage<0>(P)) {
+                             : ring2 ? (nt ? pick_acorr_stage<0, false, 2, true>(P) : pick_acorr_stage<0, false, 2>(P))
+                                     : ALZ_LPC_RING3(pick_acorr_stage<0>(P))) {
     hipLaunchKernelGGL(st_fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, st, sig, n_frames,
                        frame_len, hop, r_out, (double *)nullptr, (double *)nullptr, (int *)nullptr);
     if (hipGetLastError() != hipSuccess) *rc = fail(ALZ_E_HIP, "k_acorr_stage launch failed");
@@ -639,16 +670,21 @@ int alz_lpc_kautocor_dev_ex(const double *sig_dev, int64_t n_frames, int frame_l
     const bool fused = (flags & ALZ_LPC_FUSED) != 0;
     const bool ring2 = alz::stage_ring2(n_frames);
     const int P = order + 1;
+    const bool nt = alz::stage_nt(n_frames, frame_len);
     alz::acorr_stage_fn fn =
-        dense ? (fused ? nullptr : ring2 ? alz::pick_acorr_stage_dense<2>(P) : alz::pick_acorr_stage_dense<3>(P))
-        : fused ? (ring2 ? alz::pick_acorr_stage<1, true, 2>(P) : alz::pick_acorr_stage<1, true, 3>(P))
-                : (ring2 ? alz::pick_acorr_stage<1, false, 2>(P) : alz::pick_acorr_stage<1, false, 3>(P));
+        dense ? (fused ? nullptr
+                       : ring2 ? (nt ? alz::pick_acorr_stage_dense<2, true>(P) : alz::pick_acorr_stage_dense<2>(P))
+                               : ALZ_LPC_RING3(alz::pick_acorr_stage_dense<3>(P)))
+        : fused ? (ring2 ? (nt ? alz::pick_acorr_stage<1, true, 2, true>(P) : alz::pick_acorr_stage<1, true, 2>(P))
+                         : ALZ_LPC_RING3((alz::pick_acorr_stage<1, true, 3>(P))))
+                : (ring2 ? (nt ? alz::pick_acorr_stage<1, false, 2, true>(P) : alz::pick_acorr_stage<1, false, 2>(P))
+                         : ALZ_LPC_RING3((alz::pick_acorr_stage<1, false, 3>(P))));
     if (fn) {
       hipLaunchKernelGGL(fn, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), (ring2 ? 2 : 3) * 8192, (hipStream_t)stream,
                          sig_dev, n_frames, frame_len, hop, (double *)nullptr, coefs_dev, err_dev, status_dev);
       if (hipGetLastError() != hipSuccess) rc = alz::fail(ALZ_E_HIP, "k_acorr_stage launch failed");
       alz::note_kernel("k_acorr_stage<" + std::to_string(P) + (dense ? ",dense Levinson-Durbin" : fused ? ",lev,fma" : ",lev") +
-                       (ring2 ? ",2 slots>" : ",3 slots>"));
+                       (ring2 ? ",2 slots" : ",3 slots") + (nt ? ",nt>" : ">"));
       done = true;
     }
   }
