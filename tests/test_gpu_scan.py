@@ -216,18 +216,37 @@ def test_one_pass_layouts_maps_in_place(alz, oracle, layout, mode, C, n, pattern
   bank.reset()
   xin = np.concatenate([x1, x2], axis=ax)
   ref = oracle.bank([nb], [na], b, a, np.abs(xin) if "abs" in mode else xin, layout=layout)
-  at = 0
-  for x in (x1, x2):
-    xd = torch.from_numpy(x).cuda()
-    y = bank.process(xd, layout=layout, out=xd if "inplace" in mode else None)
-    assert "k_look" in bank.last_kernel, bank.last_kernel
-    if "abs" in mode:
-      assert "k_map" not in bank.last_kernel, bank.last_kernel      # no separate pass over the block
+  # The one-pass kernel's contract is "correct, or the NEXT entry point on the handle raises" (a workgroup that started
+  # later than the spin cap allows; tests/...::test_one_pass_beside_foreign_work_is_correct_or_raises).  So every block is
+  # followed by an entry point (get_state) before its result is judged, and a stream on which the kernel reported a
+  # timed-out wait is run again from reset -- a WRONG result without that report still fails here.  (Seen once in ~1000
+  # runs of these cases, call 16 of round 5: profiles/NOTES_r05.md 8.)
+  for attempt in range(3):
+    bank.reset()
+    at, gave_up, outs = 0, False, []
+    for x in (x1, x2):
+      xd = torch.from_numpy(x).cuda()
+      y = bank.process(xd, layout=layout, out=xd if "inplace" in mode else None)
+      kernels = bank.last_kernel
+      try:
+        bank.get_state()
+      except RuntimeError as exc:
+        assert "gave up waiting" in str(exc), exc
+        gave_up = True
+        break
+      assert "k_look" in kernels, kernels
+      if "abs" in mode:
+        assert "k_map" not in kernels, kernels      # no separate pass over the block
+      if "inplace" in mode:
+        assert y.data_ptr() == xd.data_ptr()
+      outs.append(y.cpu().numpy())
+    if not gave_up:
+      break
+  assert not gave_up, "the one-pass kernel reported a timed-out wait three times in a row"
+  for y, x in zip(outs, (x1, x2)):
     m = x.shape[ax]
     want = ref[at:at + m] if tm else ref[:, at:at + m]
-    assert norm_err(y.cpu().numpy(), want, ax) <= 1e-8, (layout, mode)
-    if "inplace" in mode:
-      assert y.data_ptr() == xd.data_ptr()
+    assert norm_err(y, want, ax) <= 1e-8, (layout, mode)
     at += m
 
 
