@@ -55,6 +55,7 @@ struct alz_bank {
   double *b_dev = nullptr, *a_dev = nullptr;
   double *xh_dev = nullptr, *yh_dev = nullptr;  // 2x capacity (k_generic's new-state copy)
   std::vector<alz::SectionDev> sec;
+  std::vector<alz::FirChains> fir_chains;   // per section (sized once: the sections point into it)
   double zero = 0.0;
   int fused = 0;
   int input_map = 0;                    // ALZ_MAP_ABS / NEG / SQUARE applied to every input sample, or 0
@@ -249,8 +250,10 @@ int alz_bank_create(int64_t n_sets, int64_t n_inputs, int mode, int n_sections, 
   // Section descriptors.  Each section's state occupies a [taps-1][channels]
   // slab (x2 for k_generic's new-state copy), slabs laid out back to back.
   int64_t boff = 0, aoff = 0;
+  h->fir_chains.resize((size_t)n_sections);
   for (int s = 0; s < n_sections; ++s) {
     alz::SectionDev d;
+    d.chains = &h->fir_chains[(size_t)s];
     d.nb = nb[s];
     d.na = na[s];
     d.b = h->b_dev + boff * n_sets;
@@ -334,6 +337,8 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->map_in) (void)hipFree(h->map_in);
   if (h->expand_in) (void)hipFree(h->expand_in);
+  for (alz::FirChains &fc : h->fir_chains)
+    if (fc.flags) (void)hipFree(fc.flags);
   for (hipStream_t st : h->host_streams)
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : h->host_events) (void)hipEventDestroy(ev);

@@ -54,7 +54,16 @@ int ensure_dynamic_lds(const void *fn, int bytes);
 //   b[k * n_sets + set], a[k * n_sets + set]
 //   xh[k * channels + c] = input  of this section at time -1-k   (k < nb-1)
 //   yh[k * channels + c] = output of this section at time -1-k   (k < na-1)
+// Pacing slab of k_fir_ring's chains (alz_fir.hip): start stamps of the runs of the launch in flight, owned by the bank,
+// one per section; grown on demand, never shrunk.  Stamps carry the launch's epoch, so the slab is never cleared.
+struct FirChains {
+  unsigned long long *flags = nullptr;
+  size_t len = 0;
+  unsigned epoch = 0;
+};
+
 struct SectionDev {
+  FirChains *chains = nullptr;   // nullptr: k_fir_ring keeps its interleaved mapping
   int nb, na;
   const double *b, *a;
   double *xh, *yh;

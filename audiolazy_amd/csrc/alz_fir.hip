@@ -49,9 +49,22 @@ struct FArgs {
   const double *xh;        // xh[k * channels + c] = x[-1-k]
   int div;                 // some a0 != 1
   double zero;             // what an all-zero tap set yields (lazy_filters.py:227-231)
-  // k_fir_ring: block (x, y) computes the runs of kRingR output rows  y * run_first_mul + s * run_stride,
-  // s = 0 .. run_count - 1 (those that start inside the block)
-  int64_t run_first_mul, run_stride, run_count;
+  // k_fir_ring: block y = q * run_group + j computes the runs of kRingR output rows
+  //   q * run_span + run_first + j * run_first_mul + s * run_stride,  s = 0 .. run_count - 1
+  // (those that start inside the block).  Interleaved mapping: run_group > gridDim.y (q = 0), run y + s * gridDim.y.
+  // Chains: run_group = W, run (q + 1) * W * M - 1 - j - s * W -- W waves walk W * M consecutive runs TOWARDS THE PAST.
+  int64_t run_group, run_span, run_first, run_first_mul, run_stride, run_count;
+  // Pacing of the chains (launch_fir): a run posts (chain_epoch << 32 | wall clock at its start) in chain_flags[run *
+  // gridDim.x + blockIdx.x]; run r starts once run r + 1 of its channel group has been going for 1 / W of this wave's
+  // own start-to-start time (less the hand-over's latency).  A hint only: nothing is read through the flags, a stale
+  // or missing one costs L2 hits, not results, and every wait gives up after 0.4 ms.
+  unsigned long long *chain_flags;
+  unsigned long long *chain_stats;   // -DALZ_TUNING builds: wait ticks, waits, waits given up, run ticks, runs
+  unsigned chain_epoch;
+  int chain_bound;         // a wait gives up after this many percent of the lead (0: after 0.4 ms)
+  int chain_w;             // waves per chain
+  int chain_lead0;         // the lead in 10 ns ticks before a wave has timed a run of its own
+  int chain_share, chain_handover;   // lead = start-to-start time * chain_share / (100 W) - chain_handover ticks
 };
 
 template <bool SHARED>
@@ -406,10 +419,57 @@ void k_fir_ring(FArgs p) {
   // the lowest row a run starting at t0 reads is t0 - (nb_padded - K + PF K) - (K - 1) (the prefetch issued by
   // the last block): runs that start past that are interior
   const int64_t reach = (int64_t)((p.nb + K - 1) / K) * K + (kRingPF + 1) * K;
-  int64_t run = (int64_t)blockIdx.y * p.run_first_mul;
+  const int64_t yq = (int64_t)blockIdx.y / p.run_group, yj = (int64_t)blockIdx.y - yq * p.run_group;
+  int64_t run = yq * p.run_span + p.run_first + yj * p.run_first_mul;
+  unsigned lead = (unsigned)p.chain_lead0;
+  uint64_t started = 0;
   for (int64_t s = 0; s < p.run_count; ++s, run += p.run_stride) {
     const int64_t t0 = run * R;
-    if (t0 >= p.n) break;
+    if (t0 >= p.n) {
+      if (p.run_stride > 0) break;
+      continue;                                              // chains walk towards the past: their first runs may not exist
+    }
+    if (p.chain_flags != nullptr) {
+      const int64_t dep = run + 1;
+      if (dep % p.run_span != 0 && dep * R < p.n) {          // the run above, unless it is another chain's or past the block
+        const unsigned long long *f = p.chain_flags + dep * gridDim.x + blockIdx.x;
+        const uint64_t wait_from = wall_clock64();
+        const unsigned patience = p.chain_bound != 0 ? lead * (unsigned)p.chain_bound / 100u : 40000u;
+        for (;;) {
+          const unsigned long long v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+          const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+          const uint64_t now = wall_clock64();
+          if (hi == p.chain_epoch && (int)((unsigned)now - lo) >= (int)lead) break;
+          if (now - wait_from >= patience) {
+#ifdef ALZ_TUNING
+            if (p.chain_stats != nullptr && threadIdx.x == 0) atomicAdd(p.chain_stats + 2, 1ull);
+#endif
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+#ifdef ALZ_TUNING
+        if (p.chain_stats != nullptr && threadIdx.x == 0) {
+          atomicAdd(p.chain_stats + 0, (unsigned long long)(wall_clock64() - wait_from));
+          atomicAdd(p.chain_stats + 1, 1ull);
+        }
+#endif
+      }
+      const uint64_t now = wall_clock64();
+      if (threadIdx.x == 0)
+        __hip_atomic_store(p.chain_flags + run * gridDim.x + blockIdx.x,
+                           ((unsigned long long)p.chain_epoch << 32) | (unsigned)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (started != 0) {
+        // start to start: the run and whatever this wave waited -- what one turn of the chain takes
+        const uint64_t turn = (now - started) * (unsigned)p.chain_share / (100u * (unsigned)p.chain_w);
+        lead = turn > (unsigned)p.chain_handover ? (unsigned)turn - (unsigned)p.chain_handover : 0u;
+#ifdef ALZ_TUNING
+        if (p.chain_stats != nullptr && threadIdx.x == 0) { atomicAdd(p.chain_stats + 3, (unsigned long long)(now - started)); atomicAdd(p.chain_stats + 4, 1ull); }
+#endif
+      }
+      started = now;
+    }
     if (t0 >= reach) ring_run<FMA, false>(p, q, t0, live, a0);
     else ring_run<FMA, true>(p, q, t0, live, a0);
   }
@@ -548,7 +608,9 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
   p.mode = io.mode; p.map_input = io.map_input;
   p.nb = sec.nb; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.div = sec.any_div ? 1 : 0;
   p.zero = io.zero;
-  p.run_first_mul = 0; p.run_stride = 1; p.run_count = 0;
+  p.run_group = (int64_t)1 << 40; p.run_span = 1; p.run_first = 0; p.run_first_mul = 0; p.run_stride = 1; p.run_count = 0;
+  p.chain_flags = nullptr; p.chain_stats = nullptr; p.chain_epoch = 0; p.chain_bound = 0; p.chain_w = 1; p.chain_lead0 = 0;
+  p.chain_share = 0; p.chain_handover = 0;
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const unsigned gy = (unsigned)((io.n + kFirTB - 1) / kFirTB);
   if (gy > 65535u) return ALZ_OK;  // block longer than the grid's y range: caller falls back
@@ -567,32 +629,112 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
              io.sxn * 8 * kRingK < ((int64_t)1 << 31) &&
              (int64_t)(sec.nb + (kRingPF + 3) * kRingK + 2 * kRingR) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge runs: 32-bit row offsets
              (int64_t)(sec.nb - 1) * io.channels * 8 < ((int64_t)1 << 31)) {
-    // Run-to-wave mapping.  A run (kRingR output rows of 64 channels) reads a window of kRingR + nb - 1 input rows,
-    // so neighbouring runs share most of their input.  Interleaved (default): the grid is 64 times what fills the
-    // chip (two waves per SIMD are resident; a grid of exactly that size left 7 - 10 % on the table: waves that finish
-    // early leave their SIMD half empty, profiles/NOTES_r03.md 5) and block y takes runs y, y + GY, y + 2 GY, ...:
-    // blocks are dispatched in order, so at any moment the resident
-    // waves of a channel group -- same XCD, since the XCD follows blockIdx.x -- work on ADJACENT runs, and a row
-    // fetched by the leading wave is found in that XCD's L2 by the others a few microseconds later (reuse distance
-    // ~1.5 MB per XCD against 4 MB of L2).  Blocked (round 1/2): block y takes 8 consecutive runs, so concurrent
-    // waves are 8 runs apart and every re-read of a row comes from HBM / Infinity Cache 40+ us later.
+    // Run-to-wave mapping.  A run (kRingR output rows of 64 channels) reads a window of kRingR + nb - 1 input rows, so
+    // neighbouring runs share most of their input -- and whether they find it in L2 is a matter of WHEN they read it.
+    // FETCH_SIZE counts half the bytes of these loads (tools/ubench_fetch8.hip on a known byte count, as for wide loads);
+    // per launch of configs[2], doubled, in units of the input block (17.2 GB; read once = 1.0):
+    //   interleaved (rounds 3 - 4: run y + s GY, the resident waves of a channel group on ADJACENT runs)   5.8
+    //     -- of the 6.6 the waves load: they start together, so at every moment they read rows kRingR apart; what one wave
+    //     reads now the next one reads R taps later, by which time the XCD's 256 waves have pulled 6 MB through 4 MB of L2
+    //   chains, free-running (W waves walk W M consecutive runs towards the past)                            3.9
+    //   chains of 8, paced, waits bounded (what runs below)                                                  1.3 (FMA: 2.1)
+    //   chains of 16, a run waits as long as it takes                                                        1.3, 2 % slower
+    // and the kernel is 4 % (two roundings per term) / 6 % (FMA) faster for it: 53.4 / 81.3 Gsamples/s against 51.3 / 77.0.
+    // Chains: tap k of run r + 1 and tap k - R of run r read the same row, so with run r + 1 AHEAD of run r by R taps'
+    // time the ~(R + nb) / R runs that need a row read it together.  Towards the past because the window reaches that
+    // way: a wave finishes run r and goes on to r - W, which is W R rows further down, where run r - W + 1 (its neighbour
+    // in the chain) has just been.  The W waves of a chain are the waves of a channel group that are resident together
+    // (they share blockIdx.x, hence the XCD and its L2); spread evenly over one start-to-start time their leads are
+    // 1 / W of it each -- R taps' time when W = nb / R, a few taps off otherwise, which the L2 absorbs.  Pacing is by
+    // start stamps in global memory (FArgs): hints, nothing is read through them.
     const int64_t runs_total = (io.n + kRingR - 1) / kRingR;
-    const int map_sel = ALZ_TUNE("ALZ_FIR_MAP", 1);
+    int map_sel = ALZ_TUNE("ALZ_FIR_MAP", -1);
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int64_t per_group = (int64_t)ALZ_FIR_WAVES * 4 * cus / gx;   // waves of one channel group the chip holds at a time
+    // Chain width (profiles/NOTES_r05.md 9: widths 2 .. 16 on banks of 2048 .. 32768 channels, 96 .. 512 taps): 8 waves
+    // when the chip holds two chains or more per group, 4 when it holds eight waves of it, and chains of 4 WITHOUT pacing
+    // below that (one chain per group: its waves are all there is to wait for, and waiting did not pay).  2 never paid.
+    int64_t W = per_group >= 16 ? 8 : 4;
+    bool paced = per_group >= 8;
+    const int fill_c = ALZ_TUNE("ALZ_FIR_CFILL", 16);
+    const int64_t gy_c = ((int64_t)fill_c * 4 * cus + gx - 1) / gx;    // blocks per channel group: fill_c per SIMD
+    int64_t Qc = gy_c / W > 0 ? gy_c / W : 1;
+    int64_t Mc = (runs_total + Qc * W - 1) / (Qc * W);
+    if (map_sel < 0) {
+      // chains when the XCD follows blockIdx.x (gx a multiple of 8: a chain's waves share an L2), the chip holds whole
+      // chains of every group, the taps reach at least two runs back, and every wave has 16 runs or more to walk (the
+      // leads a chain starts with are idle time: at 8 runs per wave the interleaved mapping was 1 % ahead); that mapping otherwise
+      const bool chains = gx % 8 == 0 && per_group >= 4 && per_group % W == 0 && sec.nb >= 2 * kRingR && Mc >= 16;
+      map_sel = chains ? 4 : 1;
+    }
     unsigned gyr;
-    if (map_sel == 1) {
+    if (map_sel == 4) {
+      W = ALZ_TUNE("ALZ_FIR_W", (int)W);
+      paced = ALZ_TUNE("ALZ_FIR_PACED", paced ? 1 : 0) != 0;
+      Qc = gy_c / W > 0 ? gy_c / W : 1;
+      Mc = (runs_total + Qc * W - 1) / (Qc * W);
+      Qc = (runs_total + Mc * W - 1) / (Mc * W);
+      if (Qc * W > 65535) return ALZ_OK;
+      gyr = (unsigned)(Qc * W);
+      p.run_group = W; p.run_span = W * Mc; p.run_first = W * Mc - 1; p.run_first_mul = -1; p.run_stride = -W; p.run_count = Mc;
+      FirChains *fc = sec.chains;
+      const size_t need = (size_t)(Qc * W * Mc + 1) * gx + 8;
+      if (paced && fc != nullptr && need > fc->len) {
+        if (fc->flags) (void)hipFree(fc->flags);               // (waits for whatever still polls them)
+        fc->flags = nullptr; fc->len = 0;
+        if (hipMalloc((void **)&fc->flags, need * sizeof(unsigned long long)) == hipSuccess &&
+            hipMemsetAsync(fc->flags, 0, need * sizeof(unsigned long long), stream) == hipSuccess)
+          fc->len = need;
+        else (void)hipGetLastError();                         // no slab: the chains run free
+      }
+      if (paced && fc != nullptr && fc->len >= need) {
+        p.chain_flags = fc->flags;
+        p.chain_epoch = ++fc->epoch;
+        p.chain_w = (int)W;
+        // a wait gives up after 1.5 leads: 50 .. 200 % time alike with chains of 8 (200 % cost 7 % with chains of 4), the
+        // longer ones fetch less; waiting "until it comes" costs 2 - 15 % (the SIMD's other wave alone does not fill it)
+        p.chain_bound = ALZ_TUNE("ALZ_FIR_BOUND", 150);
+        // lead = start-to-start time * share / (100 W) - hand-over: the hand-over (stamp stored, polled, seen: ~2.5 us)
+        // is part of every lead, and a chain whose W leads add up to more than a turn makes its waves wait for it
+        p.chain_share = ALZ_TUNE("ALZ_FIR_SHARE", 85);
+        p.chain_handover = ALZ_TUNE("ALZ_FIR_HANDOVER", 250);
+        // before a wave has timed itself: ~0.98 (two roundings per term) / 0.65 (FMA) ticks per tap and output row
+        const int64_t turn0 = (int64_t)sec.nb * kRingR * (io.fused ? 65 : 98) / 100 * p.chain_share / (100 * W);
+        p.chain_lead0 = (int)(turn0 > p.chain_handover ? turn0 - p.chain_handover : 0);
+#ifdef ALZ_TUNING
+        if (getenv("ALZ_FIR_WAITSTAT")) {
+          p.chain_stats = fc->flags + fc->len - 8;
+          (void)hipMemsetAsync(p.chain_stats, 0, 8 * sizeof(unsigned long long), stream);
+        }
+#endif
+      }
+    } else if (map_sel == 0) {
+      gyr = (unsigned)((io.n + kRingTB - 1) / kRingTB);
+      p.run_group = 1; p.run_span = kRingTB / kRingR; p.run_stride = 1; p.run_count = kRingTB / kRingR;
+    } else {
+      // interleaved: a grid 64 times what fills the chip (a grid of exactly that size left 7 - 10 % on the table: waves
+      // that finish early leave their SIMD half empty, profiles/NOTES_r03.md 5), block y takes runs y, y + GY, y + 2 GY, ...
       static const int fill = ALZ_TUNE("ALZ_FIR_FILL", 64);
       int64_t gy_fill = ((int64_t)fill * 1024 + gx - 1) / gx;  // waves that fill 1024 SIMDs `fill` times
       if (gy_fill < 1) gy_fill = 1;
       if (gy_fill > 65535) gy_fill = 65535;                      // (the grid's y range)
       gyr = (unsigned)(runs_total < gy_fill ? runs_total : gy_fill);
       p.run_first_mul = 1; p.run_stride = gyr; p.run_count = (runs_total + gyr - 1) / gyr;
-    } else {
-      gyr = (unsigned)((io.n + kRingTB - 1) / kRingTB);
-      p.run_first_mul = kRingTB / kRingR; p.run_stride = 1; p.run_count = kRingTB / kRingR;
     }
     if (io.fused) hipLaunchKernelGGL(k_fir_ring<true>, dim3(gx, gyr), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL(k_fir_ring<false>, dim3(gx, gyr), dim3(64), 0, stream, p);
-    shared_name = io.fused ? "k_fir_ring<fma>" : "k_fir_ring";
+    shared_name = map_sel == 4 ? (io.fused ? "k_fir_ring<fma,chains>" : "k_fir_ring<chains>") : (io.fused ? "k_fir_ring<fma>" : "k_fir_ring");
+#ifdef ALZ_TUNING
+    if (p.chain_stats != nullptr) {
+      unsigned long long st[8];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(st, p.chain_stats, sizeof(st), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[fir chains] waits %llu (given up %llu), %.1f us each; runs %llu, %.1f us each; waiting %.2f %% of the run time\n",
+              st[1], st[2], st[1] ? st[0] * 0.01 / st[1] : 0.0, st[4], st[4] ? st[3] * 0.01 / st[4] : 0.0,
+              st[3] ? 100.0 * st[0] / st[3] : 0.0);
+    }
+#endif
   }
   else if (sec.shared_sets)
     hipLaunchKernelGGL(k_fir<true>, dim3(gx, gy), dim3(64), tap_bytes, stream, p);

@@ -323,6 +323,38 @@ def test_cfg3_fir256_full_extent_on_strided_channels(alz, oracle, bench, fused):
     assert same_bits(got, ref)
 
 
+@pytest.mark.parametrize("C,N,nb,kernel", [(8192, 98304, 256, "chains"),      # chains of 8 waves, 16 runs per wave (the fewest that take them)
+                                          (4096, 1 << 18, 129, "chains"),    # four chains per channel group, taps not a multiple of 4
+                                          (16384, 1 << 16, 256, "chains"),   # chains of 4: the chip holds 8 waves per group
+                                          (32768, 49152, 200, "chains"),     # ... 4 per group: chains without pacing
+                                          (8192, 90000, 256, "k_fir_ring"),  # fewer than 16 runs per wave: interleaved runs
+                                          (8192 + 64, 98304, 256, "k_fir_ring")])   # the XCD does not follow the channel group
+def test_fir_ring_chains_and_interleaved_runs(alz, oracle, C, N, nb, kernel):
+  """k_fir_ring's run-to-wave mappings at the sizes that pick them (launch_fir): the waves of a channel group walk
+  consecutive runs towards the past in chains, paced by start stamps (round 5), or take interleaved runs (rounds
+  3 - 4).  Whole blocks on 48 strided channels against the oracle, bit for bit, with a delay line that is not zero,
+  a block that ends inside a run, and a second block that continues the stream (the stamps of the first launch are
+  still in the slab: epochs tell them apart)."""
+  import torch
+  rng = np.random.default_rng(C + nb)
+  taps = rng.uniform(-1, 1, nb)
+  N1 = N - 17
+  x = _gpu_noise((N1 + 6000, C), C + N)
+  bank = alz.FilterBank([(taps, np.array([1.0]))], n_inputs=C)
+  bank.reset(zero=0.375)
+  y1 = bank.process(x[:N1], layout="time")
+  assert kernel in bank.last_kernel and ("chains" in bank.last_kernel) == (kernel == "chains"), bank.last_kernel
+  y2 = bank.process(x[N1:], layout="time")
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 44).astype(int), [1, 63, 64, C - 2]])
+  idx = torch.from_numpy(pick).cuda()
+  got = torch.cat([y1.index_select(1, idx), y2.index_select(1, idx)]).cpu().numpy()
+  xs = x.index_select(1, idx).cpu().numpy()
+  del x, y1, y2
+  torch.cuda.empty_cache()
+  ref = oracle.bank([nb], [1], taps, np.ones(1), xs, xh=np.full((len(pick), nb - 1), 0.375), zero=0.375, layout="time")
+  assert same_bits(got, ref)
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_cfg5_lpc_two_to_the_twenty_frames(alz, oracle, exact):
   """configs[4] as the 2^20-frame batch the bench reports (16 384 workgroups, the two-slot ring's later rounds): every

@@ -13,13 +13,16 @@ ALG = {  # algorithmic bytes per step, as bench.py defines them
   "gammatone_fma": (8 + 8 / 256.) * 256 * 64 * 2 ** 16, "envelope_abs": 16.0 * 4096 * 2 ** 20, "timevar_shared": 16.0 * 4096 * 2 ** 18,
   "timevar_per_channel": 40.0 * 4096 * 2 ** 18, "narrow512_bit_exact": 16.0 * 512 * 2 ** 20, "narrow512_time_parallel": 16.0 * 512 * 2 ** 20,
   "narrow512_time_parallel_three_launch": 16.0 * 512 * 2 ** 20}
-# kernels whose reads are 16 B / lane streams (tile DMA, wide loads): FETCH_SIZE x 2 per the guide's gfx950 note;
-# 8 B / lane readers (FIR buffer loads) are reported raw and marked uncalibrated
-WIDE = lambda key: not key.startswith("fir256")
+# FETCH_SIZE x 2 per the guide's gfx950 note -- for every kernel: round 5 read a known byte count in k_fir_ring's shape
+# (8 B / lane buffer loads, 512-byte row pieces 64 KiB apart: tools/ubench_fetch8.hip, profiles/r05_fetch8_calibration.log)
+# and the counter reported half of it, as it does for 16 B / lane streams (TCC_EA0_RDREQ x 64 B, the requests are 128 B).
+# The tables of rounds 3 - 4 carried the FIR rows raw ("uncalibrated"): their 1.95 x was 3.4 x.
+WIDE = lambda key: True
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes + kernel trace only, summed over this library's kernels of "
                "`python bench.py --no-secondary --no-parity-check --steps 3 --warmup 1 <workload>` and divided by the 4 steps; "
-               "FETCH_SIZE doubled for the 16 B/lane streaming kernels (guide: gfx950 counts half of such a stream; calibrated here on "
-               "k_duo: 1.00001 x algorithmic), raw for the 8 B/lane FIR reads (uncalibrated); WRITE_SIZE as reported", "workloads": {}}
+               "FETCH_SIZE doubled (guide: gfx950 counts half of a stream; calibrated here on k_duo: 1.00001 x algorithmic, and in round 5 "
+               "on a known byte count read in k_fir_ring's 8 B/lane shape: tools/ubench_fetch8.hip, profiles/r05_fetch8_calibration.log "
+               "-- the FIR rows of the round 3 - 4 tables were raw, i.e. half); WRITE_SIZE as reported", "workloads": {}}
 if len(sys.argv) > 2:
   out["workloads"] = {k: v for k, v in json.load(open(sys.argv[2]))["workloads"].items() if k in ALG}
 for key, alg in ALG.items():
