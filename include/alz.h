@@ -104,7 +104,12 @@ int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host);
  *   x: n_inputs channels, y: `channels` channels, both in `layout`;
  *   ldx / ldy: leading dimension in elements (TIME_MAJOR: >= channel count,
  *   CHAN_MAJOR: >= n).  y may alias x only in DIAGONAL mode with ldx == ldy.
- * process_host stages through device buffers owned by the handle.            */
+ * process_host stages through device buffers owned by the handle.
+ * Device scratch is allocated on first need by the call that needs it and kept
+ * by the handle (chunk states of the time-parallel mode; for a long feedback-
+ * free section on a big time-major block, a slab of one 8-byte start stamp per
+ * 48 rows and 64 channels -- 1/384 of the block -- through which the waves that
+ * share input rows pace each other; nothing is READ through it: same doubles). */
 int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev,
                          int64_t n, int layout, int64_t ldx, int64_t ldy,
                          void *stream);
