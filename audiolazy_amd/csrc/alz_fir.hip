@@ -57,7 +57,9 @@ struct FArgs {
   // Pacing of the chains (launch_fir): a run posts (chain_epoch << 32 | wall clock at its start) in chain_flags[run *
   // gridDim.x + blockIdx.x]; run r starts once run r + 1 of its channel group has been going for 1 / W of this wave's
   // own start-to-start time (less the hand-over's latency).  A hint only: nothing is read through the flags, a stale
-  // or missing one costs L2 hits, not results, and every wait gives up after 0.4 ms.
+  // or missing one costs L2 hits, not results, and a wait gives up after chain_bound percent of the lead (shipped: 1.5
+  // leads -- with another kernel's blocks on the chip the chains lose their gain and no more, profiles/NOTES_r05.md 9).
+  // Times are ticks of wall_clock64(), the 100 MHz constant clock (s_memrealtime).
   unsigned long long *chain_flags;
   unsigned long long *chain_stats;   // -DALZ_TUNING builds: wait ticks, waits, waits given up, run ticks, runs
   unsigned chain_epoch;
