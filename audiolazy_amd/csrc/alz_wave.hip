@@ -826,17 +826,23 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   const int64_t tiles = (ch ? ch->chunk_len : io.n) / t;
   if (groups == 0 || tiles == 0) return ALZ_OK;
   if (ch && tiles * t != ch->chunk_len) return ALZ_OK;
+  // The opt-in FMA mode ALLOWS contraction; it does not have to be used where it loses.  A time-major bank that fills the
+  // chip with one two-wave workgroup per CU (256 - 320 groups of 16 channels) is bound by the helper wave's pass over the
+  // tile, not by the recurrence, and the default kernel has the storing wave, the non-temporal tiles and the paced pass
+  // for it: 306 - 326 Gsamples/s against the FMA kernel's 295 - 304 (profiles/NOTES_r04.md 5, NOTES_r05.md 10).  Everywhere
+  // else the FMA kernels are 2 - 12 % ahead.  The default kernel's doubles are within every contract of the mode.
+  const bool fused = io.fused && !(g == 16 && !cm && !ch && groups >= 256 && groups <= 320);
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = ALZ_TUNE("ALZ_DUO", 1);
   const bool nostore = ch && ch->nostore;
   const bool pre_abs = io.pre_op == ALZ_MAP_ABS;
-  if (io.pre_op && (!pre_abs || ch || io.fused || sec.any_div)) return ALZ_OK;   // the caller maps the input first
+  if (io.pre_op && (!pre_abs || ch || fused || sec.any_div)) return ALZ_OK;   // the caller maps the input first
   // the single-wave kernel overtakes the two-wave one once a CU holds more than two workgroups' worth
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
   const bool prefer_single = g == 16 && lanes >= single_from && !ch;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
-  const bool nt_tiles = io.stream_once && !ch && (!io.fused || ALZ_DUO_FMA3) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
+  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
@@ -854,12 +860,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
                          : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a));
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
 #if ALZ_DUO_FMA3
-    if (io.fused && nt_tiles)
+    if (fused && nt_tiles)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true, false, false, 0, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true, false, false, 0, true>(sec.present_b, sec.present_a);
     else
 #endif
-    if (io.fused)
+    if (fused)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
     else
@@ -898,7 +904,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // Measured on three boxes (profiles/r04_duo_patterns.log): 4096 channels x 2^20 time-major +2 / +13 / +10 ... 16 %,
   // channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three pauses are better on one box and worse on the
   // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
-  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!io.fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
+  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
@@ -916,7 +922,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;
   *done_channels = groups * g;
-  *kernel_name = duo ? (sec.any_div ? "k_duo<16,div>" : io.fused && !nostore ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
+  *kernel_name = duo ? (sec.any_div ? "k_duo<16,div>" : fused && !nostore ? "k_duo<16,fma>" : "k_duo<16>") : g == 16 ? "k_wave<16>" : g == 32 ? "k_wave<32>" : "k_wave<64>";
   return ALZ_OK;
 }
 

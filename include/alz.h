@@ -120,7 +120,9 @@ int alz_bank_sync(alz_bank_t *h);
  * recurrence chain) and in the shared-tap FIR kernel (one instruction per tap instead of two: the
  * throughput mode of a feedback-free section, same ascending tap order).  Results are then NOT
  * bit-identical to the reference generator (normalised differences ~1e-13, contract 1e-6);
- * default off.  No reference counterpart (CPython floats never fuse).                      */
+ * default off.  No reference counterpart (CPython floats never fuse).  The mode ALLOWS the
+ * contraction: where the default kernel is the faster one (a time-major biquad bank of 4096 - 5120
+ * channels, bound by its helper wave rather than by the recurrence) the engine keeps it.   */
 int alz_bank_set_fused(alz_bank_t *h, int on);
 /* Opt-in time-parallel mode for narrow banks (the reference's generator is one serial chain per
  * channel, lazy_filters.py:251-257, so a bank of a few hundred channels cannot fill the GPU):

@@ -75,7 +75,14 @@ def test_cfg2_fused_mode_within_contract(alz, oracle, bench):
   bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
   bank.reset()
   y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
-  assert norm_err(y, oracle.bank([3], [3], b, a, x), 0) <= 1e-10
+  ref = oracle.bank([3], [3], b, a, x)
+  assert norm_err(y, ref, 0) <= 1e-10
+  # the mode ALLOWS the contraction: a time-major bank of one two-wave workgroup per CU is bound by its helper wave and
+  # keeps the default kernel (faster there: launch_wave), the channel-major one takes the FMA kernel
+  assert bank.last_kernel == "k_duo<16>" and same_bits(y, ref), bank.last_kernel
+  bank.reset()
+  yc = bank.process(torch.from_numpy(np.ascontiguousarray(x.T)).cuda(), layout="chan").cpu().numpy()
+  assert "fma" in bank.last_kernel and norm_err(yc, ref.T, 1) <= 1e-10 and not same_bits(yc, ref.T), bank.last_kernel
 
 
 # ---- configs[2]: 256-tap FIR x 8192 channels ---------------------------------------------------
