@@ -851,7 +851,7 @@ def fill_traffic(roof, key):
   roof["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
                             "(profiles/%s, key %r): x%.4f of algorithmic%s"
                             % (row["table"], key, row["traffic_over_algorithmic"], "" if row.get("fetch_correction") == 2.0 else
-                               " (8 B/lane reads: FETCH_SIZE uncalibrated)"))
+                               " (FETCH_SIZE taken raw: a table of rounds 3 - 4)"))
 
 
 def entry(res, world, steps, unit, workload, key=None):
