@@ -664,10 +664,12 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     int64_t Qc = gy_c / W > 0 ? gy_c / W : 1;
     int64_t Mc = (runs_total + Qc * W - 1) / (Qc * W);
     if (map_sel < 0) {
-      // chains when the XCD follows blockIdx.x (gx a multiple of 8: a chain's waves share an L2), the chip holds whole
-      // chains of every group, the taps reach at least two runs back, and every wave has 16 runs or more to walk (the
+      // chains when the XCD follows blockIdx.x (gx a multiple of 8: a chain's waves share an L2), the chip holds a whole
+      // number of waves of every group and whole chains of them (forced on 1536 ... 20 480 channels that do not divide the
+      // chip, paced chains lost 2 - 7 %: a chain's waves are then not resident together), the taps reach at least two runs back, and every wave has 16 runs or more to walk (the
       // leads a chain starts with are idle time: at 8 runs per wave the interleaved mapping was 1 % ahead); that mapping otherwise
-      const bool chains = gx % 8 == 0 && per_group >= 4 && per_group % W == 0 && sec.nb >= 2 * kRingR && Mc >= 16;
+      const bool chains = gx % 8 == 0 && (int64_t)ALZ_FIR_WAVES * 4 * cus % gx == 0 && per_group >= 4 && per_group % W == 0 &&
+                          sec.nb >= 2 * kRingR && Mc >= 16;
       map_sel = chains ? 4 : 1;
     }
     unsigned gyr;

@@ -335,6 +335,7 @@ def test_cfg3_fir256_full_extent_on_strided_channels(alz, oracle, bench, fused):
                                           (16384, 1 << 16, 256, "chains"),   # chains of 4: the chip holds 8 waves per group
                                           (32768, 49152, 200, "chains"),     # ... 4 per group: chains without pacing
                                           (8192, 90000, 256, "k_fir_ring"),  # fewer than 16 runs per wave: interleaved runs
+                                          (10240, 98304, 256, "k_fir_ring"),  # 12.8 waves of a group on the chip: chains would straddle
                                           (8192 + 64, 98304, 256, "k_fir_ring")])   # the XCD does not follow the channel group
 def test_fir_ring_chains_and_interleaved_runs(alz, oracle, C, N, nb, kernel):
   """k_fir_ring's run-to-wave mappings at the sizes that pick them (launch_fir): the waves of a channel group walk

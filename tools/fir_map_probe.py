@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CONFIGS = {
   "map1": {"ALZ_FIR_MAP": "1"},                                  # rounds 3 - 4: interleaved runs
   "auto": {},                                                    # what ships: launch_fir's choice of chain width and pacing
+  "forced": {"ALZ_FIR_MAP": "4"},                                # chains by launch_fir's width rule even where its gate says no
   "free": {"ALZ_FIR_MAP": "4", "ALZ_FIR_PACED": "0"},            # the chains' mapping without the pacing
   "w4": {"ALZ_FIR_MAP": "4", "ALZ_FIR_W": "4", "ALZ_FIR_PACED": "1"},   # chains of W waves, paced
   "w8": {"ALZ_FIR_MAP": "4", "ALZ_FIR_W": "8", "ALZ_FIR_PACED": "1"},
