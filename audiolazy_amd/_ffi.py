@@ -54,6 +54,9 @@ SIGNATURES = {
   "alz_bank_set_fused": (_int, [_vp, _int]),
   "alz_bank_set_time_parallel": (_int, [_vp, _i64]),
   "alz_bank_set_input_map": (_int, [_vp, _int]),
+  "alz_bank_set_look_check": (_int, [_vp, _int]),
+  "alz_bank_look_stats": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                 ctypes.POINTER(ctypes.c_uint)]),
   "alz_map_dev": (_int, [_int, _vp, _vp, ctypes.c_double, ctypes.c_double, _i64, _vp, _vp, _int, _vp]),
   "alz_bank_last_kernel": (ctypes.c_char_p, [_vp]),
   "alz_lpc_kautocor_dev": (_int, [_vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _int, _vp]),
@@ -74,6 +77,11 @@ SIGNATURES = {
   "alz_tv_process_dev": (_int, [_int, _vp, _int, _vp, _i64, _vp, _vp, _i64, _int, _i64, _i64, _vp, _vp,
                                 ctypes.c_double, _int, _vp]),
 }
+
+
+# wait sites of the one-pass time-parallel kernel (csrc/alz_look.hip W_*: bit k of alz_bank_look_stats' last_sites)
+LOOK_WAIT_SITES = ("?", "LOAD/stored", "HELP/prepared", "HELP/replayed", "HELP/state-read", "CHAIN/published-states",
+                   "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored")
 
 
 class TvTap(ctypes.Structure):

@@ -392,6 +392,26 @@ class FilterBank(object):
     self._time_parallel = n
     return self
 
+  def set_look_check(self, mode="call"):
+    """What happens when the one-pass form of the time-parallel mode gives up one of its bounded waits (its workgroups
+    wait for each other; foreign work on the device can keep some of them from starting) -- alz_bank_set_look_check.
+    ``"call"`` (default): :meth:`process` waits for its own work and, if the kernel gave up, puts the bank's state back
+    and processes the block again with the three-launch form (an in-place block raises instead: its input is gone).
+    ``"deferred"``: :meth:`process` stays asynchronous and the NEXT call on the bank raises."""
+    code = {"call": 1, "deferred": 0}[mode]
+    _ffi.check(self._L.alz_bank_set_look_check(self._h, code))
+    self._look_check = mode
+    return self
+
+  @property
+  def look_stats(self):
+    """Counters of the one-pass time-parallel kernel on this bank: launches, launches that gave up a wait, blocks
+    processed again because of that, names of the waits that ran out last (alz_bank_look_stats)."""
+    a, b, c, m = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_uint()
+    _ffi.check(self._L.alz_bank_look_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(m)))
+    return {"launches": a.value, "gave_up": b.value, "reruns": c.value,
+            "last_sites": [n for k, n in enumerate(_ffi.LOOK_WAIT_SITES) if m.value >> k & 1]}
+
   @property
   def last_kernel(self):
     return self._L.alz_bank_last_kernel(self._h).decode()
@@ -502,6 +522,8 @@ class FilterBank(object):
       twin.set_time_parallel(self._time_parallel)
     if self._input_map:
       twin.set_input_map(self._input_map)
+    if getattr(self, "_look_check", "call") != "call":
+      twin.set_look_check(self._look_check)
     return twin
 
   def _blocks(self, seq, block=None, post=None):

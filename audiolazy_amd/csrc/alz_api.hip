@@ -85,6 +85,14 @@ struct alz_bank {
   // section pipeline of narrow cascades (process_dev): one stream per section, events per (section, chunk)
   hipStream_t sec_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sec_events;
+  // the one-pass time-parallel kernel (alz_look.hip) and its bounded waits -- alz_bank_set_look_check
+  int look_check = ALZ_LOOK_CHECK_CALL;   // verify on the call that launched it (and re-run the block) / report at the next entry point
+  bool look_launched = false;             // this process call launched the one-pass kernel
+  bool no_one_pass = false;               // the re-run of a block on which it gave up: three-launch form
+  double *state_snap = nullptr;           // the bank's state before the call (xh_dev then yh_dev), for that re-run
+  uint64_t state_snap_bytes = 0;
+  int64_t look_launches = 0, look_gave_up = 0, look_reruns = 0;
+  unsigned look_last_sites = 0;           // bit W_*: the waits that ran out in the last launch that gave up
 };
 
 namespace {
@@ -117,6 +125,13 @@ void transpose_to_dev_order(const double *src, std::vector<double> &dst, int64_t
   dst.resize((size_t)(rows * cols));
   for (int64_t r = 0; r < rows; ++r)
     for (int64_t k = 0; k < cols; ++k) dst[(size_t)(k * rows + r)] = src[r * cols + k];
+}
+
+// two arrays in one small launch (the bank's state kept / put back around a one-pass time-parallel launch)
+__global__ __launch_bounds__(256) void k_state_copy(double *d1, const double *s1, int64_t n1, double *d2, const double *s2, int64_t n2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n1) d1[i] = s1[i];
+  else if (i - n1 < n2) d2[i - n1] = s2[i - n1];
 }
 
 }  // namespace
@@ -337,6 +352,7 @@ int alz_bank_destroy(alz_bank_t *h) {
   if (h->scratch) (void)hipFree(h->scratch);
   if (h->map_in) (void)hipFree(h->map_in);
   if (h->expand_in) (void)hipFree(h->expand_in);
+  if (h->state_snap) (void)hipFree(h->state_snap);
   for (alz::FirChains &fc : h->fir_chains)
     if (fc.flags) (void)hipFree(fc.flags);
   for (hipStream_t st : h->host_streams)
@@ -419,19 +435,36 @@ int alz_bank_set_state(alz_bank_t *h, const double *xh_host, const double *yh_ho
 // The one-pass time-parallel kernel (alz_look.hip) reports a wait that ran out in a word of pinned host memory per
 // section.  Every entry point that hands results to the caller looks at it -- after its synchronisation where it has
 // one -- so a bad block is never delivered silently (round-3 review: only the NEXT one-pass call used to look).
-static int take_look_error(alz_bank_t *h) {
-  bool bad = false;
+static unsigned take_look_sites(alz_bank_t *h) {
+  unsigned sites = 0;
   for (alz::ScanScratch &sc : h->scan)
-    if (sc.look_err && *(volatile int *)sc.look_err != 0) {
-      *sc.look_err = 0;
-      bad = true;
-    }
+    if (sc.look_err)
+      for (int k = 0; k < alz::kLookErrWords; ++k)
+        if (((volatile int *)sc.look_err)[k] != 0) {
+          sc.look_err[k] = 0;
+          sites |= 1u << k;
+        }
+  if (sites) {
+    h->look_gave_up += 1;
+    h->look_last_sites = sites;
+  }
+  return sites;
+}
+static std::string look_site_names(unsigned sites) {
+  std::string out;
+  for (int k = 0; k < alz::kLookErrWords; ++k)
+    if (sites >> k & 1u) out += (out.empty() ? "" : ", ") + std::string(alz::look_wait_name(k));
+  return out;
+}
+static int take_look_error(alz_bank_t *h) {
+  const unsigned sites = take_look_sites(h);
   // (the kernel had advanced the bank's state by then: the block cannot simply be processed again)
-  return bad ? fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel of an EARLIER process call on this bank gave up "
-                               "waiting for another workgroup: the block that call wrote and the bank's state are invalid, "
-                               "and the call that reports this has processed nothing -- reset() or set_state() the bank, "
-                               "then process from the last good block again")
-             : ALZ_OK;
+  return sites ? fail(ALZ_E_HIP, "time-parallel mode: the one-pass kernel of an EARLIER process call on this bank gave up "
+                                 "waiting for another workgroup (waits that ran out: " + look_site_names(sites) + "): the block "
+                                 "that call wrote and the bank's state are invalid, "
+                                 "and the call that reports this has processed nothing -- reset() or set_state() the bank, "
+                                 "then process from the last good block again")
+               : ALZ_OK;
 }
 
 int alz_bank_get_state(alz_bank_t *h, double *xh_host, double *yh_host) {
@@ -464,7 +497,49 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
 
 int alz_bank_process_dev(alz_bank_t *h, const double *x_dev, double *y_dev, int64_t n, int layout,
                          int64_t ldx, int64_t ldy, void *stream) {
-  const int rc = process_dev_impl(h, x_dev, y_dev, n, layout, ldx, ldy, stream);
+  // The one-pass time-parallel kernel (alz_look.hip) is the one kernel of the library whose workgroups wait for each
+  // other; its waits are bounded, and a launch that gave up (its workgroups were not all resident in time: foreign work
+  // on the device) has written a bad block and a bad state.  ALZ_LOOK_CHECK_CALL (default): this call notices -- it keeps
+  // a copy of the bank's state, waits for its own work on `stream`, and on a give-up restores the state and processes the
+  // block again with the three-launch form of the same mode (same numerics), so the caller never sees it; an in-place
+  // block cannot be processed again (its input is gone): the call FAILS, with the state as it was before the call.
+  bool snap = false;
+  int64_t nx = 0, ny = 0;
+  if (h && h->look_check == ALZ_LOOK_CHECK_CALL && (h->time_parallel == ALZ_TP_AUTO || h->time_parallel == ALZ_TP_ONE_PASS) &&
+      x_dev && y_dev && n >= 4 * alz::kLookChunk && h->channels % 16 == 0) {
+    DeviceGuard g(h->device);
+    nx = (h->thx > 0 ? h->thx : 1) * h->channels * 2;
+    ny = (h->thy > 0 ? h->thy : 1) * h->channels * 2;
+    if (g.ok && grow(&h->state_snap, &h->state_snap_bytes, (uint64_t)(nx + ny) * 8) == ALZ_OK) {
+      hipLaunchKernelGGL(k_state_copy, dim3((unsigned)((nx + ny + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->state_snap,
+                         h->xh_dev, nx, h->state_snap + nx, h->yh_dev, ny);
+      snap = hipGetLastError() == hipSuccess;
+    }
+  }
+  if (h) h->look_launched = false;
+  int rc = process_dev_impl(h, x_dev, y_dev, n, layout, ldx, ldy, stream);
+  if (rc == ALZ_OK && h->look_launched && h->look_check == ALZ_LOOK_CHECK_CALL) {
+    DeviceGuard g(h->device);
+    ALZ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const unsigned sites = take_look_sites(h);
+    if (sites) {
+      const std::string what = "time-parallel mode: the one-pass kernel gave up waiting for another workgroup (waits that ran out: " +
+                               look_site_names(sites) + ")";
+      if (!snap) return fail(ALZ_E_HIP, what + " and no copy of the bank's state could be kept: the block and the bank's state are invalid");
+      hipLaunchKernelGGL(k_state_copy, dim3((unsigned)((nx + ny + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->xh_dev,
+                         h->state_snap, nx, h->yh_dev, h->state_snap + nx, ny);
+      ALZ_HIP_CHECK(hipGetLastError());
+      if (x_dev == y_dev)
+        return fail(ALZ_E_HIP, what + " on an IN-PLACE block: its contents are invalid and its input is gone; the bank's state is "
+                               "what it was before this call -- process the block again from a copy of its input");
+      const std::string first = h->last_kernels;
+      h->no_one_pass = true;
+      rc = process_dev_impl(h, x_dev, y_dev, n, layout, ldx, ldy, stream);
+      h->no_one_pass = false;
+      h->look_reruns += 1;
+      h->last_kernels = first + "  [gave up: " + look_site_names(sites) + "; block processed again:] " + h->last_kernels;
+    }
+  }
   // two samples through every section make each section's input history its predecessor's output history
   if (rc == ALZ_OK && h && n >= 2) h->state_consistent = true;
   return rc;
@@ -488,6 +563,8 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
   DeviceGuard g(h->device);
   if (!g.ok) return fail(ALZ_E_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
+  // (the re-run of a block on which the one-pass kernel gave up: the same mode without that form)
+  const int64_t tp_mode = (h->no_one_pass && h->time_parallel < 0) ? alz::kTpThreeLaunch : h->time_parallel;
 
   // the elementwise input stage: |x| rides on the section's own input reads where the kernels can
   // do that for free (one biquad-class section, the streaming kernels and k_small); anything else
@@ -509,7 +586,7 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
       probe.syn = layout == ALZ_TIME_MAJOR ? ldy : 1; probe.syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
       probe.map_input = (h->mode == ALZ_BANK_OUTER && (h->n_inputs % 64) == 0) ? 1 : 0;
       probe.c_first = 0; probe.c_count = h->channels;
-      fusable = h->mode != ALZ_BANK_OUTER && alz::scan_takes_one_pass(s0, probe, h->time_parallel);
+      fusable = h->mode != ALZ_BANK_OUTER && alz::scan_takes_one_pass(s0, probe, tp_mode);
     }
     if (fusable) {
       pre_fused = ALZ_MAP_ABS;
@@ -637,10 +714,14 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
       if (h->time_parallel != 0 && whole && !generic) {
         // opt-in time-parallel mode: whole chunks of the whole bank; the ragged rest continues
         // serially from the state the replay pass left
-        rc = alz::launch_scan(sec, s, io, st, h->time_parallel, &h->scan[(size_t)s],
+        rc = alz::launch_scan(sec, s, io, st, tp_mode, &h->scan[(size_t)s],
                               &done_n, &name);
         if (rc) return rc;
         if (done_n > 0) done_c = c_count;
+        if (done_n > 0 && strcmp(name, "k_scan(k_look)") == 0) {
+          h->look_launched = true;
+          h->look_launches += 1;
+        }
       }
       if (done_c == 0 && !generic && whole) rc = alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
       if (rc) return rc;
@@ -920,6 +1001,22 @@ int alz_bank_sync(alz_bank_t *h) {
   DeviceGuard g(h->device);
   ALZ_HIP_CHECK(hipDeviceSynchronize());
   return take_look_error(h);
+}
+
+int alz_bank_set_look_check(alz_bank_t *h, int mode) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  if (mode != ALZ_LOOK_CHECK_CALL && mode != ALZ_LOOK_CHECK_DEFERRED) return fail(ALZ_E_ARG, "mode must be ALZ_LOOK_CHECK_CALL or ALZ_LOOK_CHECK_DEFERRED");
+  h->look_check = mode;
+  return ALZ_OK;
+}
+
+int alz_bank_look_stats(const alz_bank_t *h, int64_t *launches, int64_t *gave_up, int64_t *reruns, unsigned *last_sites) {
+  if (!h) return fail(ALZ_E_ARG, "NULL handle");
+  if (launches) *launches = h->look_launches;
+  if (gave_up) *gave_up = h->look_gave_up;
+  if (reruns) *reruns = h->look_reruns;
+  if (last_sites) *last_sites = h->look_last_sites;
+  return ALZ_OK;
 }
 
 const char *alz_bank_last_kernel(const alz_bank_t *h) { return h ? h->last_kernels.c_str() : ""; }

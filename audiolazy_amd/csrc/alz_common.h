@@ -157,7 +157,8 @@ struct ScanScratch {                 // owned by the bank handle, grown on deman
   int64_t tab_len = 0;               // chunk length the tables belong to (0: none)
   double *zbuf = nullptr;            // k_look: published chunk end states
   uint64_t zbuf_bytes = 0;
-  int *look_err = nullptr;           // k_look: one word of pinned host memory the kernel sets if a bounded wait ran out
+  int *look_err = nullptr;           // k_look: kLookErrWords words of pinned host memory, one per wait site (alz_look.hip W_*): the kernel
+                                     // sets the word of a bounded wait that ran out
 };
 // alz_tvduo.hip: time-varying biquad-class filter with bank-wide coefficient series, streaming kernel (recurrence, feed-forward and store waves)
 int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy, int cm, int64_t channels, int nb, int na,
@@ -179,6 +180,11 @@ int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int6
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name);
 constexpr int64_t kLookChunk = 512;
+constexpr int kLookErrWords = 16;
+constexpr int64_t kTpThreeLaunch = -3;   // internal chunk_len value: the engine's chunk length, never the one-pass form (the re-run of a block
+                                         // on which the one-pass kernel gave up)
+// names of the wait sites, for messages (index = word of look_err)
+const char *look_wait_name(int site);
 // whether launch_look would take this section and block (shape only; `cus` = the device's CU count)
 bool look_takes(const SectionDev &sec, const BlockIO &io, int cus);
 // whether launch_scan would send this section and block to the one-pass form for the handle's chunk-length setting
@@ -201,11 +207,13 @@ __device__ __forceinline__ void publish(int *flag, int value, int lane) {
   if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void await(const int *flag, int need, int &cap, int *err) {
+// `site`: which wait this is (alz_look.hip's W_* codes) -- a wait that runs out sets err[site], so the host can say which
+// of the protocol's dependencies did not arrive
+__device__ __forceinline__ void await(const int *flag, int need, int &cap, int *err, int site = 0) {
   int spins = 0;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > cap) { if (err) *err = 1; cap = 0; break; }      // (cannot happen: every wait points to earlier work; a wave
+    if (++spins > cap) { if (err) err[site] = 1; cap = 0; break; }   // (cannot happen: every wait points to earlier work; a wave
   }                                                        //  that gave up once no longer waits at all)
   asm volatile("" ::: "memory");
 }

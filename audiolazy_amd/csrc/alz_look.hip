@@ -78,7 +78,7 @@ constexpr int kNT = 8;                       // tiles per chunk (L = 512)
 constexpr int kSlots = ALZ_LOOK_SLOTS;       // tile slots in LDS
 constexpr int kSlot = 8192 + kChunks * 16;   // a tile in the DMA layout (16 bytes of pad per 1 KiB chunk)
 constexpr int kHist = 256;                   // the two rows before a tile: [2][16] doubles
-constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (hipMemset 0xFF)
+constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (k_look_prep)
 constexpr int kMaxW = 16;                    // workgroups per channel group (the predecessors' states live in registers)
 #ifdef ALZ_ABLATE
 #define ALZ_LOOK_CAP(p) ((p).dbg ? 1 : kSpinCap)      // (an ablated run publishes nothing: do not wait for it)
@@ -101,10 +101,12 @@ struct LArgs {
   unsigned long long *z;       // [groups][n_chunks][2][16] published zero-state end states
   const double *hsave;         // in place: the two input rows in front of every chunk, [groups][n_chunks][32] in the
                                // history transfer's own order (time-major [2][16], channel-major [16][2]); else nullptr
-  int *err;                    // set when a spin ran into its cap
+  int *err;                    // [kLookErrWords] of pinned host memory: word W_* set when that wait ran into its cap
   int dbg;                     // -DALZ_ABLATE builds only (timing experiments, WRONG output): 2 no replay arithmetic,
                                // 4 no feed-forward pass, 8 no stores, 16 no tile DMA, 32 no chunk-state chain,
-                               // 64 no zero-state sums; with -DALZ_LOOK_TIMING 256 / 512 print the replay / the other waves' cycle counts
+                               // 64 no zero-state sums; with -DALZ_LOOK_TIMING 256 / 512 print the replay / the other waves' cycle counts;
+                               // 1024 the workgroups of chunk 0 start ~40 us late, 2048 the input history is written as soon as the last
+                               // tile lands (round 5's order) -- together they show the race of NOTES_r06.md 1 on every launch
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -248,7 +250,11 @@ __device__ __forceinline__ double sum_rows(double x) {
   return __hiloint2double((int)b1[0], (int)b0[0]) + __hiloint2double((int)b1[1], (int)b0[1]);
 }
 
-enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_ZDONE, F_COUNT = 8 };
+enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_ZDONE, F_INIT, F_COUNT = 8 };
+// Which bounded wait ran out (word of LArgs::err; launch_look's caller reads them all): wave / what it waited for.
+enum { W_ANY = 0, W_LOAD_STORED, W_HELP_PREPARED, W_HELP_REPLAYED, W_HELP_INIT, W_CHAIN_Z, W_CHAIN_REPLAYED, W_CHAIN_ZDONE,
+       W_CHAIN_PREPARED, W_REPLAY_CHUNK, W_LOAD_FINAL, W_COUNT };
+static_assert(W_COUNT <= kLookErrWords, "one word of pinned host memory per wait site");
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -318,6 +324,12 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
   if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0;
   __syncthreads();
+#if defined(ALZ_ABLATE)
+  if (ALZ_DBG(p, 1024) && w == 0) {                          // (a late start of chunk 0's workgroups, as a slow XCD would give)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 4000) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 
   if (wave == 1) {
     // ------------------------------ LOAD ------------------------------
@@ -400,8 +412,20 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) *reinterpret_cast<double *>(ps + (4 * j + q) * kStep) = acc[j];
     };
-    // the input history the bank keeps for the next block: the last two x rows of the block (owner of the last chunk)
+    // The input history the bank keeps for the next block: the last two x rows of the block (owner of the last chunk).
+    // They are picked up when the last tile lands and WRITTEN ONLY AFTER THE LOOP: the workgroup of chunk 0 reads the
+    // same words (hh1, hh2) when it starts, and nothing orders the start of one workgroup against the progress of
+    // another's LOAD wave -- with one or two chunks per workgroup this wave reaches its last tile without waiting for
+    // anybody (round 6: the race behind the one wrong block of round 5, profiles/NOTES_r06.md 1).  After the loop every
+    // tile of this workgroup has been stored, hence replayed, hence chained from z_0, which chunk 0's workgroup
+    // published after it had prepared -- i.e. after it had read its history.
     const bool owns_last = ((K - 1) % W) == w;
+    double keep_x1 = 0.0, keep_x2 = 0.0;
+#if defined(ALZ_ABLATE)
+    const bool early_state = ALZ_DBG(p, 2048);               // (the round-5 order, for the demonstration of the race)
+#else
+    constexpr bool early_state = false;
+#endif
     for (int t = 0; t < kDmaLead && t < TOT; ++t) queue_tile(t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     prepare_tile(0);
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       {
         int need = i + kDmaLead - kSlots + 1;
         need = need > TOT ? TOT : need;
-        if (need > 0) await(flags + F_STORED, need, cap, p.err);
+        if (need > 0) await(flags + F_STORED, need, cap, p.err, W_LOAD_STORED);
       }
       ALZ_LOOK_MARK(0)
       if (i + kDmaLead < TOT && !ALZ_DBG(p, 16)) queue_tile(i + kDmaLead);
@@ -425,8 +449,12 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       if (i + 1 < TOT) {
         if (owns_last && i + 1 == TOT - 1 && q == 3) {        // (before the tile is overwritten with p)
           const char *xs = smem + ((i + 1) % kSlots) * kSlot + xlane_off;
-          if (p.nb > 1) p.xh[0 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
-          if (p.nb > 2) p.xh[1 * p.channels + c] = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
+          keep_x1 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 1)));
+          keep_x2 = look_pre<PRE>(*reinterpret_cast<const double *>(xs + ALZ_EOFF(T - 2)));
+          if (early_state) {
+            if (p.nb > 1) p.xh[0 * p.channels + c] = keep_x1;
+            if (p.nb > 2) p.xh[1 * p.channels + c] = keep_x2;
+          }
         }
         ALZ_LOOK_MARK(2)
         if (!ALZ_DBG(p, 4)) prepare_tile(i + 1);
@@ -440,6 +468,11 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
              (double)cyc[0] / n_iv, (double)cyc[1] / n_iv, (double)cyc[2] / n_iv, (double)cyc[3] / n_iv);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    await(flags + F_STORED, TOT, cap, p.err, W_LOAD_FINAL);  // (the loop's last iteration has waited for this already)
+    if (owns_last && q == 3 && !early_state) {
+      if (p.nb > 1) p.xh[0 * p.channels + c] = keep_x1;
+      if (p.nb > 2) p.xh[1 * p.channels + c] = keep_x2;
+    }
   } else if (wave == 2) {
     // ------------------------------ HELP ------------------------------
     const int row = lane / 8, cp = lane % 8;
@@ -476,9 +509,9 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       const bool zs_on = i < TOT && !ALZ_DBG(p, 64);
       const int ts = i - kStoreBehind;
       const bool st_on = ts >= 0 && ts < TOT;
-      if (i < TOT) await(flags + F_PREPARED, i + 1, cap, p.err);
+      if (i < TOT) await(flags + F_PREPARED, i + 1, cap, p.err, W_HELP_PREPARED);
       ALZ_LOOK_MARK(1)
-      if (st_on) await(flags + F_REPLAYED, ts + 1, cap, p.err);
+      if (st_on) await(flags + F_REPLAYED, ts + 1, cap, p.err, W_HELP_REPLAYED);
       ALZ_LOOK_MARK(5)
       double zp[16];
       if (zs_on) {
@@ -519,6 +552,9 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         const double c2 = __builtin_fma(M21, Z1, __builtin_fma(M22, Z2, z2));
         Z1 = tt == 0 ? z1 : c1;
         Z2 = tt == 0 ? z2 : c2;
+        // (the first state goes out only once this workgroup's CHAIN wave has read the bank's state: the owner of the last
+        // chunk overwrites that state when everything before it -- every workgroup's first chunk included -- is done)
+        if (i == NT - 1) await(flags + F_INIT, 1, cap, p.err, W_HELP_INIT);
         if (tt == NT - 1 && q == 0) {
           const int64_t j = (int64_t)w + (int64_t)(i / NT) * W;
           __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(Z1), __ATOMIC_RELAXED,
@@ -545,6 +581,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
     double S1 = (p.na > 1) ? p.yh[0 * p.channels + c] : 0.0;
     double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
     asm volatile("" : "+v"(S1), "+v"(S2));
+    publish(flags + F_INIT, 1, lane);                          // (the state words are in registers)
     for (int seq = 0; seq < my_chunks; ++seq) {
       if ((seq > 0 || w > 0) && !ALZ_DBG(p, 32)) {
         const int64_t cj = (int64_t)w + (int64_t)seq * W;
@@ -573,7 +610,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
           }
           if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
           if (++tries > ALZ_LOOK_CAP(p)) {                   // (cannot happen: the states come from earlier chunks)
-            *p.err = 1;
+            p.err[W_CHAIN_Z] = 1;
 #pragma unroll
             for (int e = 0; e < kMaxW; ++e) {
               if (a1[e] == kSentinel) a1[e] = 0;
@@ -594,7 +631,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         }
       }
       // the buffer of this parity held the state of chunk number seq - 2: the replay has read it
-      if (seq >= 2) await(flags + F_REPLAYED, NT * (seq - 2) + 1, cap, p.err);
+      if (seq >= 2) await(flags + F_REPLAYED, NT * (seq - 2) + 1, cap, p.err, W_CHAIN_REPLAYED);
       if (q == 0) {
         *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + cl * 8) = S1;
         *reinterpret_cast<double *>(sbuf + (seq & 1) * 256 + 128 + cl * 8) = S2;
@@ -603,8 +640,8 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       // former, LOAD prepared the latter
       {
         const int zneed = NT * seq + NT, pneed = NT * seq + NT + 2;
-        await(flags + F_ZDONE, zneed > TOT ? TOT : zneed, cap, p.err);
-        await(flags + F_PREPARED, pneed > TOT ? TOT : pneed, cap, p.err);
+        await(flags + F_ZDONE, zneed > TOT ? TOT : zneed, cap, p.err, W_CHAIN_ZDONE);
+        await(flags + F_PREPARED, pneed > TOT ? TOT : pneed, cap, p.err, W_CHAIN_PREPARED);
       }
       publish(flags + F_CHUNK, seq + 1, lane);
     }
@@ -614,7 +651,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
     LookState st = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double pr[4][8];
     ALZ_LOOK_CLOCK(3)                                          // tile / tail / chunk wait
-    await(flags + F_CHUNK, 1, cap, p.err);
+    await(flags + F_CHUNK, 1, cap, p.err, W_REPLAY_CHUNK);
     {
       const char *cur = smem + lane_off - q * kStep;         // tile 0: groups 0 and 1 of the register ring
 #pragma unroll
@@ -629,7 +666,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
       const int sn = (sr + 1 == kSlots) ? 0 : sr + 1;
       const char *nxt = (t + 1 < TOT) ? smem + sn * kSlot + lane_off - q * kStep : cur;
       if (tic == 0) {
-        if (t > 0) await(flags + F_CHUNK, seq + 1, cap, p.err);
+        if (t > 0) await(flags + F_CHUNK, seq + 1, cap, p.err, W_REPLAY_CHUNK);
         ALZ_LOOK_MARK(2)
         if (!ALZ_DBG(p, 2)) {
           const double s1 = *reinterpret_cast<const double *>(sbuf + (seq & 1) * 256 + cl * 8);
@@ -662,6 +699,12 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 #undef ALZ_LOOK_CLOCK
 #undef ALZ_LOOK_MARK
 
+const char *look_wait_name(int site) {
+  static const char *const names[W_COUNT] = {"?", "LOAD/stored", "HELP/prepared", "HELP/replayed", "HELP/state-read", "CHAIN/published-states",
+                                             "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored"};
+  return site >= 0 && site < W_COUNT ? names[site] : "?";
+}
+
 typedef void (*look_fn)(LArgs);
 template <bool CM, int PRE>
 static look_fn pick_look_in(unsigned pb, unsigned pa) {
@@ -676,10 +719,15 @@ static look_fn pick_look(unsigned pb, unsigned pa, bool cm, int pre) {
   return nullptr;
 }
 
-// in place: the two input rows in front of every chunk, saved before any workgroup overwrites them (LArgs::hsave)
-__global__ __launch_bounds__(256) void k_look_hsave(const double *x, int64_t ldx, int cm, int64_t groups, int64_t K, double *hsave) {
+// What a launch needs set up, in one small launch in front of it: the published-state array filled with the "not yet
+// published" pattern and, in place (hsave != nullptr), the two input rows in front of every chunk saved before any
+// workgroup overwrites them (LArgs::hsave).  (Round 5: a hipMemsetAsync and a k_look_hsave launch.)
+__global__ __launch_bounds__(256) void k_look_prep(unsigned long long *z, const double *x, int64_t ldx, int cm, int64_t groups, int64_t K,
+                                                   double *hsave) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= groups * K * 32) return;
+  z[i] = kSentinel;
+  if (!hsave) return;
   const int64_t gk = i >> 5, g = gk / K, j = gk - g * K;
   const int e = (int)(i & 31);
   if (j == 0) return;                                   // (chunk 0 starts from the bank's own history)
@@ -780,10 +828,8 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
     }
   }
   if ((int64_t)per_cu * cus < groups * W) return ALZ_OK;     // (not co-resident: the three-launch form takes the block)
-  if (inplace)
-    hipLaunchKernelGGL(k_look_hsave, dim3((unsigned)((zdoubles + 255) / 256)), dim3(256), 0, stream, io.x, p.ldx, cm ? 1 : 0, groups, K,
-                       zbuf + zdoubles);
-  ALZ_HIP_CHECK(hipMemsetAsync(zbuf, 0xFF, (size_t)zdoubles * sizeof(double), stream));
+  hipLaunchKernelGGL(k_look_prep, dim3((unsigned)((zdoubles + 255) / 256)), dim3(256), 0, stream, (unsigned long long *)zbuf, io.x, p.ldx,
+                     cm ? 1 : 0, groups, K, inplace ? zbuf + zdoubles : (double *)nullptr);
   void *args[] = {(void *)&p};
   if (ALZ_TUNE("ALZ_LOOK_COOP", 1) == 0) {       // (tuning builds: the plain launch of round 3, for A/B timing)
     hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);

@@ -150,7 +150,7 @@ bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk
   if (io.c_first != 0 || io.c_count != io.channels || io.channels % 16) return false;
   if (io.n < 4 * kLookChunk) return false;
   const int cus = device_cus();
-  bool one_pass = chunk_len == ALZ_TP_ONE_PASS;
+  bool one_pass = chunk_len == ALZ_TP_ONE_PASS;          // (kTpThreeLaunch: the engine's chunk length, never this form)
   if (chunk_len == ALZ_TP_AUTO) {
     const int64_t groups = io.channels / 16, Kl = io.n / kLookChunk;
     int64_t wk = groups > 0 ? cus / groups : 0;
@@ -177,7 +177,7 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
     if (!scratch->look_err) {
       if (hipHostMalloc((void **)&scratch->look_err, 64, hipHostMallocDefault) != hipSuccess)
         return fail(ALZ_E_NOMEM, "hipHostMalloc failed (time-parallel scratch)");
-      *scratch->look_err = 0;
+      for (int k = 0; k < kLookErrWords; ++k) scratch->look_err[k] = 0;
     }
     const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) * (io.x == io.y ? 2 : 1);   // (+ the saved history rows of an in-place run)
     uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;

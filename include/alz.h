@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALZ_VERSION 311 /* 0.3.2: time-parallel mode for time-major cascades, one-pass form in both layouts / in place / with the |x| map (same entry points); 0.3.1: + alz_lag_matrix_dev; 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
+#define ALZ_VERSION 320 /* 0.4.0: + alz_bank_set_look_check, alz_bank_look_stats (the one-pass time-parallel kernel verified on the call that launched it); 0.3.2: time-parallel mode for time-major cascades, one-pass form in both layouts / in place / with the |x| map (same entry points); 0.3.1: + alz_lag_matrix_dev; 0.3.0: + alz_comm_* (direct RCCL), one-launch ALZ_LPC_DENSE, any LPC order; 0.2.1: + alz_levinson_dev_ex, ALZ_LPC_DENSE (0.2.0: alz_map_dev, alz_bank_set_input_map, alz_bank_set_time_parallel, alz_lpc_kautocor_dev_ex) */
 
 /* status codes; the Python shim re-raises the reference's exception types */
 #define ALZ_OK 0
@@ -153,6 +153,26 @@ int alz_bank_set_fused(alz_bank_t *h, int on);
 #define ALZ_TP_AUTO (-1)
 #define ALZ_TP_ONE_PASS (-2)
 int alz_bank_set_time_parallel(alz_bank_t *h, int64_t chunk_len);
+/* The one-pass form is the one kernel of the library whose workgroups wait for each other (chunk states travel from
+ * workgroup to workgroup while the block is in flight); it is launched cooperatively -- all its workgroups fit on the
+ * device at once -- but foreign work holding compute units can still keep some of them from starting, so its waits are
+ * BOUNDED and a launch can give up (having written a bad block and a bad bank state).  What the handle does then:
+ *   ALZ_LOOK_CHECK_CALL (default): the process call that launched the kernel keeps a copy of the bank's state
+ *     (one small launch), waits for its own work on `stream`, and if the kernel gave up puts the state back and
+ *     processes the block again with the three-launch form of the same mode (same numerics): the caller never sees
+ *     it (alz_bank_last_kernel shows it, alz_bank_look_stats counts it).  An IN-PLACE block cannot be processed
+ *     again -- that call fails with ALZ_E_HIP, the bank's state as before the call.  Costs the call its asynchrony.
+ *   ALZ_LOOK_CHECK_DEFERRED: the call stays asynchronous; a give-up is reported (ALZ_E_HIP, naming the waits that
+ *     ran out) by the NEXT entry point of the handle that hands results over or takes a block (process, sync,
+ *     get_state), and the bank must be reset / set_state'd by the caller.
+ * No reference counterpart (the reference is one serial generator per channel, lazy_filters.py:251-257).            */
+#define ALZ_LOOK_CHECK_DEFERRED 0
+#define ALZ_LOOK_CHECK_CALL 1
+int alz_bank_set_look_check(alz_bank_t *h, int mode);
+/* Counters of the one-pass kernel on this handle since it was created: launches, launches that gave up, blocks
+ * processed again because of that, and the waits that ran out in the last such launch (bit k = wait site k of
+ * csrc/alz_look.hip's W_* list).  Any pointer may be NULL.  Diagnostic (tests/test_gpu_look_soak.py).             */
+int alz_bank_look_stats(const alz_bank_t *h, int64_t *launches, int64_t *gave_up, int64_t *reruns, unsigned *last_sites);
 
 /* Name of the kernel variant the last process call dispatched to (diagnostic;
  * tests use it to prove the fast paths are the ones exercised).              */

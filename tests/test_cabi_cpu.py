@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
   for name in syms:
     assert hasattr(lib, name), "libalzhip.so does not export %s" % name
   assert sorted(_ffi.SIGNATURES) == syms
-  assert lib.alz_version() == 311
+  assert lib.alz_version() == 320
 
 
 def test_status_codes_map_to_reference_exceptions():

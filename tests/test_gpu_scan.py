@@ -216,38 +216,26 @@ def test_one_pass_layouts_maps_in_place(alz, oracle, layout, mode, C, n, pattern
   bank.reset()
   xin = np.concatenate([x1, x2], axis=ax)
   ref = oracle.bank([nb], [na], b, a, np.abs(xin) if "abs" in mode else xin, layout=layout)
-  # The one-pass kernel's contract is "correct, or the NEXT entry point on the handle raises" (a workgroup that started
-  # later than the spin cap allows; tests/...::test_one_pass_beside_foreign_work_is_correct_or_raises).  So every block is
-  # followed by an entry point (get_state) before its result is judged, and a stream on which the kernel reported a
-  # timed-out wait is run again from reset -- a WRONG result without that report still fails here.  (Seen once in ~1000
-  # runs of these cases, call 16 of round 5: profiles/NOTES_r05.md 8.)
-  for attempt in range(3):
-    bank.reset()
-    at, gave_up, outs = 0, False, []
-    for x in (x1, x2):
-      xd = torch.from_numpy(x).cuda()
-      y = bank.process(xd, layout=layout, out=xd if "inplace" in mode else None)
-      kernels = bank.last_kernel
-      try:
-        bank.get_state()
-      except RuntimeError as exc:
-        assert "gave up waiting" in str(exc), exc
-        gave_up = True
-        break
-      assert "k_look" in kernels, kernels
-      if "abs" in mode:
-        assert "k_map" not in kernels, kernels      # no separate pass over the block
-      if "inplace" in mode:
-        assert y.data_ptr() == xd.data_ptr()
-      outs.append(y.cpu().numpy())
-    if not gave_up:
-      break
-  assert not gave_up, "the one-pass kernel reported a timed-out wait three times in a row"
-  for y, x in zip(outs, (x1, x2)):
+  # Round 6: the process call that launches the one-pass kernel verifies it (ALZ_LOOK_CHECK_CALL, the default) -- the
+  # block a call returns is good, or the call raises.  No retries here: on an otherwise idle GPU a give-up is a failure
+  # (round 5 re-ran such streams; the wrong block it had seen once was a race on the bank's input history between
+  # workgroups of launches with one chunk per workgroup -- this test's second block --, profiles/NOTES_r06.md 1).
+  at = 0
+  for x in (x1, x2):
+    xd = torch.from_numpy(x).cuda()
+    y = bank.process(xd, layout=layout, out=xd if "inplace" in mode else None)
+    kernels = bank.last_kernel
+    assert "k_look" in kernels and "gave up" not in kernels, kernels
+    if "abs" in mode:
+      assert "k_map" not in kernels, kernels      # no separate pass over the block
+    if "inplace" in mode:
+      assert y.data_ptr() == xd.data_ptr()
     m = x.shape[ax]
     want = ref[at:at + m] if tm else ref[:, at:at + m]
-    assert norm_err(y, want, ax) <= 1e-8, (layout, mode)
+    assert norm_err(y.cpu().numpy(), want, ax) <= 1e-8, (layout, mode)
     at += m
+  st = bank.look_stats
+  assert st["launches"] == 2 and st["gave_up"] == 0 and st["reruns"] == 0, st
 
 
 def test_one_pass_is_deterministic_and_agrees_with_three_launches(alz):
@@ -291,8 +279,9 @@ def test_one_pass_beside_foreign_work_is_correct_or_raises(alz, oracle, hold_ms,
   """The one-pass kernel needs all its workgroups resident at once (137 KiB of LDS each, one per CU).  While a kernel on
   ANOTHER stream holds half the CUs with 110 KiB of LDS per workgroup, half of k_look's workgroups cannot start: its
   resident workgroups wait for them.  A short hold only delays the block (it must still be correct); a hold beyond the
-  kernel's bounded waits makes it give up -- and then the handle must SAY so at the next synchronisation point
-  (alz_bank_sync -> RuntimeError), never hand over a silently bad block (round-3 review, weak #3)."""
+  kernel's bounded waits makes it give up.  In the DEFERRED check mode (asynchronous calls) the handle must then SAY so
+  at the next synchronisation point (alz_bank_sync -> RuntimeError, naming the waits that ran out), never hand over a
+  silently bad block (round-3 review, weak #3)."""
   import torch
   C, n = 512, 1 << 16
   b, a = resonators(C)
@@ -300,7 +289,7 @@ def test_one_pass_beside_foreign_work_is_correct_or_raises(alz, oracle, hold_ms,
   x = rng.uniform(-1, 1, (n, C))
   ref = oracle.bank([3], [3], b, a, x, layout="time")
   xd = torch.from_numpy(x).cuda()
-  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass").set_look_check("deferred")
   bank.reset()
   y = bank.process(xd, layout="time")                      # a first, undisturbed block (module load, scratch)
   bank.sync()
@@ -314,7 +303,8 @@ def test_one_pass_beside_foreign_work_is_correct_or_raises(alz, oracle, hold_ms,
     bank.sync()
   except RuntimeError as exc:
     raised = True
-    assert "one-pass" in str(exc) or "time-parallel" in str(exc), str(exc)
+    assert ("one-pass" in str(exc) or "time-parallel" in str(exc)) and "waits that ran out: " in str(exc), str(exc)
+    assert bank.look_stats["gave_up"] == 1 and bank.look_stats["last_sites"], bank.look_stats
   torch.cuda.synchronize()
   if not raised:
     assert norm_err(y.cpu().numpy(), ref, 0) <= 1e-8       # no error reported: the block must be right
@@ -325,3 +315,48 @@ def test_one_pass_beside_foreign_work_is_correct_or_raises(alz, oracle, hold_ms,
   y = bank.process(xd, layout="time")
   bank.sync()
   assert norm_err(y.cpu().numpy(), ref, 0) <= 1e-8
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+def test_one_pass_gives_up_and_the_call_processes_the_block_again(alz, oracle, layout):
+  """Round 6 (ALZ_LOOK_CHECK_CALL, the default): the process call that launched the one-pass kernel waits for it; when
+  the kernel gave up a wait (here: another stream holds half the CUs for 1.5 s, beyond the kernel's bounded waits), the
+  call puts the bank's state back and processes the block again with the three-launch form -- the caller gets a GOOD
+  block from the call that produced it, and the bank continues correctly with the next block.  In place the input is
+  gone: that call raises, the state is what it was before it, and the block can be processed again from a copy."""
+  import torch
+  C, n = 512, 1 << 15
+  tm = layout == "time"
+  ax = 0 if tm else 1
+  b, a = resonators(C)
+  rng = np.random.default_rng(78)
+  xs = [rng.uniform(-1, 1, (n, C) if tm else (C, n)) for _ in range(3)]
+  ref = oracle.bank([3], [3], b, a, np.concatenate(xs, axis=ax), layout=layout)
+  refs = [ref[k * n:(k + 1) * n] if tm else ref[:, k * n:(k + 1) * n] for k in range(3)]
+  side = torch.cuda.Stream()
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel("one-pass")
+  bank.reset()
+  y0 = bank.process(torch.from_numpy(xs[0]).cuda(), layout=layout)
+  assert "k_look" in bank.last_kernel and norm_err(y0.cpu().numpy(), refs[0], ax) <= 1e-8
+  # block 1 beside a long hold
+  assert _hog().hog_launch(128, 110 * 1024, 1500 * 1000, side.cuda_stream) == 0
+  y1 = bank.process(torch.from_numpy(xs[1]).cuda(), layout=layout)
+  st = bank.look_stats
+  assert norm_err(y1.cpu().numpy(), refs[1], ax) <= 1e-8, (st, bank.last_kernel)
+  if st["gave_up"]:                                        # (the hold may also have been over before the kernel's waits were)
+    assert st["reruns"] == 1 and st["last_sites"] and "gave up" in bank.last_kernel and "processed again" in bank.last_kernel, (st, bank.last_kernel)
+  torch.cuda.synchronize()
+  # block 2 in place beside a long hold: good, or the call raises and leaves the state of before the call
+  x2 = torch.from_numpy(xs[2]).cuda()
+  work = x2.clone()
+  assert _hog().hog_launch(128, 110 * 1024, 1500 * 1000, side.cuda_stream) == 0
+  try:
+    y2 = bank.process(work, layout=layout, out=work)
+  except RuntimeError as exc:
+    assert "IN-PLACE" in str(exc) and "waits that ran out: " in str(exc), str(exc)
+    torch.cuda.synchronize()
+    work = x2.clone()
+    y2 = bank.process(work, layout=layout, out=work)
+  assert norm_err(y2.cpu().numpy(), refs[2], ax) <= 1e-8, bank.look_stats
+
+

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 6: ONE runner for every GPU-box call of the round (round 5 had 37 one-off r05_call*.sh).
+#   gpurun --timeout T -- 'bash tools/r06.sh <call> [args]'
+# Each call writes under gpurun_out/r06_<call>/; tools/README.md has the table "figure -> call".
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+call=$1; shift
+O=$R/gpurun_out/r06_$call
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+rocm-smi --showuniqueid 2>/dev/null | grep "GPU\[" | head -1 | tee $O/smi.log
+suite() { timeout ${1:-1500} python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -n "passed\|failed\|error" $O/pytest_gpu.log | tail -3; }
+smoke() { timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; }
+driver() { timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-json $O/bench_driver_full.json > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench rc=$?"; python tools/show_line.py $O/bench_driver.json | cut -c1-170; }
+stats() { cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --full-json $O/bench_under_rocprof.json "$@" > $O/stats.log 2>&1
+  find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+  find $O/stats -name "*kernel_trace.csv" -exec sh -c 'grep -E "Kernel_Name|alz::" "$1" > '$O'/kernel_dispatches.csv' _ {} \;
+  rm -rf $O/stats; head -12 $O/kernel_stats.csv | cut -c1-170; cd $R; }
+case $call in
+  look)    # the one-pass kernel: the race demonstrated on the ablation build, the soak, the scan tests, then the whole suite
+    for dbg in 3072 1024; do
+      ALZ_LIBRARY=$R/tools/variants/libalzhip_lookrace.so ALZ_WAVE_DEBUG=$dbg timeout 300 python tools/look_race_demo.py 20 2>&1 | tee -a $O/look_race_demo.log
+    done
+    timeout 600 python -m pytest tests/test_gpu_look_soak.py -x -q -s > $O/soak.log 2>&1; echo "soak rc=$?"; tail -25 $O/soak.log
+    timeout 600 python -m pytest tests/test_gpu_scan.py -x -q > $O/scan.log 2>&1; echo "scan rc=$?"; tail -5 $O/scan.log
+    suite; smoke; driver ;;
+  suite)   suite; smoke ;;
+  final)   suite; smoke; driver; stats ;;
+  py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
+  sh)      timeout ${T:-900} bash "$@" 2>&1 | tee $O/sh_$(basename $1 .sh).log | tail -${TAIL:-40} ;;
+  *) echo "unknown call $call" ;;
+esac
