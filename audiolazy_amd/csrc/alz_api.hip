@@ -699,7 +699,9 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
         io.map_input = 0;
         io.pre_op = 0;
       }
-      if (generic && io.x == io.y) {
+      io.c_first = c_first;
+      io.c_count = c_count;
+      if (generic && io.x == io.y && !alz::comb_takes_in_place(sec, io)) {
         // k_fir / k_generic read their history from the block, so they cannot overwrite it
         int rc = grow(&h->scratch, &h->scratch_bytes, y_extent * 8);
         if (rc) return rc;

@@ -119,10 +119,14 @@ struct CascChunks {
 };
 int launch_cascade_chunks(const SectionDev *secs, int nsec, const BlockIO &io, hipStream_t stream,
                           const CascChunks &ch, bool *taken, const char **kernel_name);
-// alz_comb.hip: sparse sections whose feedback delays are all long (comb filters), time-major,
-// x != y; *taken says whether the shape was this kernel's
+// alz_comb.hip: sparse sections whose feedback delays are all long (comb filters): the step kernels k_comb_tm /
+// k_comb_cm (either layout, in place when the numerator is b0 alone) or k_sparse (time-major, x != y); *taken says
+// whether the shape was one of theirs
 int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
                   const char **kernel_name);
+// whether launch_sparse runs this section IN PLACE on this block (io.x == io.y; the step kernels k_comb_tm / k_comb_cm
+// with the single numerator tap b0): the caller then needs no copy of the block
+bool comb_takes_in_place(const SectionDev &sec, const BlockIO &io);
 // alz_fir.hip: long feedback-free sections on time-major blocks (x != y); *taken says whether
 // the shape was this kernel's
 int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,

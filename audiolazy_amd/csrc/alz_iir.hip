@@ -313,11 +313,11 @@ int launch_section(const SectionDev &sec, const BlockIO &io, hipStream_t stream,
     hipLaunchKernelGGL((k_masked<16, 9>), grid, block, 0, stream, p);
     *kernel_name = "k_masked<16,9>";
   } else {
-    if (io.x == io.y) return fail(ALZ_E_ARG, "k_fir / k_generic cannot run in place");
     bool taken = false;
     int rc = launch_sparse(sec, io, stream, &taken, kernel_name);
     if (rc) return rc;
     if (taken) return ALZ_OK;
+    if (io.x == io.y) return fail(ALZ_E_ARG, "k_fir / k_generic cannot run in place");
     rc = launch_fir(sec, io, stream, &taken, kernel_name);
     if (rc) return rc;
     if (taken) return ALZ_OK;

@@ -81,7 +81,7 @@ constexpr int kHist = 256;                   // the two rows before a tile: [2][
 constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (k_look_prep)
 constexpr int kMaxW = 16;                    // workgroups per channel group (the predecessors' states live in registers)
 #ifdef ALZ_ABLATE
-#define ALZ_LOOK_CAP(p) ((p).dbg ? 1 : kSpinCap)      // (an ablated run publishes nothing: do not wait for it)
+#define ALZ_LOOK_CAP(p) (((p).dbg & 1023) ? 1 : kSpinCap)      // (an ablated run publishes nothing: do not wait for it)
 #else
 #define ALZ_LOOK_CAP(p) kSpinCap
 #endif

@@ -224,6 +224,17 @@ def cpu_baseline(b, a, budget_s=3.5):
   legs["c_port"] = {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1,
                     "sample": "oracle/alz_oracle.c, %d of the %d channels x %d samples, %d passes"
                               % (Cc, C, n, done // (Cc * n))}
+  # (v) the reference's comb: D memory variables shifted per sample (lazy_filters.py:254-255), one process
+  D = 441
+  cb, ca = [1.0], [1.0] + [0.0] * (D - 1) + [-math.e ** (-D / 20000.0)]
+  _py_channel((cb, ca, 1 << 8, 1, 1))
+  done, el = 0, 0.0
+  while el < budget_s:
+    d, e = _py_channel((cb, ca, 1 << 13, 4321 + done, 1))
+    done, el = done + d, el + e
+  legs["py_comb_1proc"] = {"value": done / el / 1e9, "unit": "Gsamples/s", "cores": 1,
+                           "sample": "comb.tau(441, 20000): 1 channel x %d samples, %d passes (the generated loop shifts %d memory "
+                                     "variables per sample)" % (1 << 13, done // (1 << 13), D)}
   head = legs["py_pool"]
   return {"value": head["value"], "unit": "Gsamples/s", "cores": head["cores"], "host_logical_cpus": cores,
           "usable_cores": usable, "kind": "reference" if reference_package() is not None else "port",
@@ -701,6 +712,70 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
           "roofline": hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)}
 
 
+def comb_coefs(C, D, linearized=False, fs=48000.0):
+  """comb.tau-style feedback combs (lazy_filters.py:1118-1147): y[n] = x[n] + alpha y[n - D], alpha = e ** (-D / tau) with
+  the decay time tau spread over 0.05 - 2 s per channel; `linearized`: the delay D + frac as the reference's linearize()
+  leaves it (lazy_filters.py:339-373) -- two adjacent taps alpha (1 - frac) z^-D and alpha frac z^-(D+1)."""
+  tau = np.geomspace(0.05 * fs, 2.0 * fs, C)
+  alpha = np.array([math.e ** (-D / t) for t in tau])
+  a = np.zeros((C, D + 2 if linearized else D + 1))
+  a[:, 0] = 1.0
+  if linearized:
+    frac = np.linspace(0.1, 0.9, C)
+    a[:, D] = -(alpha * (1.0 - frac))
+    a[:, D + 1] = -(alpha * frac)
+  else:
+    a[:, D] = -alpha
+  return np.ones((C, 1)), a
+
+
+def wl_comb(ctx, args, alz, C, N, D, steps, warmup, layout="time", linearized=False, inplace=False):
+  """A bank of feedback combs / Karplus-Strong strings (north_star's "resonator/comb"): the step kernels
+  of csrc/alz_comb.hip.  16 algorithmic bytes per channel-sample, HBM-bound for a wide bank; ONE string is bound by the
+  serial hand-over from one period of the delay line to the next."""
+  torch = ctx.torch
+  b, a = comb_coefs(C, D, linearized)
+  na = a.shape[1]
+  bank = alz.FilterBank([(b, a)], n_inputs=C, device=ctx.local)
+  bank.reset()
+  tm = layout == "time"
+  x = ctx.noise((N, C) if tm else (C, N), 7)
+  y = x if inplace else torch.empty_like(x)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout=layout, out=y), steps, warmup)
+  kernel = bank.last_kernel
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    # full width on a short block (several periods of the delay line), then the whole length on a few strided channels
+    nchk = min(N, 4 * D + 100)
+    xs = ctx.noise((nchk, C) if tm else (C, nchk), 8)
+    bank.reset()
+    got = bank.process(xs, layout=layout).cpu().numpy()
+    ref = oracle.bank([1], [na], b, a, xs.cpu().numpy(), layout=layout)
+    parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk) if bits_equal(got, ref) else "MISMATCH"
+    if N > nchk and not parity.startswith("MISMATCH"):
+      xl = ctx.noise((N, C) if tm else (C, N), 7)         # (the timed block again: an in-place run has overwritten it)
+      bank.reset()
+      yl = bank.process(xl, layout=layout)
+      pick = np.unique(np.linspace(0, C - 1, min(C, 8)).astype(int))
+      idx = torch.from_numpy(pick).to(ctx.dev)
+      got = yl.index_select(1 if tm else 0, idx).cpu().numpy()
+      ref = oracle.bank([1], [na], b[pick], a[pick], xl.index_select(1 if tm else 0, idx).cpu().numpy(), layout=layout)
+      parity += ("; full block length: %d strided channels x %d samples bit-exact" % (len(pick), N) if bits_equal(got, ref)
+                 else "; MISMATCH on the full block length")
+      if "MISMATCH" in parity:
+        parity = "MISMATCH: " + parity
+      del xl, yl
+  del x, y, bank
+  torch.cuda.empty_cache()
+  roof = hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)
+  if C == 1:
+    roof["note"] = ("one string: the %d samples of a period are independent, the periods are serial -- bound by the hand-over "
+                    "from period to period (an LDS round trip + the DF-I sum per step), not by HBM" % D)
+  return {"units": float(C) * N, "elapsed": elapsed, "timing": ctx.last_stats, "kernel": kernel, "parity": parity, "roofline": roof,
+          "C": C, "N": N}
+
+
 def timevar_bank(torch, dev, C, N, per_channel):
   """Coefficients of the time-varying resonator bank: b0[n] x[n] + b2 x[n-2] - a1[n] y[n-1] - a2[n] y[n-2] whose series
   sweep the centre frequency from 200 Hz to 4 kHz at 48 kHz (``resonator.z_exp(Stream(freqs), bw)`` with vector-valued
@@ -894,7 +969,8 @@ def short_parity(p):
 # The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
 # the tail of the line still holds configs[2..4].
 SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
-                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "envelope_abs", "timevar_shared", "timevar_per_channel",
+                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string",
+                   "timevar_shared", "timevar_per_channel",
                    "gammatone_one_stream", "gammatone_one_stream_time_parallel", "gammatone_one_stream_time_parallel_tm", "lpc_1m", "lpc_1m_bit_identical",
                    "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
 
@@ -987,7 +1063,10 @@ def main():
   ap.add_argument("--full-json", default=None,
                   help="where rank 0 writes the full (verbose) record; default gpurun_out/bench_full.json when that "
                        "directory can be made, '-' to skip")
-  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar"], default="biquad",
+  ap.add_argument("--comb-delay", type=int, default=441, help="--workload comb: the feedback delay in samples")
+  ap.add_argument("--comb-linearized", action="store_true", help="--workload comb: two adjacent feedback taps (linearize()d fractional delay)")
+  ap.add_argument("--in-place", action="store_true", help="--workload comb: y = x")
+  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar", "comb"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
@@ -1074,6 +1153,15 @@ def main():
         r = wl_envelope(ctx, args, alz, 4096, N, 5, 1)
         secondary["envelope_abs"] = entry(r, 1, 5, "Gsamples/s", "envelope.abs (lowpass.pole of |x|) on 4096 channels x 2^20 "
                                           "samples: the elementwise stage of SURVEY.md 8 (f1) fused into the filter kernel", key="envelope_abs")
+        r = wl_comb(ctx, args, alz, 4096, 1 << 18, 441, 5, 1)
+        secondary["comb_fb"] = entry(r, 1, 5, "Gsamples/s", "comb.tau (y[n] = x[n] + alpha y[n - 441], lazy_filters.py:1118-1147) x 4096 "
+                                     "channels x 2^18 samples, time-major: lanes over the delay line, the ring in LDS", key="comb_fb")
+        r = wl_comb(ctx, args, alz, 4096, 1 << 18, 441, 5, 1, layout="chan")
+        secondary["comb_fb_chan"] = entry(r, 1, 5, "Gsamples/s", "the same bank on channel-major blocks [C, N]: a wave per channel", key="comb_fb_chan")
+        r = wl_comb(ctx, args, alz, 1, 1 << 22, 109, 5, 1, layout="chan", linearized=True)
+        secondary["karplus_one_string"] = entry(r, 1, 5, "Gsamples/s", "ONE Karplus-Strong string (lazy_synth.py:624-657: comb.tau(...).linearize(), "
+                                                "two adjacent feedback taps at 109 / 110 samples) x 2^22 samples: the reference's own use "
+                                                "(examples/ode_to_joy.py:84)", key="karplus_one_string")
         r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1)
         secondary["timevar_shared"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples "
                                             "steered by three coefficient series shared by the channels (Stream coefficients, "
@@ -1132,6 +1220,18 @@ def main():
                           "input streams per GPU (512 streams sharded over 8), %d-sample blocks, float64, "
                           "%s" % (res["B"], res["S"], res["N"],
                                   "x [N, S] -> y [N, B, S]" if res["layout"] == "time" else "x [S, N] -> y [B, S, N]"),
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  elif args.workload == "comb":
+    if (C, N) == (4096, 1 << 20):
+      N = 1 << 18
+    res = wl_comb(ctx, args, alz, C, N, args.comb_delay, args.steps, args.warmup, layout=args.layout,
+                  linearized=args.comb_linearized, inplace=args.in_place)
+    total_units = float(world) * C * N
+    metric, unit = "Gsamples/s through a bank of feedback combs (comb.tau)", "Gsamples/s"
+    config = {"workload": "comb.tau x %d channels, delay %d%s, float64, %d-sample blocks%s" % (
+                  C, args.comb_delay, " (linearized: two taps)" if args.comb_linearized else "", N, ", in place" if args.in_place else ""),
+              "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   elif args.workload == "timevar":

@@ -388,9 +388,10 @@ def test_fir_config3_width_properties(alz):
 
 
 @pytest.mark.parametrize("D,alpha", [(16, 0.5), (109, 0.97), (441, -0.9)])
-def test_long_feedback_combs_use_the_sparse_kernel(alz, oracle, D, alpha):
+def test_long_feedback_combs_use_the_step_kernel(alz, oracle, D, alpha):
   """comb.fb / comb.tau with long delays (lazy_filters.py:1090-1147) and a linearize()d-style
-  two-tap feedback: the delay line is the block itself; bit-exact, state carried across blocks."""
+  two-tap feedback: steps of independent samples with the delay line as an LDS ring (round 6; round 1: the block itself
+  as the delay line, lane = channel); bit-exact, state carried across blocks."""
   rng = np.random.default_rng(D)
   C, N = 80, 3 * D + 37
   x = rng.uniform(-1, 1, (N, C))
@@ -401,7 +402,7 @@ def test_long_feedback_combs_use_the_sparse_kernel(alz, oracle, D, alpha):
   mem = rng.uniform(-1, 1, D + 1).tolist()
   bank.reset(memory=mem, zero=0.0)
   y = bank.process(x)
-  assert bank.last_kernel == "k_sparse"
+  assert bank.last_kernel == "k_comb_tm"
   yh = np.tile(np.array(mem), (C, 1))
   ref = oracle.bank([3], [D + 2], b, a, x, xh=np.zeros((C, 2)), yh=yh.copy())
   assert same_bits(y, ref)
@@ -413,7 +414,125 @@ def test_long_feedback_combs_use_the_sparse_kernel(alz, oracle, D, alpha):
   a2 = np.zeros((C, D + 1)); a2[:, 0] = 1.0; a2[:, D] = -al
   bank2 = alz.FilterBank([(np.ones((C, 1)), a2)], n_inputs=C)
   bank2.reset()
-  assert same_bits(bank2.process(x), oracle.bank([1], [D + 1], np.ones((C, 1)), a2, x)) and bank2.last_kernel == "k_sparse"
+  assert same_bits(bank2.process(x), oracle.bank([1], [D + 1], np.ones((C, 1)), a2, x)) and bank2.last_kernel == "k_comb_tm"
+  # a ragged channel count stays on the lane-per-channel kernel (same doubles)
+  bank3 = alz.FilterBank([(np.ones((C - 3, 1)), a2[:C - 3])], n_inputs=C - 3)
+  bank3.reset()
+  assert same_bits(bank3.process(x[:, :C - 3].copy()), oracle.bank([1], [D + 1], np.ones((C - 3, 1)), a2[:C - 3], x[:, :C - 3].copy()))
+  assert bank3.last_kernel == "k_sparse"
+
+
+def _comb_case(shape, D, C, rng):
+  """(b [C, nb], a [C, na]) of the comb family: per-channel coefficients, the zero pattern of the reference's designs."""
+  g = rng.uniform(0.3, 0.97, C) * rng.choice([-1.0, 1.0], C)
+  f = rng.uniform(0.1, 0.9, C)
+  if shape == "fb":            # comb.fb / comb.tau: 1 / (1 - g z^-D)
+    b = np.ones((C, 1)); a = np.zeros((C, D + 1)); a[:, 0] = 1; a[:, D] = -g
+  elif shape == "lin":         # ... .linearize(): 1 / (1 - g (1 - f) z^-D - g f z^-(D+1))   (karplus_strong)
+    b = np.ones((C, 1)); a = np.zeros((C, D + 2)); a[:, 0] = 1; a[:, D] = -g * (1 - f); a[:, D + 1] = -g * f
+  elif shape == "ff":          # comb.ff: 1 + g z^-D
+    b = np.zeros((C, D + 1)); b[:, 0] = 1; b[:, D] = g; a = np.ones((C, 1))
+  elif shape == "fflin":       # comb.ff linearized: three numerator taps
+    b = np.zeros((C, D + 2)); b[:, 0] = 1; b[:, D] = g * (1 - f); b[:, D + 1] = g * f; a = np.ones((C, 1))
+  else:                        # "mixed": (b0 + b3 z^-3) / (1 - g z^-D)
+    b = np.zeros((C, 4)); b[:, 0] = rng.uniform(0.5, 1.5, C); b[:, 3] = rng.uniform(-0.5, 0.5, C)
+    a = np.zeros((C, D + 1)); a[:, 0] = 1; a[:, D] = -g
+  return b, a
+
+
+@pytest.mark.parametrize("layout", ["time", "chan"])
+@pytest.mark.parametrize("shape,D", [("fb", 16), ("fb", 441), ("fb", 700), ("lin", 24), ("lin", 109), ("lin", 441), ("ff", 441),
+                                       ("fflin", 70), ("mixed", 109), ("mixed", 300)])
+def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, layout, shape, D):
+  """Round 6: k_comb_tm / k_comb_cm (csrc/alz_comb.hip) -- the comb family of lazy_filters.py:1087-1173 and its
+  linearize()d forms (:339-373) on time-major and channel-major blocks, out of place and (single numerator tap) in place,
+  over blocks that are longer than, equal to and shorter than a step / a chunk / the delay line, with a non-trivial delay
+  line to start from (karplus_strong's memory=white_noise, lazy_synth.py:624-657); bit-exact against the oracle as ONE
+  continuous run, asserting the kernel taken."""
+  import torch
+  rng = np.random.default_rng(D + len(shape))
+  C = 48
+  tm = layout == "time"
+  ax = 0 if tm else 1
+  b, a = _comb_case(shape, D, C, rng)
+  nb, na = b.shape[1], a.shape[1]
+  lens = [3 * D + 38, D // 2 + 4, 2 * 256 + 78, 256, 2]     # (even lengths: 16-byte rows in [C, N])
+  xs = [rng.uniform(-1, 1, (m, C) if tm else (C, m)) for m in lens]
+  xh0 = rng.uniform(-1, 1, (C, max(nb - 1, 1)))
+  yh0 = rng.uniform(-1, 1, (C, max(na - 1, 1)))
+  ref = oracle.bank([nb], [na], b, a, np.concatenate(xs, axis=ax), layout=layout, xh=xh0.copy(), yh=yh0.copy())
+  want = "k_comb_tm" if tm else "k_comb_cm"
+  for inplace in ((False, True) if nb == 1 else (False,)):
+    bank = alz.FilterBank([(b, a)], n_inputs=C)
+    bank.set_state(xh0, yh0)
+    at = 0
+    for x in xs:
+      xd = torch.from_numpy(x).cuda()
+      y = bank.process(xd, layout=layout, out=xd if inplace else None)
+      assert bank.last_kernel == want, (bank.last_kernel, shape, D, layout, inplace)
+      m = x.shape[ax]
+      r = ref[at:at + m] if tm else ref[:, at:at + m]
+      assert same_bits(y.cpu().numpy(), r), (shape, D, layout, inplace, at)
+      at += m
+
+
+@pytest.mark.parametrize("D", [16, 63, 64, 109, 257, 1000, 3000])
+def test_one_string_lanes_over_the_delay(alz, oracle, D):
+  """A single Karplus-Strong string (lazy_synth.py:624-657: comb.tau(...).linearize()(zeros(), memory=white_noise)): one
+  channel, lanes over the delay line (k_comb_cm), as [1, N] and as the reference's [N, 1] column, from a noise-filled
+  delay line, in place and not; bit-exact, block after block."""
+  import torch
+  rng = np.random.default_rng(D)
+  b, a = _comb_case("lin", D, 1, rng)
+  na = a.shape[1]
+  yh0 = rng.uniform(-1, 1, (1, na - 1))
+  lens = [5 * D + 10, 700, 66]
+  xs = [np.zeros(lens[0]), rng.uniform(-1e-3, 1e-3, lens[1]), np.zeros(lens[2])]
+  ref = oracle.bank([1], [na], b, a, np.concatenate(xs)[None, :], layout="chan", yh=yh0.copy())[0]
+  for layout in ("chan", "time"):
+    for inplace in (False, True):
+      bank = alz.FilterBank([(b, a)], n_inputs=1)
+      bank.set_state(np.zeros((1, 1)), yh0)
+      at = 0
+      for x in xs:
+        xd = torch.from_numpy(x[None, :] if layout == "chan" else x[:, None]).cuda()
+        y = bank.process(xd, layout=layout, out=xd if inplace else None)
+        assert bank.last_kernel == "k_comb_cm", bank.last_kernel
+        assert same_bits(y.cpu().numpy().ravel(), ref[at:at + len(x)]), (D, layout, inplace, at)
+        at += len(x)
+
+
+def test_comb_outer_bank_and_wide_block(alz, oracle):
+  """A comb per (set, input) pair -- an OUTER bank reading by input index -- and a block wide and long enough for every
+  workgroup / wave to run many steps (4096 channels x 4096 samples, D = 441: bench.py's comb_fb shape, shortened)."""
+  import torch
+  rng = np.random.default_rng(5)
+  D, S, B = 120, 32, 3
+  g = rng.uniform(0.5, 0.95, B)
+  a = np.zeros((B, D + 1)); a[:, 0] = 1; a[:, D] = -g
+  b = np.ones((B, 1))
+  for layout in ("time", "chan"):
+    x = rng.uniform(-1, 1, (900, S) if layout == "time" else (S, 900))
+    bank = alz.FilterBank([(b, a)], n_inputs=S, mode="outer")
+    bank.reset()
+    y = bank.process(torch.from_numpy(x).cuda(), layout=layout).cpu().numpy()
+    assert bank.last_kernel in ("k_comb_tm", "k_comb_cm") or "k_expand" in bank.last_kernel, bank.last_kernel
+    for s in range(B):
+      xs = x if layout == "time" else x
+      r = oracle.bank([1], [D + 1], b[s], a[s], x, layout=layout)
+      got = y[:, s * S:(s + 1) * S] if layout == "time" else y[s * S:(s + 1) * S]
+      assert same_bits(got, r), (layout, s)
+  import bench
+  C, N, D = 4096, 4096, 441
+  bb, aa = bench.comb_coefs(C, D)
+  x = rng.uniform(-1, 1, (N, C))
+  ref = oracle.bank([1], [D + 1], bb, aa, x, layout="time")
+  bank = alz.FilterBank([(bb, aa)], n_inputs=C)
+  bank.reset()
+  assert same_bits(bank.process(torch.from_numpy(x).cuda(), layout="time").cpu().numpy(), ref) and bank.last_kernel == "k_comb_tm"
+  xt = np.ascontiguousarray(x.T)
+  bank.reset()
+  assert same_bits(bank.process(torch.from_numpy(xt).cuda(), layout="chan").cpu().numpy(), ref.T) and bank.last_kernel == "k_comb_cm"
 
 
 def test_random_structure_sweep(alz, oracle):

@@ -24,6 +24,18 @@ case $call in
     timeout 600 python -m pytest tests/test_gpu_look_soak.py -x -q -s > $O/soak.log 2>&1; echo "soak rc=$?"; tail -25 $O/soak.log
     timeout 600 python -m pytest tests/test_gpu_scan.py -x -q > $O/scan.log 2>&1; echo "scan rc=$?"; tail -5 $O/scan.log
     suite; smoke; driver ;;
+  comb)    # the comb step kernels: their tests, the karplus goldens, timings by shape, round 1's k_sparse beside them
+    timeout 900 python -m pytest tests/test_gpu_bank.py tests/test_gpu_filters_api.py -x -q -k "comb or string or karplus" > $O/comb_tests.log 2>&1; echo "comb tests rc=$?"; tail -5 $O/comb_tests.log
+    B="--no-cpu-baseline --no-secondary --steps 10 --warmup 2 --full-json -"
+    for a in "--layout time" "--layout chan" "--layout time --in-place" "--layout chan --in-place" "--layout time --comb-linearized" "--layout chan --comb-linearized" \
+             "--layout time --comb-delay 64" "--layout chan --comb-delay 64" "--channels 1 --log2-samples 22 --comb-delay 109 --comb-linearized --layout chan" \
+             "--channels 1 --log2-samples 22 --comb-delay 441 --layout chan" "--channels 16384 --log2-samples 16 --layout time" "--channels 16384 --log2-samples 16 --layout chan"; do
+      echo "== comb $a"; timeout 300 python bench.py --workload comb $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+    done 2>&1 | tee $O/comb_shapes.log
+    echo "== round 1's k_sparse on the same shapes (tuning build, ALZ_COMB_OFF=1)" | tee -a $O/comb_shapes.log
+    for a in "--layout time" "--channels 1 --log2-samples 20 --comb-delay 109 --comb-linearized --layout time"; do
+      echo "== k_sparse $a"; ALZ_COMB_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 300 python bench.py --workload comb $a $B --no-parity-check > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+    done 2>&1 | tee -a $O/comb_shapes.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
