@@ -81,7 +81,8 @@ SIGNATURES = {
 
 # wait sites of the one-pass time-parallel kernel (csrc/alz_look.hip W_*: bit k of alz_bank_look_stats' last_sites)
 LOOK_WAIT_SITES = ("?", "LOAD/stored", "HELP/prepared", "HELP/replayed", "HELP/state-read", "CHAIN/published-states",
-                   "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored")
+                   "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored", "CHAIN/neighbour-start-state",
+                   "CHUNK-BOUNDARY-CHECK-FAILED")
 
 
 class TvTap(ctypes.Structure):

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(64) void k_sparse(SArgs p) {
 }
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
+#ifndef ALZ_COMB_NT
+#define ALZ_COMB_NT 0      // variant builds: 1 = non-temporal input loads and output stores (A/B: profiles/NOTES_r06.md 2)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_comb_tm: time-major.  blockDim = 8 P threads (P rows per pass, a multiple of 8: whole waves), T = P U rows per step.
@@ -156,7 +159,11 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
   auto xrow = [&](int64_t t) -> dbl2 {
     t = t < N ? t : N - 1;
     const double *src = t >= 0 ? xb + t * sxn : xhb + (-t - 1) * C;
+#if ALZ_COMB_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(src));
+#else
     return *reinterpret_cast<const dbl2 *>(src);
+#endif
   };
   dbl2 xv[U][NFF > 0 ? NFF : 1];
 #pragma unroll
@@ -194,7 +201,11 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
     for (int u = 0; u < U; ++u) {
       const int64_t n = n0 + r + P * u;
       if (n < N) {
+#if ALZ_COMB_NT
+        __builtin_nontemporal_store(acc[u], reinterpret_cast<dbl2 *>(yb + n * syn));
+#else
         *reinterpret_cast<dbl2 *>(yb + n * syn) = acc[u];
+#endif
         if constexpr (NFB > 0) {
           int w = q0 + r + P * u;
           w -= w >= R ? R : 0;
@@ -223,14 +234,22 @@ __device__ __forceinline__ void comb_dma16(const void *gsrc, unsigned lds_dst) {
       "s_mov_b32 %0, m0\n\t"
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
+#if ALZ_COMB_NT
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+#else
       "global_load_lds_dwordx4 %1, off\n\t"
+#endif
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
 __device__ __forceinline__ void comb_store16(double *gdst, dbl2 v) {
+#if ALZ_COMB_NT
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+#else
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+#endif
 }
 
 template <int NFF, int NFB, int U>

@@ -184,6 +184,7 @@ int launch_expand(const double *x, double *xe, int64_t n, int64_t channels, int6
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name);
 constexpr int64_t kLookChunk = 512;
+uint64_t look_scratch_bytes(int64_t groups, int64_t chunks);   // what launch_look needs in `zbuf` for that many 16-channel groups and chunks
 constexpr int kLookErrWords = 16;
 constexpr int64_t kTpThreeLaunch = -3;   // internal chunk_len value: the engine's chunk length, never the one-pass form (the re-run of a block
                                          // on which the one-pass kernel gave up)

@@ -16,13 +16,18 @@
 //       HELP    stores finished tiles, and forms every chunk's zero-state end state z_j WITHOUT a second recurrence:
 //               the end state of a tile is a dot product of its p rows with the impulse response of 1/A(z) (32 FMAs
 //               per lane and tile, weights computed once per launch), carried from tile to tile through A^64 and
-//               published in global memory with the chunk's last tile (64-bit agent-scope atomic stores into an array
-//               pre-filled with a NaN pattern no computation produces: no flags, no fences);
+//               published in global memory with the chunk's last tile (64-bit agent-scope atomic stores, every word
+//               twice: as it is and XORed with a key no other launch has -- a reader takes a word only when the pair
+//               matches, so whatever the array held before, from an earlier launch or from nobody, is simply "not
+//               yet published": no flags, no fences, and since round 6 no pre-filling either);
 //       CHAIN   hands REPLAY the true start state of every chunk, which needs no other workgroup's replay: it is
 //               chained in zero-state space, S_j = M ( ... M (M S_{j-W} + z_{j-W}) + z_{j-W+1} ... ) + z_{j-1}
 //               (M = A^512 per channel, the matrix alz_scan.hip caches), from the workgroup's own previous start state
-//               and the z of the W chunks in between, fetched (four 1 KiB global -> LDS transfers, repeated until none
-//               shows the NaN pattern) as soon as the neighbours publish them.
+//               and the z of the W chunks in between, fetched (eight 1 KiB global -> LDS transfers, repeated until
+//               every pair matches the key) as soon as the neighbours publish them.  It also CHECKS the result of all
+//               this where it can be checked (round 6): every start state is published like the z, and two chunks
+//               later the replay's TRUE state at the end of chunk j is compared with the start state the neighbour
+//               used for chunk j + 1 -- a chunk that started from a wrong state cannot leave the kernel unreported.
 //     Waits only ever point to smaller chunk indices and earlier tiles, and every workgroup of the launch is resident:
 //     no deadlock; bounded spins guard against the impossible.
 //
@@ -48,6 +53,7 @@
 // In place (x == y): a tile is stored long after it was read, and by the workgroup that read it; only the two rows in
 // front of a chunk belong to another workgroup, so a small launch saves those for every chunk first (k_look_hsave).
 #include "alz_common.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -78,7 +84,7 @@ constexpr int kNT = 8;                       // tiles per chunk (L = 512)
 constexpr int kSlots = ALZ_LOOK_SLOTS;       // tile slots in LDS
 constexpr int kSlot = 8192 + kChunks * 16;   // a tile in the DMA layout (16 bytes of pad per 1 KiB chunk)
 constexpr int kHist = 256;                   // the two rows before a tile: [2][16] doubles
-constexpr unsigned long long kSentinel = ~0ull;   // the "not yet published" pattern (k_look_prep)
+constexpr int kPub = 64;                     // 64-bit words per published chunk state: [value 1, value 1 ^ key, value 2, value 2 ^ key][16 channels]
 constexpr int kMaxW = 16;                    // workgroups per channel group (the predecessors' states live in registers)
 #ifdef ALZ_ABLATE
 #define ALZ_LOOK_CAP(p) (((p).dbg & 1023) ? 1 : kSpinCap)      // (an ablated run publishes nothing: do not wait for it)
@@ -98,7 +104,9 @@ struct LArgs {
   const double *b, *a;
   double *xh, *yh;             // the bank's state [taps-1][channels]
   const double *power;         // M = A^512 per channel: [4][channels] (M11 M12 M21 M22)
-  unsigned long long *z;       // [groups][n_chunks][2][16] published zero-state end states
+  unsigned long long *z;       // [groups][n_chunks][kPub] published zero-state end states
+  unsigned long long *s;       // [groups][n_chunks][kPub] published chunk start states (for the check at the chunk boundaries)
+  unsigned long long key;      // this launch's key: a published word counts when word ^ its twin == key
   const double *hsave;         // in place: the two input rows in front of every chunk, [groups][n_chunks][32] in the
                                // history transfer's own order (time-major [2][16], channel-major [16][2]); else nullptr
   int *err;                    // [kLookErrWords] of pinned host memory: word W_* set when that wait ran into its cap
@@ -253,7 +261,7 @@ __device__ __forceinline__ double sum_rows(double x) {
 enum { F_PREPARED = 0, F_STORED, F_REPLAYED, F_CHUNK, F_ZDONE, F_INIT, F_COUNT = 8 };
 // Which bounded wait ran out (word of LArgs::err; launch_look's caller reads them all): wave / what it waited for.
 enum { W_ANY = 0, W_LOAD_STORED, W_HELP_PREPARED, W_HELP_REPLAYED, W_HELP_INIT, W_CHAIN_Z, W_CHAIN_REPLAYED, W_CHAIN_ZDONE,
-       W_CHAIN_PREPARED, W_REPLAY_CHUNK, W_LOAD_FINAL, W_COUNT };
+       W_CHAIN_PREPARED, W_REPLAY_CHUNK, W_LOAD_FINAL, W_CHAIN_CHECK_WAIT, W_CHECK_FAILED, W_COUNT };
 static_assert(W_COUNT <= kLookErrWords, "one word of pinned host memory per wait site");
 
 template <int N>
@@ -307,9 +315,11 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
   const int n_iv = TOT + kStoreBehind + 1;
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   char *hist = smem + kSlots * kSlot;                         // [kSlots][2][16] doubles: rows -2, -1 of every tile
-  char *zlds = hist + kSlots * kHist;                         // [kMaxW][2][16] doubles: the requested chunk end states
-  char *sbuf = zlds + kMaxW * 256;                            // [2][2][16] doubles: chunk start states, by chunk parity
-  int *flags = reinterpret_cast<int *>(sbuf + 512);           // [F_COUNT] progress counters
+  char *zlds = hist + kSlots * kHist;                         // [kMaxW][kPub] words: the requested chunk end states
+  char *sbuf = zlds + kMaxW * kPub * 8;                       // [2][2][16] doubles: chunk start states, by chunk parity
+  char *ebuf = sbuf + 512;                                    // [3][2][16] doubles: the replay's true state at the end of a chunk, by chunk % 3
+  char *vlds = ebuf + 768;                                    // [kPub] words: a neighbour's published start state (the boundary check)
+  int *flags = reinterpret_cast<int *>(vlds + kPub * 8);      // [F_COUNT] progress counters
   int cap = 1 << 22;                                          // (~0.3 s of polling)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int lane_off = CM ? cl * kChanPitch : cl * 8;        // the lane's channel in the p / y image of a tile
@@ -318,7 +328,16 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 #define ALZ_EOFF(u) (CM ? (u) * 8 : (u) * G * 8 + (((u) * G) >> 7) * 16)
   // global row of tile t's first sample: chunk (w + (t / NT) W), tile t % NT of it
   auto tile_row = [&](int t) -> int64_t { return ((int64_t)w + (int64_t)(t / NT) * W) * (NT * T) + (t % NT) * T; };
-  unsigned long long *zg = p.z + group * K * 32;              // this group's [K][2][16]
+  unsigned long long *zg = p.z + group * K * kPub;            // this group's [K][kPub]
+  unsigned long long *sg = p.s + group * K * kPub;
+  const unsigned long long key = p.key;
+  auto publish_pair = [&](unsigned long long *dst, double v1, double v2) {   // (the 16 lanes of one copy; dst = the chunk's kPub words)
+    const unsigned long long b1 = (unsigned long long)__double_as_longlong(v1), b2 = (unsigned long long)__double_as_longlong(v2);
+    __hip_atomic_store(dst + cl, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 16 + cl, b1 ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 32 + cl, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 48 + cl, b2 ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   double na1 = 0, na2 = 0;
   if (PA & 1u) na1 = -p.a[1 * p.n_sets + set];
   if (PA & 2u) na2 = -p.a[2 * p.n_sets + set];
@@ -557,10 +576,7 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         if (i == NT - 1) await(flags + F_INIT, 1, cap, p.err, W_HELP_INIT);
         if (tt == NT - 1 && q == 0) {
           const int64_t j = (int64_t)w + (int64_t)(i / NT) * W;
-          __hip_atomic_store(zg + j * 32 + cl, (unsigned long long)__double_as_longlong(Z1), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(zg + j * 32 + 16 + cl, (unsigned long long)__double_as_longlong(Z2), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+          publish_pair(zg + j * kPub, Z1, Z2);
         }
       }
       ALZ_LOOK_MARK(3)
@@ -582,40 +598,65 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
     double S2 = (p.na > 2) ? p.yh[1 * p.channels + c] : 0.0;
     asm volatile("" : "+v"(S1), "+v"(S2));
     publish(flags + F_INIT, 1, lane);                          // (the state words are in registers)
+    // Round 6: what the chain produced is CHECKED at every chunk boundary.  The replay of chunk j ends in the true state
+    // (the DF-I statement sample by sample from chunk j's start state); the workgroup of chunk j + 1 started from the state
+    // its own chain gave it, M S + z over up to W chunks -- the same number within the mode's error (1e-10 .. 1e-7 of the
+    // signal's scale) unless some z, some start state or some replay was wrong.  A mismatch sets W_CHECK_FAILED: the
+    // process call then runs the block again in three launches (ALZ_LOOK_CHECK_CALL) or the next call raises.
+    double smax = 0.0;
+    auto check_boundary = [&](int vs) {
+      const int64_t cv = (int64_t)w + (int64_t)vs * W;         // the chunk whose end is checked
+      if (cv + 1 >= K || ALZ_DBG(p, 32 | 2)) return;           // (the block's last chunk ends in the bank's state: no successor)
+      await(flags + F_REPLAYED, NT * (vs + 1), cap, p.err, W_CHAIN_CHECK_WAIT);
+      unsigned long long v1 = 0, v2 = 0;
+      int tries = 0;
+      while (true) {
+        if (lane < 32) dma16_coherent(sg + (cv + 1) * kPub + 2 * lane, lds0 + (unsigned)(vlds - smem));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long *vl = reinterpret_cast<const unsigned long long *>(vlds) + cl;
+        v1 = vl[0];
+        v2 = vl[32];
+        const bool missing = (v1 ^ vl[16]) != key || (v2 ^ vl[48]) != key;
+        if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
+        if (++tries > ALZ_LOOK_CAP(p)) { p.err[W_CHAIN_CHECK_WAIT] = 1; return; }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      const double n1 = __longlong_as_double((long long)v1), n2 = __longlong_as_double((long long)v2);
+      const double e1 = *reinterpret_cast<const double *>(ebuf + (vs % 3) * 256 + cl * 8);
+      const double e2 = *reinterpret_cast<const double *>(ebuf + (vs % 3) * 256 + 128 + cl * 8);
+      const double d = __builtin_fabs(e1 - n1) + __builtin_fabs(e2 - n2);
+      const double sc = __builtin_fabs(e1) + __builtin_fabs(e2) + __builtin_fabs(n1) + __builtin_fabs(n2);
+      smax = sc > smax ? sc : smax;                            // (the scale of this channel's states so far: a boundary in near-silence is not held to its own size)
+      if (d > 1e-5 * smax) p.err[W_CHECK_FAILED] = 1;          // (a NaN -- a NaN in the input -- is not a mismatch)
+    };
     for (int seq = 0; seq < my_chunks; ++seq) {
       if ((seq > 0 || w > 0) && !ALZ_DBG(p, 32)) {
         const int64_t cj = (int64_t)w + (int64_t)seq * W;
         const int64_t req_first = seq > 0 ? cj - W : 0;      // z_first .. z_{cj-1}
         const int req_cnt = (int)(cj - req_first);
-        // all of them at once, as four 1 KiB global -> LDS transfers, again until none shows the "not yet published"
-        // pattern (this wave has nothing else to do; the last of them appears when the neighbour's HELP wave has
-        // summed its chunk)
+        // all of them at once, as eight 1 KiB global -> LDS transfers, again until every requested pair matches the key
+        // (this wave has nothing else to do; the last of them appears when the neighbour's HELP wave has summed its chunk)
         unsigned long long a1[kMaxW], a2[kMaxW];
         int tries = 0;
         while (true) {
 #pragma unroll
-          for (int o = 0; o < kMaxW / 4; ++o) {              // lane l of transfer o: chunk 4 o + l / 16, 16-byte piece l % 16
-            int64_t ch = req_first + 4 * o + (lane >> 4);
+          for (int o = 0; o < kMaxW / 2; ++o) {              // lane l of transfer o: chunk 2 o + l / 32, 16-byte piece l % 32
+            int64_t ch = req_first + 2 * o + (lane >> 5);
             if (ch > K - 1) ch = K - 1;                      // (beyond the request: any valid address, never read)
-            dma16_coherent(zg + ch * 32 + 2 * (lane & 15), lds0 + (unsigned)(zlds - smem) + o * 1024);
+            dma16_coherent(zg + ch * kPub + 2 * (lane & 31), lds0 + (unsigned)(zlds - smem) + o * 1024);
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           bool missing = false;
 #pragma unroll
           for (int e = 0; e < kMaxW; ++e) {
-            const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * 32 + cl;
+            const unsigned long long *zl = reinterpret_cast<const unsigned long long *>(zlds) + e * kPub + cl;
             a1[e] = zl[0];
-            a2[e] = zl[16];
-            missing |= e < req_cnt && (a1[e] == kSentinel || a2[e] == kSentinel);
+            a2[e] = zl[32];
+            missing |= e < req_cnt && ((a1[e] ^ zl[16]) != key || (a2[e] ^ zl[48]) != key);
           }
           if (__builtin_amdgcn_ballot_w64(missing) == 0) break;
           if (++tries > ALZ_LOOK_CAP(p)) {                   // (cannot happen: the states come from earlier chunks)
             p.err[W_CHAIN_Z] = 1;
-#pragma unroll
-            for (int e = 0; e < kMaxW; ++e) {
-              if (a1[e] == kSentinel) a1[e] = 0;
-              if (a2[e] == kSentinel) a2[e] = 0;
-            }
             break;
           }
           __builtin_amdgcn_s_sleep(16);
@@ -630,6 +671,11 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
           }
         }
       }
+#if defined(ALZ_ABLATE)
+      if (ALZ_DBG(p, 4096) && group == 1 && seq == 1 && w == 2) S1 += 0.125;   // (a wrong start state, for the demonstration of the boundary check)
+#endif
+      // the start state goes out like the z (chunk 0 starts from the bank's state: nothing to compare it with)
+      if (q == 0 && (seq > 0 || w > 0)) publish_pair(sg + ((int64_t)w + (int64_t)seq * W) * kPub, S1, S2);
       // the buffer of this parity held the state of chunk number seq - 2: the replay has read it
       if (seq >= 2) await(flags + F_REPLAYED, NT * (seq - 2) + 1, cap, p.err, W_CHAIN_REPLAYED);
       if (q == 0) {
@@ -644,7 +690,11 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         await(flags + F_PREPARED, pneed > TOT ? TOT : pneed, cap, p.err, W_CHAIN_PREPARED);
       }
       publish(flags + F_CHUNK, seq + 1, lane);
+      // the replay is past chunk seq - 2 by now (the tiles this round waited for are prepared at most two chunks ahead of
+      // it): that chunk's true end state against the start state its successor was given
+      if (seq >= 2) check_boundary(seq - 2);
     }
+    for (int vs = my_chunks >= 2 ? my_chunks - 2 : 0; vs < my_chunks; ++vs) check_boundary(vs);
   } else {
     // ------------------------------ REPLAY ------------------------------
     asm volatile("" : "+v"(na1), "+v"(na2));
@@ -677,6 +727,10 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
         look_tile<PA, false, kStep>(cur, nxt, q, 0.0, 0.0, na1, na2, st, pr);
       }
       ALZ_LOOK_MARK(0)
+      if (tic == NT - 1 && q == 0) {                         // copy 0's state after a chunk's last tile: the true end state (CHAIN's check)
+        *reinterpret_cast<double *>(ebuf + (seq % 3) * 256 + cl * 8) = st.m1;
+        *reinterpret_cast<double *>(ebuf + (seq % 3) * 256 + 128 + cl * 8) = st.m2;
+      }
       publish(flags + F_REPLAYED, t + 1, lane);              // (behind the tile's writes in the LDS's order)
       // copy 0 has just finished the tile: after the last one its (m1, m2) is the bank's state after the block
       if (t == TOT - 1 && q == 0 && ((K - 1) % W) == w) {
@@ -701,7 +755,8 @@ __global__ __launch_bounds__(256) void k_look(LArgs p) {
 
 const char *look_wait_name(int site) {
   static const char *const names[W_COUNT] = {"?", "LOAD/stored", "HELP/prepared", "HELP/replayed", "HELP/state-read", "CHAIN/published-states",
-                                             "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored"};
+                                             "CHAIN/replayed", "CHAIN/summed", "CHAIN/prepared", "REPLAY/start-state", "LOAD/all-stored", "CHAIN/neighbour-start-state",
+                                             "CHUNK-BOUNDARY-CHECK-FAILED"};
   return site >= 0 && site < W_COUNT ? names[site] : "?";
 }
 
@@ -719,15 +774,10 @@ static look_fn pick_look(unsigned pb, unsigned pa, bool cm, int pre) {
   return nullptr;
 }
 
-// What a launch needs set up, in one small launch in front of it: the published-state array filled with the "not yet
-// published" pattern and, in place (hsave != nullptr), the two input rows in front of every chunk saved before any
-// workgroup overwrites them (LArgs::hsave).  (Round 5: a hipMemsetAsync and a k_look_hsave launch.)
-__global__ __launch_bounds__(256) void k_look_prep(unsigned long long *z, const double *x, int64_t ldx, int cm, int64_t groups, int64_t K,
-                                                   double *hsave) {
+// in place: the two input rows in front of every chunk, saved before any workgroup overwrites them (LArgs::hsave)
+__global__ __launch_bounds__(256) void k_look_hsave(const double *x, int64_t ldx, int cm, int64_t groups, int64_t K, double *hsave) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= groups * K * 32) return;
-  z[i] = kSentinel;
-  if (!hsave) return;
   const int64_t gk = i >> 5, g = gk / K, j = gk - g * K;
   const int e = (int)(i & 31);
   if (j == 0) return;                                   // (chunk 0 starts from the bank's own history)
@@ -755,10 +805,12 @@ bool look_takes(const SectionDev &sec, const BlockIO &io, int cus) {
   return pick_look(sec.present_b, sec.present_a, cm && !tm, io.pre_op) != nullptr;
 }
 
+uint64_t look_scratch_bytes(int64_t groups, int64_t chunks) { return (uint64_t)groups * chunks * (2 * kPub + 32) * sizeof(double); }
+
 // One-pass time-parallel run of a biquad-class section over whole 512-sample chunks of a block (either layout, also in
 // place, optionally with |x| on the input reads).  `power` = the section's M = A^512 per channel ([4][channels],
-// alz_scan.hip); `zbuf` (>= 2 x groups * chunks * 32 doubles: the published states, then the saved history rows of an
-// in-place run) and `err` are scratch of the handle.  *done_samples: the whole chunks covered (0: not this kernel's shape).
+// alz_scan.hip); `zbuf` (look_scratch_bytes(groups, chunks): the published end states, the published start states, then
+// the saved history rows of an in-place run; never cleared) and `err` are scratch of the handle.  *done_samples: the whole chunks covered (0: not this kernel's shape).
 int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, const double *power, double *zbuf,
                 uint64_t zbuf_bytes, int *err, int64_t *done_samples, const char **kernel_name) {
   *done_samples = 0;
@@ -789,8 +841,8 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   if (W > K) W = (int)K;
   if (W > kMaxW) W = kMaxW;
   const bool inplace = io.x == io.y;
-  const uint64_t zdoubles = (uint64_t)groups * K * 32;
-  if ((inplace ? 2 : 1) * zdoubles * sizeof(double) > zbuf_bytes) return ALZ_OK;
+  const uint64_t zwords = (uint64_t)groups * K * kPub;      // published end states, then as many for the start states, then the
+  if (look_scratch_bytes(groups, K) > zbuf_bytes) return ALZ_OK;   // saved history rows of an in-place run
   look_fn fn = pick_look(sec.present_b, sec.present_a, cm, io.pre_op);
   if (!fn) return ALZ_OK;
   LArgs p;
@@ -798,11 +850,22 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
   p.n_inputs = io.mode == ALZ_BANK_OUTER ? io.n_inputs : 0; p.n_sets = io.n_sets; p.workers = W;
   p.nb = sec.nb; p.na = sec.na; p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   p.power = power; p.z = (unsigned long long *)zbuf; p.err = err;
-  p.hsave = inplace ? zbuf + zdoubles : nullptr;
+  p.s = (unsigned long long *)zbuf + zwords;
+  p.hsave = inplace ? zbuf + 2 * zwords : nullptr;
+  {
+    // a key no other launch of this process has had (the scratch may hold any earlier launch's words, of this bank or,
+    // after a free and a malloc, of another): splitmix64 of a process-wide counter, never zero
+    static std::atomic<unsigned long long> counter{0x9E3779B97F4A7C15ull};
+    unsigned long long z = counter.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p.key = z ? z : 0x5851F42D4C957F2Dull;
+  }
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
   const size_t slot = cm ? (size_t)kSlotCM : (size_t)kSlot;
-  const size_t lds = (size_t)kSlots * slot + (size_t)kSlots * kHist + (size_t)kMaxW * 256 + 512 + 64;
+  const size_t lds = (size_t)kSlots * slot + (size_t)kSlots * kHist + (size_t)kMaxW * kPub * 8 + 512 + 768 + kPub * 8 + 64;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
   // Every workgroup of the launch waits on others: they must all be resident at once.  The runtime is asked to
@@ -828,8 +891,9 @@ int launch_look(const SectionDev &sec, const BlockIO &io, hipStream_t stream, co
     }
   }
   if ((int64_t)per_cu * cus < groups * W) return ALZ_OK;     // (not co-resident: the three-launch form takes the block)
-  hipLaunchKernelGGL(k_look_prep, dim3((unsigned)((zdoubles + 255) / 256)), dim3(256), 0, stream, (unsigned long long *)zbuf, io.x, p.ldx,
-                     cm ? 1 : 0, groups, K, inplace ? zbuf + zdoubles : (double *)nullptr);
+  if (inplace)
+    hipLaunchKernelGGL(k_look_hsave, dim3((unsigned)((groups * K * 32 + 255) / 256)), dim3(256), 0, stream, io.x, p.ldx, cm ? 1 : 0, groups, K,
+                       zbuf + 2 * zwords);
   void *args[] = {(void *)&p};
   if (ALZ_TUNE("ALZ_LOOK_COOP", 1) == 0) {       // (tuning builds: the plain launch of round 3, for A/B timing)
     hipLaunchKernelGGL(fn, dim3((unsigned)(groups * W)), dim3(256), lds, stream, p);

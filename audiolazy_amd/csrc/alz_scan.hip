@@ -179,7 +179,7 @@ int launch_scan(const SectionDev &sec, int section_index, const BlockIO &io, hip
         return fail(ALZ_E_NOMEM, "hipHostMalloc failed (time-parallel scratch)");
       for (int k = 0; k < kLookErrWords; ++k) scratch->look_err[k] = 0;
     }
-    const uint64_t zneed = (uint64_t)groups * Kl * 32 * sizeof(double) * (io.x == io.y ? 2 : 1);   // (+ the saved history rows of an in-place run)
+    const uint64_t zneed = look_scratch_bytes(groups, Kl);
     uint64_t have_z = scratch->zbuf_bytes, have_p = scratch->power_bytes;
     int rc2 = grow_scratch(&scratch->zbuf, &have_z, zneed);
     if (rc2) return rc2;

@@ -16,7 +16,8 @@ def test_cpu_baseline_legs_run_and_rank_as_expected():
   assert cpu["kind"] == ("reference" if bench.reference_package() is not None else "port")
   assert cpu["unit"] == "Gsamples/s" and cpu["host_logical_cpus"] == os.cpu_count()
   legs = cpu["legs"]
-  assert set(legs) == {"py_1proc", "py_pool", "py_rows", "c_port"}
+  assert set(legs) == {"py_1proc", "py_pool", "py_rows", "c_port", "py_comb_1proc"}
+  assert legs["py_comb_1proc"]["value"] < legs["py_1proc"]["value"]     # (the O(D) shift per sample, lazy_filters.py:254-255)
   assert all(leg["value"] > 0 and leg["unit"] == "Gsamples/s" for leg in legs.values())
   assert cpu["value"] == legs["py_pool"]["value"] and cpu["cores"] == legs["py_pool"]["cores"] >= 1
   # the interpreter pays per sample: one Python generator is far below the same statement compiled by gcc

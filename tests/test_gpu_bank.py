@@ -456,7 +456,7 @@ def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, 
   ax = 0 if tm else 1
   b, a = _comb_case(shape, D, C, rng)
   nb, na = b.shape[1], a.shape[1]
-  lens = [3 * D + 38, D // 2 + 4, 2 * 256 + 78, 256, 2]     # (even lengths: 16-byte rows in [C, N])
+  lens = [m + (m & 1) for m in (3 * D + 38, D // 2 + 4, 2 * 256 + 78, 256, 2)]     # (even lengths: 16-byte rows in [C, N])
   xs = [rng.uniform(-1, 1, (m, C) if tm else (C, m)) for m in lens]
   xh0 = rng.uniform(-1, 1, (C, max(nb - 1, 1)))
   yh0 = rng.uniform(-1, 1, (C, max(na - 1, 1)))

@@ -21,6 +21,7 @@ case $call in
     for dbg in 3072 1024; do
       ALZ_LIBRARY=$R/tools/variants/libalzhip_lookrace.so ALZ_WAVE_DEBUG=$dbg timeout 300 python tools/look_race_demo.py 20 2>&1 | tee -a $O/look_race_demo.log
     done
+    ALZ_LIBRARY=$R/tools/variants/libalzhip_lookrace.so ALZ_WAVE_DEBUG=4096 timeout 300 python tools/look_check_demo.py 2>&1 | tee $O/look_check_demo.log
     timeout 600 python -m pytest tests/test_gpu_look_soak.py -x -q -s > $O/soak.log 2>&1; echo "soak rc=$?"; tail -25 $O/soak.log
     timeout 600 python -m pytest tests/test_gpu_scan.py -x -q > $O/scan.log 2>&1; echo "scan rc=$?"; tail -5 $O/scan.log
     suite; smoke; driver ;;
@@ -32,6 +33,10 @@ case $call in
              "--channels 1 --log2-samples 22 --comb-delay 441 --layout chan" "--channels 16384 --log2-samples 16 --layout time" "--channels 16384 --log2-samples 16 --layout chan"; do
       echo "== comb $a"; timeout 300 python bench.py --workload comb $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
     done 2>&1 | tee $O/comb_shapes.log
+    echo "== non-temporal loads / stores (variant build -DALZ_COMB_NT=1)" | tee -a $O/comb_shapes.log
+    for a in "--layout time" "--layout chan" "--channels 16384 --log2-samples 16 --layout time"; do
+      echo "== nt $a"; ALZ_LIBRARY=$R/tools/variants/libalzhip_combnt.so timeout 300 python bench.py --workload comb $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+    done 2>&1 | tee -a $O/comb_shapes.log
     echo "== round 1's k_sparse on the same shapes (tuning build, ALZ_COMB_OFF=1)" | tee -a $O/comb_shapes.log
     for a in "--layout time" "--channels 1 --log2-samples 20 --comb-delay 109 --comb-linearized --layout time"; do
       echo "== k_sparse $a"; ALZ_COMB_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 300 python bench.py --workload comb $a $B --no-parity-check > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
