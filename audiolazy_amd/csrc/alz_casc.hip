@@ -781,11 +781,13 @@ static constexpr int kPXRing = 7;   // x ring: six 8 KiB tiles in flight per wor
 // per-wave cycle accounting (variant builds only; a clock read also waits for the wave's outstanding LDS operations, so
 // "work" includes the drain): work = barrier exit -> barrier entry, wait = inside the barrier; the wave that waits
 // least is the one the interval waits for
-#define PIPE_CLOCK_DECL long long pc_work = 0, pc_wait = 0, pc_last = __builtin_readcyclecounter(); long long pc_n = 0;
+#define PIPE_CLOCK_DECL long long pc_work = 0, pc_wait = 0, pc_last = __builtin_readcyclecounter(); long long pc_n = 0; \
+    const long long pc_c0 = pc_last, pc_w0 = wall_clock64();
 #define PIPE_BARRIER() do { const long long c0_ = __builtin_readcyclecounter(); if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier(); \
     const long long c1_ = __builtin_readcyclecounter(); pc_work += c0_ - pc_last; pc_wait += c1_ - c0_; pc_last = c1_; ++pc_n; } while (0)
-#define PIPE_CLOCK_REPORT() do { if (blockIdx.x == 5 && lane == 0) printf("k_pipe wave %d: %.1f cycles of work + %.1f in the barrier per interval (%lld intervals)\n", \
-    wave, (double)pc_work / (double)pc_n, (double)pc_wait / (double)pc_n, pc_n); } while (0)
+#define PIPE_CLOCK_REPORT() do { if ((blockIdx.x == 5 || blockIdx.x == 200) && lane == 0) printf("k_pipe block %d wave %d: %.1f cycles of work + %.1f in the barrier per interval (%lld intervals); shader clock %.0f MHz over the launch (cycle counter against the 100 MHz wall clock)\n", \
+    (int)blockIdx.x, wave, (double)pc_work / (double)pc_n, (double)pc_wait / (double)pc_n, pc_n, \
+    (double)(__builtin_readcyclecounter() - pc_c0) / ((double)(wall_clock64() - pc_w0) / 100.0)); } while (0)
 #else
 #define PIPE_CLOCK_DECL
 #define PIPE_CLOCK_REPORT() do {} while (0)

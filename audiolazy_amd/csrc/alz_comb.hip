@@ -109,14 +109,14 @@ __global__ __launch_bounds__(64) void k_sparse(SArgs p) {
 }
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-#ifndef ALZ_COMB_NT
-#define ALZ_COMB_NT 0      // variant builds: 1 = non-temporal input loads and output stores (A/B: profiles/NOTES_r06.md 2)
-#endif
+// NT (a template parameter of both step kernels): non-temporal input loads and output stores for blocks of 256 MiB and more --
+// measured +9 % time-major, +6 % channel-major, +10 % at 16 384 channels on the 4096-channel x 2^18 bank (round 6, call 4:
+// profiles/r06_comb_shapes.log); smaller blocks, whose result the next call finds in the Infinity Cache, keep the default.
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_comb_tm: time-major.  blockDim = 8 P threads (P rows per pass, a multiple of 8: whole waves), T = P U rows per step.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NFF, int NFB, int U>
+template <int NFF, int NFB, int U, bool NT>
 __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = (int)threadIdx.x, cp = tid & 7, r = tid >> 3;
@@ -159,11 +159,8 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
   auto xrow = [&](int64_t t) -> dbl2 {
     t = t < N ? t : N - 1;
     const double *src = t >= 0 ? xb + t * sxn : xhb + (-t - 1) * C;
-#if ALZ_COMB_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(src));
-#else
-    return *reinterpret_cast<const dbl2 *>(src);
-#endif
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const dbl2 *>(src));
+    else return *reinterpret_cast<const dbl2 *>(src);
   };
   dbl2 xv[U][NFF > 0 ? NFF : 1];
 #pragma unroll
@@ -201,11 +198,8 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
     for (int u = 0; u < U; ++u) {
       const int64_t n = n0 + r + P * u;
       if (n < N) {
-#if ALZ_COMB_NT
-        __builtin_nontemporal_store(acc[u], reinterpret_cast<dbl2 *>(yb + n * syn));
-#else
-        *reinterpret_cast<dbl2 *>(yb + n * syn) = acc[u];
-#endif
+        if constexpr (NT) __builtin_nontemporal_store(acc[u], reinterpret_cast<dbl2 *>(yb + n * syn));
+        else *reinterpret_cast<dbl2 *>(yb + n * syn) = acc[u];
         if constexpr (NFB > 0) {
           int w = q0 + r + P * u;
           w -= w >= R ? R : 0;
@@ -228,31 +222,23 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr int kCombChunk = 256;   // samples per chunk of the wave's global traffic (two 1 KiB transfers)
 
+template <bool NT>
 __device__ __forceinline__ void comb_dma16(const void *gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-#if ALZ_COMB_NT
-      "global_load_lds_dwordx4 %1, off nt\n\t"
-#else
-      "global_load_lds_dwordx4 %1, off\n\t"
-#endif
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+template <bool NT>
 __device__ __forceinline__ void comb_store16(double *gdst, dbl2 v) {
-#if ALZ_COMB_NT
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
-#else
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
-#endif
+  if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(gdst), "v"(v) : "memory");
 }
 
-template <int NFF, int NFB, int U>
+template <int NFF, int NFB, int U, bool NT>
 __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = kCombChunk;
@@ -295,7 +281,7 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
     if (t0 + CH <= p.n) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i)
-        comb_dma16(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & MX) * 8));
+        comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & MX) * 8));
     } else {
       for (int64_t t = t0 + lane; t < p.n; t += 64) xr[(int)t & MX] = xc[t];
     }
@@ -333,7 +319,7 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i) {
         const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & MY]);
-        comb_store16(yc + t0 + 128 * i + 2 * lane, v);
+        comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
       }
     } else {
       for (int64_t t = t0 + lane; t < p.n; t += 64) yc[t] = yr[(int)t & MY];
@@ -365,26 +351,26 @@ __global__ void k_copy_rows(double *dst, const double *src, int64_t count, int64
 }
 
 typedef void (*comb_fn)(SArgs);
-template <int NFF, int NFB>
+template <int NFF, int NFB, bool NT>
 static comb_fn pick_tm_u(int u) {
   switch (u) {
-    case 1: return (comb_fn)k_comb_tm<NFF, NFB, 1>;
-    case 2: return (comb_fn)k_comb_tm<NFF, NFB, 2>;
-    case 4: return (comb_fn)k_comb_tm<NFF, NFB, 4>;
-    default: return (comb_fn)k_comb_tm<NFF, NFB, 6>;
+    case 1: return (comb_fn)k_comb_tm<NFF, NFB, 1, NT>;
+    case 2: return (comb_fn)k_comb_tm<NFF, NFB, 2, NT>;
+    case 4: return (comb_fn)k_comb_tm<NFF, NFB, 4, NT>;
+    default: return (comb_fn)k_comb_tm<NFF, NFB, 6, NT>;
   }
 }
-template <int NFF, int NFB>
+template <int NFF, int NFB, bool NT>
 static comb_fn pick_cm_u(int u) {
   switch (u) {
-    case 1: return (comb_fn)k_comb_cm<NFF, NFB, 1>;
-    case 2: return (comb_fn)k_comb_cm<NFF, NFB, 2>;
-    default: return (comb_fn)k_comb_cm<NFF, NFB, 4>;
+    case 1: return (comb_fn)k_comb_cm<NFF, NFB, 1, NT>;
+    case 2: return (comb_fn)k_comb_cm<NFF, NFB, 2, NT>;
+    default: return (comb_fn)k_comb_cm<NFF, NFB, 4, NT>;
   }
 }
-static comb_fn pick_comb(bool cm, int nff, int nfb, int u) {
-#define ALZ_COMB(F, B) if (nff == F && nfb == B) return cm ? pick_cm_u<F, B>(u) : pick_tm_u<F, B>(u);
-  // comb.fb / comb.tau, their linearize()d forms and karplus_strong; comb.ff and its linearize()d form; a numerator pair in front of either
+static comb_fn pick_comb(bool cm, int nff, int nfb, int u, bool nt = false) {
+#define ALZ_COMB(F, B) if (nff == F && nfb == B) return cm ? (nt ? pick_cm_u<F, B, true>(u) : pick_cm_u<F, B, false>(u)) : (nt ? pick_tm_u<F, B, true>(u) : pick_tm_u<F, B, false>(u));
+  // comb.fb / comb.tau, their linearize()d forms and karplus_strong; comb.ff and its linearize()d form; a numerator pair or triple in front of either
   ALZ_COMB(1, 1) ALZ_COMB(1, 2) ALZ_COMB(2, 0) ALZ_COMB(3, 0) ALZ_COMB(2, 1) ALZ_COMB(2, 2) ALZ_COMB(3, 1) ALZ_COMB(3, 2)
 #undef ALZ_COMB
   return nullptr;
@@ -478,7 +464,8 @@ int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, 
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const int64_t nx = (int64_t)(sec.nb - 1) * io.channels, ny = (int64_t)(sec.na - 1) * io.channels;
   double *xh_new = sec.xh + nx, *yh_new = sec.yh + ny;
-  comb_fn fn = pl.ok ? pick_comb(pl.cm, sec.n_ff, sec.n_fb, pl.u) : nullptr;
+  const bool nt = (uint64_t)io.n * (uint64_t)io.c_count * 8u >= (256ull << 20);
+  comb_fn fn = pl.ok ? pick_comb(pl.cm, sec.n_ff, sec.n_fb, pl.u, nt) : nullptr;
   if (fn) {
     if (pl.lds > 0) {
       const int rc = ensure_dynamic_lds((const void *)fn, (int)pl.lds);

@@ -42,7 +42,7 @@ def test_single_gpu_line_with_cpu_baseline():
   cpu = line["cpu_baseline"]
   assert {"value", "unit", "cores", "kind", "sample", "legs"} <= set(cpu) and cpu["kind"] in ("port", "reference")
   assert 1 <= cpu["cores"] <= os.cpu_count() and cpu["host_logical_cpus"] == os.cpu_count()
-  assert set(cpu["legs"]) == {"py_1proc", "py_pool", "py_rows", "c_port"}
+  assert set(cpu["legs"]) == {"py_1proc", "py_pool", "py_rows", "c_port", "py_comb_1proc"}
   assert all(leg > 0 for leg in cpu["legs"].values())          # (the compact line keeps the legs' values only)
   # the interpreter path is orders of magnitude below the C port of the same statement
   assert cpu["legs"]["py_1proc"] < cpu["legs"]["c_port"]

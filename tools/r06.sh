@@ -41,6 +41,18 @@ case $call in
     for a in "--layout time" "--channels 1 --log2-samples 20 --comb-delay 109 --comb-linearized --layout time"; do
       echo "== k_sparse $a"; ALZ_COMB_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 300 python bench.py --workload comb $a $B --no-parity-check > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
     done 2>&1 | tee -a $O/comb_shapes.log ;;
+  pipe)    # configs[3] k_pipe: SQ counters of the shipped kernel (one pass per set), per-wave cycle accounting and the shader clock
+           # of THIS box under the kernel's load (-DALZ_ABLATE -DALZ_PIPE_TIMING variant), the same for the headline kernel's box rate
+    G="--workload gammatone --no-cpu-baseline --no-secondary --no-parity-check --steps 6 --warmup 2 --full-json -"
+    timeout 300 python bench.py --workload gammatone --no-cpu-baseline --no-secondary --steps 10 --warmup 2 --full-json - > $O/g.json 2> $O/g.err; python tools/show_line.py $O/g.json | head -1 | cut -c1-200 | tee $O/pipe_rate.log
+    ALZ_LIBRARY=$R/tools/variants/libalzhip_pipetiming.so timeout 300 python bench.py $G 2>&1 | grep "k_pipe block" | sort | uniq -c | sort -rn | head -12 | tee $O/pipe_timing.log
+    for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
+               "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE" \
+               "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAVES"; do
+      tag=$(echo $set | cut -d' ' -f1)
+      (cd /tmp; timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- python $R/bench.py $G > $O/pmc_$tag.log 2>&1)
+      python tools/pmc_summary.py $O/pmc_$tag 2>&1 | grep -A12 "k_pipe" | head -14 | tee -a $O/pipe_pmc.txt; rm -rf $O/pmc_$tag
+    done ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
