@@ -725,6 +725,8 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
           h->look_launches += 1;
         }
       }
+      if (done_c == 0 && whole) rc = alz::launch_mid(sec, io, st, &done_n, &done_c, &name);
+      if (rc) return rc;
       if (done_c == 0 && !generic && whole) rc = alz::launch_wave(sec, io, st, &done_n, &done_c, &name);
       if (rc) return rc;
       if (done_c > 0) note(name);

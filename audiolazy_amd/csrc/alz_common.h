@@ -131,6 +131,10 @@ bool comb_takes_in_place(const SectionDev &sec, const BlockIO &io);
 // the shape was this kernel's
 int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, bool *taken,
                const char **kernel_name);
+// alz_mid.hip: one-section IIR filters of order 3 .. 8 (dense coefficients) and short numerators with one far tap
+// (maverage.recursive) as a three-wave streaming kernel on time-major blocks; reports what it covered like launch_wave
+int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int64_t *done_samples, int64_t *done_channels,
+               const char **kernel_name);
 // alz_wave.hip: the streaming kernel takes the full tiles of the full channel groups it
 // can and reports how much that was; the caller finishes the rest with launch_section
 int launch_wave(const SectionDev &sec, const BlockIO &io, hipStream_t stream,

@@ -776,6 +776,58 @@ def wl_comb(ctx, args, alz, C, N, D, steps, warmup, layout="time", linearized=Fa
           "C": C, "N": N}
 
 
+def wl_mid(ctx, args, alz, C, N, steps, warmup, kind="butter6"):
+  """One-section filters between "biquad" and "long FIR" (csrc/alz_mid.hip): `butter6` = ZFilter(butter(6, cutoff)) per channel
+  as the reference's examples/butterworth_with_noise.py:52-67 builds it (nb = na = 7, one section: the recurrence is one multiply
+  and six dependent additions per sample -- chain-bound); `maverage256` = maverage.recursive(256) (lazy_analysis.py:569-591:
+  b0 = 1/256, b256 = -1/256, a1 = -1: HBM-bound)."""
+  torch = ctx.torch
+  if kind == "butter6":
+    from scipy import signal
+    ba = [signal.butter(6, wn) for wn in np.linspace(0.08, 0.6, C)]
+    b, a = np.array([v[0] for v in ba]), np.array([v[1] for v in ba])
+  else:
+    b = np.zeros(257)
+    b[0], b[256] = 1.0 / 256, -1.0 / 256
+    a = np.array([1.0, -1.0])
+  nb, na = b.shape[-1], a.shape[-1]
+  bank = alz.FilterBank([(b, a)], n_inputs=C, device=ctx.local)
+  bank.reset()
+  x = ctx.noise((N, C), 9)
+  y = torch.empty_like(x)
+  elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="time", out=y), steps, warmup)
+  kernel = bank.last_kernel
+  parity = "skipped (--no-parity-check)"
+  if ctx.rank == 0 and not args.no_parity_check:
+    from oracle import oracle
+    nchk = min(N, 2048)
+    bank.reset()
+    got = bank.process(x[:nchk].contiguous(), layout="time").cpu().numpy()
+    ref = oracle.bank([nb], [na], b, a, x[:nchk].cpu().numpy(), layout="time")
+    parity = "bit-exact vs oracle, %d channels x %d samples" % (C, nchk) if bits_equal(got, ref) else "MISMATCH"
+    if N > nchk and not parity.startswith("MISMATCH"):
+      bank.reset()
+      bank.process(x, layout="time", out=y)
+      pick = np.unique(np.linspace(0, C - 1, min(C, 16)).astype(int))
+      idx = torch.from_numpy(pick).to(ctx.dev)
+      got = y.index_select(1, idx).cpu().numpy()
+      ref = oracle.bank([nb], [na], b[pick] if b.ndim == 2 else b, a[pick] if a.ndim == 2 else a,
+                        x.index_select(1, idx).cpu().numpy(), layout="time")
+      parity += ("; full block length: %d strided channels x %d samples bit-exact" % (len(pick), N) if bits_equal(got, ref)
+                 else "; MISMATCH on the full block length")
+      if "MISMATCH" in parity:
+        parity = "MISMATCH: " + parity
+  del x, y, bank
+  torch.cuda.empty_cache()
+  roof = hbm_roof(ALG_BYTES_PER_SAMPLE * C * N, k_ms)
+  if kind == "butter6":
+    roof["note"] = ("chain-bound, not HBM-bound: the reference's left-to-right sum puts one multiply and six additions of every "
+                    "sample behind y[n-1] (7 dependent FP64 operations x ~7.5 cycles), so %d channels cannot pass ~%.0f Gsamples/s "
+                    "bit-exactly whatever the kernel" % (C, C * 2.1e9 / 52.5 / 1e9))
+  return {"units": float(C) * N, "elapsed": elapsed, "timing": ctx.last_stats, "kernel": kernel, "parity": parity, "roofline": roof,
+          "C": C, "N": N}
+
+
 def timevar_bank(torch, dev, C, N, per_channel):
   """Coefficients of the time-varying resonator bank: b0[n] x[n] + b2 x[n-2] - a1[n] y[n-1] - a2[n] y[n-2] whose series
   sweep the centre frequency from 200 Hz to 4 kHz at 48 kHz (``resonator.z_exp(Stream(freqs), bw)`` with vector-valued
@@ -969,7 +1021,7 @@ def short_parity(p):
 # The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
 # the tail of the line still holds configs[2..4].
 SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
-                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string",
+                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
                    "timevar_shared", "timevar_per_channel",
                    "gammatone_one_stream", "gammatone_one_stream_time_parallel", "gammatone_one_stream_time_parallel_tm", "lpc_1m", "lpc_1m_bit_identical",
                    "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
@@ -1066,7 +1118,7 @@ def main():
   ap.add_argument("--comb-delay", type=int, default=441, help="--workload comb: the feedback delay in samples")
   ap.add_argument("--comb-linearized", action="store_true", help="--workload comb: two adjacent feedback taps (linearize()d fractional delay)")
   ap.add_argument("--in-place", action="store_true", help="--workload comb: y = x")
-  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar", "comb"], default="biquad",
+  ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar", "comb", "butter6", "maverage256"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")
   args = ap.parse_args()
@@ -1162,6 +1214,12 @@ def main():
         secondary["karplus_one_string"] = entry(r, 1, 5, "Gsamples/s", "ONE Karplus-Strong string (lazy_synth.py:624-657: comb.tau(...).linearize(), "
                                                 "two adjacent feedback taps at 109 / 110 samples) x 2^22 samples: the reference's own use "
                                                 "(examples/ode_to_joy.py:84)", key="karplus_one_string")
+        r = wl_mid(ctx, args, alz, 4096, 1 << 18, 5, 1, kind="butter6")
+        secondary["iir_order6"] = entry(r, 1, 5, "Gsamples/s", "ZFilter(butter(6, cutoff)) as ONE section (examples/butterworth_with_noise.py:52-67) "
+                                        "x 4096 channels x 2^18 samples", key="iir_order6")
+        r = wl_mid(ctx, args, alz, 4096, 1 << 18, 5, 1, kind="maverage256")
+        secondary["maverage_recursive_256"] = entry(r, 1, 5, "Gsamples/s", "maverage.recursive(256) (lazy_analysis.py:569-591) x 4096 channels x 2^18 "
+                                                    "samples", key="maverage_recursive_256")
         r = wl_timevar(ctx, args, alz, 4096, 1 << 18, 5, 1)
         secondary["timevar_shared"] = entry(r, 1, 5, "Gsamples/s", "time-varying resonator bank: 4096 channels x 2^18 samples "
                                             "steered by three coefficient series shared by the channels (Stream coefficients, "
@@ -1232,6 +1290,16 @@ def main():
     config = {"workload": "comb.tau x %d channels, delay %d%s, float64, %d-sample blocks%s" % (
                   C, args.comb_delay, " (linearized: two taps)" if args.comb_linearized else "", N, ", in place" if args.in_place else ""),
               "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]" if args.layout == "time" else "channel-major [C, N]",
+              "kernel": res["kernel"], "parity_spot_check": res["parity"]}
+    roof = res["roofline"]
+  elif args.workload in ("butter6", "maverage256"):
+    if (C, N) == (4096, 1 << 20):
+      N = 1 << 18
+    res = wl_mid(ctx, args, alz, C, N, args.steps, args.warmup, kind=args.workload)
+    total_units = float(world) * C * N
+    metric, unit = "Gsamples/s through a bank of one-section filters (%s)" % args.workload, "Gsamples/s"
+    config = {"workload": "%s x %d channels, float64, %d-sample blocks" % (args.workload, C, N),
+              "channels_per_gpu": C, "block_samples": N, "layout": "time-major [N, C]",
               "kernel": res["kernel"], "parity_spot_check": res["parity"]}
     roof = res["roofline"]
   elif args.workload == "timevar":

@@ -53,6 +53,13 @@ case $call in
       (cd /tmp; timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- python $R/bench.py $G > $O/pmc_$tag.log 2>&1)
       python tools/pmc_summary.py $O/pmc_$tag 2>&1 | grep -A12 "k_pipe" | head -14 | tee -a $O/pipe_pmc.txt; rm -rf $O/pmc_$tag
     done ;;
+  mid)     # k_mid: its tests, the two workloads, the lane-per-channel kernels on the same shapes (tuning build, ALZ_MID_OFF=1)
+    timeout 900 python -m pytest tests/test_gpu_mid.py -x -q > $O/mid_tests.log 2>&1; echo "mid tests rc=$?"; tail -5 $O/mid_tests.log
+    B="--no-cpu-baseline --no-secondary --steps 10 --warmup 2 --full-json -"
+    for a in "--workload butter6" "--workload maverage256" "--workload butter6 --channels 16384 --log2-samples 16" "--workload maverage256 --channels 16384 --log2-samples 16"; do
+      echo "== $a"; timeout 300 python bench.py $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+      echo "== round 5's kernels: $a"; ALZ_MID_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 600 python bench.py $a $B --no-parity-check --steps 3 --warmup 1 > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+    done 2>&1 | tee $O/mid_shapes.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
