@@ -298,7 +298,6 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
   // numerator: dense b_0 .. b_{NB-1}, optionally one far tap behind it
   int nbd = 0, far_delay = 0;
   bool far = false;
-  if (sec.n_ff < 1) return ALZ_OK;
   if (sec.nb <= 9 && sec.present_b == (1u << sec.nb) - 1u) {
     nbd = sec.nb;
   } else if (sec.n_ff >= 2 && sec.n_ff <= 3) {

@@ -60,6 +60,14 @@ case $call in
       echo "== $a"; timeout 300 python bench.py $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
       echo "== round 5's kernels: $a"; ALZ_MID_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 600 python bench.py $a $B --no-parity-check --steps 3 --warmup 1 > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
     done 2>&1 | tee $O/mid_shapes.log ;;
+  pipelong) # configs[3]: the same kernel timed as 12 launches on a cold chip and as 90, alternating (NOTES_r06.md 3: the "box spread")
+    for k in 1 2 3; do
+      for a in "--steps 10 --warmup 2" "--steps 60 --warmup 30"; do
+        timeout 300 python bench.py --workload gammatone --no-cpu-baseline --no-secondary --no-parity-check $a --full-json - > $O/g.json 2> $O/g.err
+        echo "$a: $(python tools/show_line.py $O/g.json | head -1 | cut -c1-90)"
+      done
+    done 2>&1 | tee $O/pipe_long.log ;;
+  asan)    bash tools/asan_check.sh gpu 2>&1 | tee $O/asan_gpu.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
