@@ -327,6 +327,154 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_string: one Karplus-Strong string (or a few) -- a step is exactly ONE PERIOD of the delay line, held in registers.
+//
+// y[n] = b0 x[n] + (-a_D) y[n - D] (+ (-a_{D+1}) y[n - D - 1]): with a step of D samples, lane l's slot u is sample
+// k D + 64 u + l of step k, and y[n - D] is the SAME lane's slot of the step before -- a register.  The second tap of a
+// linearize()d delay (lazy_filters.py:339-373) is that register's left neighbour: one wavefront shift (v_mov_b32_dpp
+// wave_shr:1, two per double), lane 0 of a slot taking lane 63 of the slot before it and, for the period's first sample,
+// the period's LAST sample of two steps ago.  The LDS round trip that k_comb_cm has between a step and the next is gone
+// from the chain: a step costs its own ~15 instructions per slot.  x still arrives by 1 KiB global -> LDS transfers ahead
+// of the steps and y leaves from an LDS ring in 1 KiB stores (both off the chain).  D <= 512 (eight slots), numerator b0
+// alone, channel-major rows / single strings.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shr1(double v, double lane0) {
+  // every lane takes its left neighbour's v; lane 0 takes lane0 (wave-uniform)
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_of(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void comb_wait_vm(int n) {    // at most n vector-memory operations outstanding (n even; rounded down)
+  switch (n >> 1) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+template <int NFB, int U, bool NT>
+__global__ __launch_bounds__(256) void k_string(SArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = kCombChunk;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)threadIdx.x & 63;
+  const int wpb = (int)blockDim.x >> 6;
+  const int64_t c = p.c_first + (int64_t)blockIdx.x * wpb + wave;
+  if (c >= p.c_end) return;                                             // (no barriers in this kernel)
+  int64_t in, set;
+  if (p.mode == ALZ_BANK_OUTER) {
+    in = p.map_input ? c % p.n_inputs : c;
+    set = c / p.n_inputs;
+  } else {
+    in = c;
+    set = (p.n_sets == 1) ? 0 : c;
+  }
+  const int D = p.ka[0];
+  const double b0 = p.b[set];
+  const double na1 = -p.a[(int64_t)D * p.n_sets + set];
+  double na2 = 0.0;
+  if constexpr (NFB == 2) na2 = -p.a[(int64_t)(D + 1) * p.n_sets + set];
+  const int R = p.ring, M = R - 1;                                      // one size for both rings (a power of two): one index serves both
+  double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * 2 * R;
+  double *yr = xr + R;
+  const unsigned xr_lds = (unsigned)(uintptr_t)xr;
+  const double *xc = p.x + in * p.sxc;
+  double *yc = p.y + c * p.syc;
+  const int64_t N = p.n;
+  const int last_lane = (D - 1) & 63;
+  // the period before the block: slot u of lane l is y[-D + 64 u + l] = yh[D - 1 - 64 u - l]
+  double prev[U], old_last = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = 64 * u + lane;
+    prev[u] = idx < D ? p.yh[(int64_t)(D - 1 - idx) * p.channels + c] : 0.0;
+  }
+  if constexpr (NFB == 2) old_last = p.yh[(int64_t)D * p.channels + c];   // y[-D-1]
+  const int64_t n_chunks = (N + CH - 1) / CH;
+  // vector-memory operations are issued in groups of two (a chunk's transfers, a chunk's stores) or, for the ragged last
+  // chunk, by the compiler (waited for in full); `seq` counts the groups, seq_of[c & 7] remembers a fetch's number
+  int seq = 0, seq_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t fetched = 0, landed = 0, stored = 0;
+  bool ragged_in_flight = false;
+  auto fetch = [&](int64_t k) {
+    const int64_t t0 = k * CH;
+    if (t0 + CH <= N) {
+#pragma unroll
+      for (int i = 0; i < CH / 128; ++i)
+        comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & M) * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) seq_of[j] = (j == ((int)k & 7)) ? seq : seq_of[j];
+      ++seq;
+    } else {
+      for (int64_t t = t0 + lane; t < N; t += 64) xr[(int)t & M] = xc[t];
+      ragged_in_flight = true;
+    }
+  };
+  auto store_chunk = [&](int64_t k) {
+    const int64_t t0 = k * CH;
+    if (t0 + CH <= N) {
+#pragma unroll
+      for (int i = 0; i < CH / 128; ++i) {
+        const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & M]);
+        comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
+      }
+      ++seq;
+    } else {
+      for (int64_t t = t0 + lane; t < N; t += 64) yc[t] = yr[(int)t & M];
+    }
+  };
+  for (; fetched < n_chunks && fetched < 3; ++fetched) fetch(fetched);     // (three chunks ahead of the stores: the rings hold four)
+  for (int64_t n0 = 0; n0 < N; n0 += D) {
+    const int rem = N - n0 < D ? (int)(N - n0) : D;
+    // the chunks this step reads must have landed
+    const int64_t need = (n0 + rem - 1) / CH;
+    while (landed <= need) {
+      int sq = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sq = (j == ((int)landed & 7)) ? seq_of[j] : sq;
+      if (ragged_in_flight || (landed + 1) * CH > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else comb_wait_vm(2 * (seq - sq - 1));
+      ++landed;
+    }
+    double carry = old_last, nxt[U];
+    if constexpr (NFB == 2) old_last = lane_of(prev[U - 1], last_lane);   // the period's last sample, before this step replaces it
+    const int tb = (int)n0 + lane;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = 64 * u + lane;
+      const int at = (tb + 64 * u) & M;
+      double v = prev[u], left = 0.0;
+      if constexpr (NFB == 2) {                                         // (with every lane active: the shift reads its neighbour's register)
+        left = shr1(prev[u], carry);
+        carry = lane_of(prev[u], 63);
+      }
+      if (idx < rem) {
+        v = b0 * xr[at] + na1 * prev[u];
+        if constexpr (NFB == 2) v = v + na2 * left;
+        yr[at] = v;
+      }
+      nxt[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) prev[u] = nxt[u];
+    // finished chunks leave; the ring then has room for more input
+    while ((stored + 1) * CH <= n0 + rem) {
+      store_chunk(stored);
+      ++stored;
+      if (fetched < n_chunks) { fetch(fetched); ++fetched; }
+    }
+  }
+  if (stored < n_chunks) store_chunk(stored);                             // the ragged last chunk
+}
+
 // histories after the block, for both delay lines (written to the spare halves of the slabs)
 __global__ void k_sparse_state(SArgs p, double *xh_new, double *yh_new, int do_x, int do_y) {
   const int64_t c = p.c_first + (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -376,7 +524,25 @@ static comb_fn pick_comb(bool cm, int nff, int nfb, int u, bool nt = false) {
   return nullptr;
 }
 
+template <int NFB, bool NT>
+static comb_fn pick_string_u(int u) {
+  switch (u) {
+    case 1: return (comb_fn)k_string<NFB, 1, NT>;
+    case 2: return (comb_fn)k_string<NFB, 2, NT>;
+    case 3: return (comb_fn)k_string<NFB, 3, NT>;
+    case 4: return (comb_fn)k_string<NFB, 4, NT>;
+    case 5: return (comb_fn)k_string<NFB, 5, NT>;
+    case 6: return (comb_fn)k_string<NFB, 6, NT>;
+    case 7: return (comb_fn)k_string<NFB, 7, NT>;
+    default: return (comb_fn)k_string<NFB, 8, NT>;
+  }
+}
+static comb_fn pick_string(int nfb, int u, bool nt) {
+  return nfb == 1 ? (nt ? pick_string_u<1, true>(u) : pick_string_u<1, false>(u)) : (nt ? pick_string_u<2, true>(u) : pick_string_u<2, false>(u));
+}
+
 struct CombPlan {
+  bool string = false;              // k_string: a period of the delay line in registers
   bool ok = false, cm = false;
   int u = 1, threads = 0, T = 0, ring = 0, xring = 0;
   size_t lds = 0;
@@ -400,6 +566,15 @@ static CombPlan plan_comb(const SectionDev &sec, const BlockIO &io) {
   if (cm) {
     // a wave per channel; 16-byte pieces of a channel's row
     if (io.channels > 1 && ((io.sxc | io.syc) & 1)) return pl;
+    // a few strings whose period fits a wave's registers: steps of one period, no LDS round trip between them
+    if (io.c_count <= 256 && dmin <= 512 && sec.n_ff == 1 && sec.tap_b[0] == 0 && sec.n_fb >= 1 &&
+        (sec.n_fb == 1 || sec.tap_a[1] == sec.tap_a[0] + 1) && !ALZ_TUNE("ALZ_STRING_OFF", 0)) {
+      int wpb = io.c_count < 4 ? (int)io.c_count : 4;
+      pl.ok = true; pl.cm = true; pl.string = true; pl.u = (dmin + 63) / 64; pl.threads = 64 * wpb; pl.T = dmin; pl.ring = 4 * kCombChunk; pl.xring = pl.ring;
+      pl.lds = (size_t)2 * pl.ring * 8 * wpb;
+      pl.grid = (unsigned)((io.c_count + wpb - 1) / wpb);
+      return pl;
+    }
     int u = dmin >= 256 ? 4 : dmin > 64 ? 2 : 1;
     if (u == 2 && dmin > 128) u = 4;
     int T = dmin < 64 * u ? dmin : 64 * u;
@@ -465,14 +640,14 @@ int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, 
   const int64_t nx = (int64_t)(sec.nb - 1) * io.channels, ny = (int64_t)(sec.na - 1) * io.channels;
   double *xh_new = sec.xh + nx, *yh_new = sec.yh + ny;
   const bool nt = (uint64_t)io.n * (uint64_t)io.c_count * 8u >= (256ull << 20);
-  comb_fn fn = pl.ok ? pick_comb(pl.cm, sec.n_ff, sec.n_fb, pl.u, nt) : nullptr;
+  comb_fn fn = !pl.ok ? nullptr : pl.string ? pick_string(sec.n_fb, pl.u, nt) : pick_comb(pl.cm, sec.n_ff, sec.n_fb, pl.u, nt);
   if (fn) {
     if (pl.lds > 0) {
       const int rc = ensure_dynamic_lds((const void *)fn, (int)pl.lds);
       if (rc) return rc;
     }
     hipLaunchKernelGGL(fn, dim3(pl.grid), dim3((unsigned)pl.threads), pl.lds, stream, p);
-    *kernel_name = pl.cm ? "k_comb_cm" : "k_comb_tm";
+    *kernel_name = pl.string ? "k_string" : pl.cm ? "k_comb_cm" : "k_comb_tm";
   } else {
     if (!sparse_ok) return ALZ_OK;
     hipLaunchKernelGGL(k_sparse, dim3(gx), dim3(64), 0, stream, p);

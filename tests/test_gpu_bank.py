@@ -440,10 +440,10 @@ def _comb_case(shape, D, C, rng):
   return b, a
 
 
-@pytest.mark.parametrize("layout", ["time", "chan"])
+@pytest.mark.parametrize("layout,C", [("time", 48), ("chan", 48), ("chan", 272)])
 @pytest.mark.parametrize("shape,D", [("fb", 16), ("fb", 441), ("fb", 700), ("lin", 24), ("lin", 109), ("lin", 441), ("ff", 441),
                                        ("fflin", 70), ("mixed", 109), ("mixed", 300)])
-def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, layout, shape, D):
+def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, layout, C, shape, D):
   """Round 6: k_comb_tm / k_comb_cm (csrc/alz_comb.hip) -- the comb family of lazy_filters.py:1087-1173 and its
   linearize()d forms (:339-373) on time-major and channel-major blocks, out of place and (single numerator tap) in place,
   over blocks that are longer than, equal to and shorter than a step / a chunk / the delay line, with a non-trivial delay
@@ -451,7 +451,6 @@ def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, 
   continuous run, asserting the kernel taken."""
   import torch
   rng = np.random.default_rng(D + len(shape))
-  C = 48
   tm = layout == "time"
   ax = 0 if tm else 1
   b, a = _comb_case(shape, D, C, rng)
@@ -461,7 +460,8 @@ def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, 
   xh0 = rng.uniform(-1, 1, (C, max(nb - 1, 1)))
   yh0 = rng.uniform(-1, 1, (C, max(na - 1, 1)))
   ref = oracle.bank([nb], [na], b, a, np.concatenate(xs, axis=ax), layout=layout, xh=xh0.copy(), yh=yh0.copy())
-  want = "k_comb_tm" if tm else "k_comb_cm"
+  # channel-major: up to 256 strings whose period fits a wave's registers (D <= 512, numerator b0 alone) take k_string
+  want = "k_comb_tm" if tm else "k_string" if (C <= 256 and D <= 512 and shape in ("fb", "lin")) else "k_comb_cm"
   for inplace in ((False, True) if nb == 1 else (False,)):
     bank = alz.FilterBank([(b, a)], n_inputs=C)
     bank.set_state(xh0, yh0)
@@ -476,7 +476,7 @@ def test_comb_step_kernels_both_layouts_in_place_and_across_blocks(alz, oracle, 
       at += m
 
 
-@pytest.mark.parametrize("D", [16, 63, 64, 109, 257, 1000, 3000])
+@pytest.mark.parametrize("D", [16, 63, 64, 65, 109, 128, 257, 441, 512, 513, 1000, 3000])
 def test_one_string_lanes_over_the_delay(alz, oracle, D):
   """A single Karplus-Strong string (lazy_synth.py:624-657: comb.tau(...).linearize()(zeros(), memory=white_noise)): one
   channel, lanes over the delay line (k_comb_cm), as [1, N] and as the reference's [N, 1] column, from a noise-filled
@@ -486,8 +486,8 @@ def test_one_string_lanes_over_the_delay(alz, oracle, D):
   b, a = _comb_case("lin", D, 1, rng)
   na = a.shape[1]
   yh0 = rng.uniform(-1, 1, (1, na - 1))
-  lens = [5 * D + 10, 700, 66]
-  xs = [np.zeros(lens[0]), rng.uniform(-1e-3, 1e-3, lens[1]), np.zeros(lens[2])]
+  lens = [5 * D + 10, 700, 66, 2 * D, 256 * 3]
+  xs = [np.zeros(lens[0]), rng.uniform(-1e-3, 1e-3, lens[1]), np.zeros(lens[2]), rng.uniform(-1, 1, lens[3]), np.zeros(lens[4])]
   ref = oracle.bank([1], [na], b, a, np.concatenate(xs)[None, :], layout="chan", yh=yh0.copy())[0]
   for layout in ("chan", "time"):
     for inplace in (False, True):
@@ -497,7 +497,7 @@ def test_one_string_lanes_over_the_delay(alz, oracle, D):
       for x in xs:
         xd = torch.from_numpy(x[None, :] if layout == "chan" else x[:, None]).cuda()
         y = bank.process(xd, layout=layout, out=xd if inplace else None)
-        assert bank.last_kernel == "k_comb_cm", bank.last_kernel
+        assert bank.last_kernel == ("k_string" if D <= 512 else "k_comb_cm"), bank.last_kernel
         assert same_bits(y.cpu().numpy().ravel(), ref[at:at + len(x)]), (D, layout, inplace, at)
         at += len(x)
 

@@ -30,12 +30,12 @@ case $call in
     B="--no-cpu-baseline --no-secondary --steps 10 --warmup 2 --full-json -"
     for a in "--layout time" "--layout chan" "--layout time --in-place" "--layout chan --in-place" "--layout time --comb-linearized" "--layout chan --comb-linearized" \
              "--layout time --comb-delay 64" "--layout chan --comb-delay 64" "--channels 1 --log2-samples 22 --comb-delay 109 --comb-linearized --layout chan" \
-             "--channels 1 --log2-samples 22 --comb-delay 441 --layout chan" "--channels 16384 --log2-samples 16 --layout time" "--channels 16384 --log2-samples 16 --layout chan"; do
+             "--channels 1 --log2-samples 22 --comb-delay 441 --layout chan" "--channels 64 --log2-samples 20 --comb-delay 109 --comb-linearized --layout chan" "--channels 16384 --log2-samples 16 --layout time" "--channels 16384 --log2-samples 16 --layout chan"; do
       echo "== comb $a"; timeout 300 python bench.py --workload comb $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
     done 2>&1 | tee $O/comb_shapes.log
-    echo "== non-temporal loads / stores (variant build -DALZ_COMB_NT=1)" | tee -a $O/comb_shapes.log
-    for a in "--layout time" "--layout chan" "--channels 16384 --log2-samples 16 --layout time"; do
-      echo "== nt $a"; ALZ_LIBRARY=$R/tools/variants/libalzhip_combnt.so timeout 300 python bench.py --workload comb $a $B > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
+    echo "== one string through k_comb_cm (tuning build, ALZ_STRING_OFF=1)" | tee -a $O/comb_shapes.log
+    for a in "--channels 1 --log2-samples 22 --comb-delay 109 --comb-linearized --layout chan" "--channels 1 --log2-samples 22 --comb-delay 441 --layout chan"; do
+      echo "== k_comb_cm $a"; ALZ_STRING_OFF=1 ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so timeout 300 python bench.py --workload comb $a $B --no-parity-check > $O/tmp.json 2> $O/tmp.err || tail -3 $O/tmp.err; python tools/show_line.py $O/tmp.json | head -1 | cut -c1-230
     done 2>&1 | tee -a $O/comb_shapes.log
     echo "== round 1's k_sparse on the same shapes (tuning build, ALZ_COMB_OFF=1)" | tee -a $O/comb_shapes.log
     for a in "--layout time" "--channels 1 --log2-samples 20 --comb-delay 109 --comb-linearized --layout time"; do
