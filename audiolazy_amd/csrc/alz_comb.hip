@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
 // linearize()d delay (lazy_filters.py:339-373) is that register's left neighbour: one wavefront shift (v_mov_b32_dpp
 // wave_shr:1, two per double), lane 0 of a slot taking lane 63 of the slot before it and, for the period's first sample,
 // the period's LAST sample of two steps ago.  The LDS round trip that k_comb_cm has between a step and the next is gone
-// from the chain: a step costs its own ~15 instructions per slot.  x still arrives by 1 KiB global -> LDS transfers ahead
-// of the steps and y leaves from an LDS ring in 1 KiB stores (both off the chain).  D <= 512 (eight slots), numerator b0
+// from the chain: a step costs its own ~15 instructions per slot.  x still arrives by 1 KiB global -> LDS transfers -- TWELVE
+// chunks ahead of the steps: with three (the first build) every chunk was waited for, 1.2 us each, and the kernel was slower
+// than k_comb_cm -- and y leaves from an LDS ring in 1 KiB stores (both off the chain).  D <= 512 (eight slots), numerator b0
 // alone, channel-major rows / single strings.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double shr1(double v, double lane0) {
@@ -349,16 +350,16 @@ __device__ __forceinline__ double lane_of(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 __device__ __forceinline__ void comb_wait_vm(int n) {    // at most n vector-memory operations outstanding (n even; rounded down)
+#define ALZ_VMC(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * k) : "memory"); break;
   switch (n >> 1) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    ALZ_VMC(0) ALZ_VMC(1) ALZ_VMC(2) ALZ_VMC(3) ALZ_VMC(4) ALZ_VMC(5) ALZ_VMC(6) ALZ_VMC(7) ALZ_VMC(8) ALZ_VMC(9) ALZ_VMC(10) ALZ_VMC(11)
+    ALZ_VMC(12) ALZ_VMC(13) ALZ_VMC(14) ALZ_VMC(15) ALZ_VMC(16) ALZ_VMC(17) ALZ_VMC(18) ALZ_VMC(19) ALZ_VMC(20) ALZ_VMC(21) ALZ_VMC(22) ALZ_VMC(23)
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
   }
+#undef ALZ_VMC
 }
+constexpr int kStringAhead = 12;     // chunks of input in flight: a step of one period takes ~0.1 us, a transfer ~2 us to land
+constexpr int kStringXRing = 16 * kCombChunk, kStringYRing = 4 * kCombChunk;
 
 template <int NFB, int U, bool NT>
 __global__ __launch_bounds__(256) void k_string(SArgs p) {
@@ -382,9 +383,9 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
   const double na1 = -p.a[(int64_t)D * p.n_sets + set];
   double na2 = 0.0;
   if constexpr (NFB == 2) na2 = -p.a[(int64_t)(D + 1) * p.n_sets + set];
-  const int R = p.ring, M = R - 1;                                      // one size for both rings (a power of two): one index serves both
-  double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * 2 * R;
-  double *yr = xr + R;
+  constexpr int MX = kStringXRing - 1, MY = kStringYRing - 1;
+  double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * (kStringXRing + kStringYRing);
+  double *yr = xr + kStringXRing;
   const unsigned xr_lds = (unsigned)(uintptr_t)xr;
   const double *xc = p.x + in * p.sxc;
   double *yc = p.y + c * p.syc;
@@ -400,8 +401,8 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
   if constexpr (NFB == 2) old_last = p.yh[(int64_t)D * p.channels + c];   // y[-D-1]
   const int64_t n_chunks = (N + CH - 1) / CH;
   // vector-memory operations are issued in groups of two (a chunk's transfers, a chunk's stores) or, for the ragged last
-  // chunk, by the compiler (waited for in full); `seq` counts the groups, seq_of[c & 7] remembers a fetch's number
-  int seq = 0, seq_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // chunk, by the compiler (waited for in full); `seq` counts the groups, seq_of[c & 15] remembers a fetch's number
+  int seq = 0, seq_of[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int64_t fetched = 0, landed = 0, stored = 0;
   bool ragged_in_flight = false;
   auto fetch = [&](int64_t k) {
@@ -409,12 +410,12 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     if (t0 + CH <= N) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i)
-        comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & M) * 8));
+        comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & MX) * 8));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) seq_of[j] = (j == ((int)k & 7)) ? seq : seq_of[j];
+      for (int j = 0; j < 16; ++j) seq_of[j] = (j == ((int)k & 15)) ? seq : seq_of[j];
       ++seq;
     } else {
-      for (int64_t t = t0 + lane; t < N; t += 64) xr[(int)t & M] = xc[t];
+      for (int64_t t = t0 + lane; t < N; t += 64) xr[(int)t & MX] = xc[t];
       ragged_in_flight = true;
     }
   };
@@ -423,15 +424,15 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     if (t0 + CH <= N) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i) {
-        const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & M]);
+        const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & MY]);
         comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
       }
       ++seq;
     } else {
-      for (int64_t t = t0 + lane; t < N; t += 64) yc[t] = yr[(int)t & M];
+      for (int64_t t = t0 + lane; t < N; t += 64) yc[t] = yr[(int)t & MY];
     }
   };
-  for (; fetched < n_chunks && fetched < 3; ++fetched) fetch(fetched);     // (three chunks ahead of the stores: the rings hold four)
+  for (; fetched < n_chunks && fetched < kStringAhead; ++fetched) fetch(fetched);   // (that far ahead of the stores: the x ring holds sixteen)
   for (int64_t n0 = 0; n0 < N; n0 += D) {
     const int rem = N - n0 < D ? (int)(N - n0) : D;
     // the chunks this step reads must have landed
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     while (landed <= need) {
       int sq = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sq = (j == ((int)landed & 7)) ? seq_of[j] : sq;
+      for (int j = 0; j < 16; ++j) sq = (j == ((int)landed & 15)) ? seq_of[j] : sq;
       if (ragged_in_flight || (landed + 1) * CH > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else comb_wait_vm(2 * (seq - sq - 1));
       ++landed;
@@ -450,16 +451,16 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = 64 * u + lane;
-      const int at = (tb + 64 * u) & M;
+      const int t = tb + 64 * u;
       double v = prev[u], left = 0.0;
       if constexpr (NFB == 2) {                                         // (with every lane active: the shift reads its neighbour's register)
         left = shr1(prev[u], carry);
         carry = lane_of(prev[u], 63);
       }
       if (idx < rem) {
-        v = b0 * xr[at] + na1 * prev[u];
+        v = b0 * xr[t & MX] + na1 * prev[u];
         if constexpr (NFB == 2) v = v + na2 * left;
-        yr[at] = v;
+        yr[t & MY] = v;
       }
       nxt[u] = v;
     }
@@ -570,8 +571,9 @@ static CombPlan plan_comb(const SectionDev &sec, const BlockIO &io) {
     if (io.c_count <= 256 && dmin <= 512 && sec.n_ff == 1 && sec.tap_b[0] == 0 && sec.n_fb >= 1 &&
         (sec.n_fb == 1 || sec.tap_a[1] == sec.tap_a[0] + 1) && !ALZ_TUNE("ALZ_STRING_OFF", 0)) {
       int wpb = io.c_count < 4 ? (int)io.c_count : 4;
-      pl.ok = true; pl.cm = true; pl.string = true; pl.u = (dmin + 63) / 64; pl.threads = 64 * wpb; pl.T = dmin; pl.ring = 4 * kCombChunk; pl.xring = pl.ring;
-      pl.lds = (size_t)2 * pl.ring * 8 * wpb;
+      if (io.c_count >= 16 && wpb > 2) wpb = 2;
+      pl.ok = true; pl.cm = true; pl.string = true; pl.u = (dmin + 63) / 64; pl.threads = 64 * wpb; pl.T = dmin; pl.ring = kStringYRing; pl.xring = kStringXRing;
+      pl.lds = (size_t)(kStringXRing + kStringYRing) * 8 * wpb;
       pl.grid = (unsigned)((io.c_count + wpb - 1) / wpb);
       return pl;
     }

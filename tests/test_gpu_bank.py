@@ -516,7 +516,7 @@ def test_comb_outer_bank_and_wide_block(alz, oracle):
     bank = alz.FilterBank([(b, a)], n_inputs=S, mode="outer")
     bank.reset()
     y = bank.process(torch.from_numpy(x).cuda(), layout=layout).cpu().numpy()
-    assert bank.last_kernel in ("k_comb_tm", "k_comb_cm") or "k_expand" in bank.last_kernel, bank.last_kernel
+    assert bank.last_kernel in ("k_comb_tm", "k_comb_cm", "k_string") or "k_expand" in bank.last_kernel, bank.last_kernel
     for s in range(B):
       xs = x if layout == "time" else x
       r = oracle.bank([1], [D + 1], b[s], a[s], x, layout=layout)
