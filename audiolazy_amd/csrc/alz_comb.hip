@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
   for (int j = 0; j < NFF; ++j) { kb[j] = p.kb[j]; bc[j] = p.b[(int64_t)kb[j] * p.n_sets + set]; }
 #pragma unroll
   for (int j = 0; j < NFB; ++j) { ka[j] = p.ka[j]; nac[j] = -p.a[(int64_t)ka[j] * p.n_sets + set]; }
+  // (in registers NOW: a value the compiler still has in flight when the loop starts gets its s_waitcnt vmcnt(0) INSIDE the loop,
+  // where it drains the transfers queued ahead -- k_string's first build spent 1.2 us per step that way)
+#pragma unroll
+  for (int j = 0; j < NFF; ++j) asm volatile("" : "+v"(bc[j]));
+#pragma unroll
+  for (int j = 0; j < NFB; ++j) asm volatile("" : "+v"(nac[j]));
   const int RX = p.xring, RY = p.ring, MX = RX - 1, MY = RY - 1;        // powers of two
   double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * (RX + RY);   // x[t] at xr[t & MX]
   double *yr = xr + RX;                                                 // y[t] at yr[t & MY]
@@ -399,6 +405,11 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     prev[u] = idx < D ? p.yh[(int64_t)(D - 1 - idx) * p.channels + c] : 0.0;
   }
   if constexpr (NFB == 2) old_last = p.yh[(int64_t)D * p.channels + c];   // y[-D-1]
+  double b0v = b0, na1v = na1;
+  // (everything loaded so far is in registers NOW: see k_comb_cm)
+  asm volatile("" : "+v"(b0v), "+v"(na1v), "+v"(na2), "+v"(old_last));
+#pragma unroll
+  for (int u = 0; u < U; ++u) asm volatile("" : "+v"(prev[u]));
   const int64_t n_chunks = (N + CH - 1) / CH;
   // vector-memory operations are issued in groups of two (a chunk's transfers, a chunk's stores) or, for the ragged last
   // chunk, by the compiler (waited for in full); `seq` counts the groups, seq_of[c & 15] remembers a fetch's number
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
         carry = lane_of(prev[u], 63);
       }
       if (idx < rem) {
-        v = b0 * xr[t & MX] + na1 * prev[u];
+        v = b0v * xr[t & MX] + na1v * prev[u];
         if constexpr (NFB == 2) v = v + na2 * left;
         yr[t & MY] = v;
       }

@@ -951,7 +951,7 @@ def wl_collective(ctx, args, C, n):
 _PMC = None
 
 
-PMC_TABLES = ("r05_pmc_traffic_table.json", "r04_pmc_traffic_table.json", "r03_pmc_traffic_table.json")     # newest first
+PMC_TABLES = ("r06_pmc_traffic_table.json", "r05_pmc_traffic_table.json", "r04_pmc_traffic_table.json", "r03_pmc_traffic_table.json")     # newest first
 
 
 def fill_traffic(roof, key):

@@ -41,3 +41,8 @@ run narrow512_bit_exact --channels 512 --time-parallel 0
 run narrow512_time_parallel --channels 512 --time-parallel 1
 run narrow512_time_parallel_chan --channels 512 --time-parallel 1 --layout chan
 run narrow512_time_parallel_three_launch --channels 512 --time-parallel 8192
+run comb_fb --workload comb
+run comb_fb_chan --workload comb --layout chan
+run karplus_one_string --workload comb --channels 1 --log2-samples 22 --comb-delay 109 --comb-linearized --layout chan
+run iir_order6 --workload butter6
+run maverage_recursive_256 --workload maverage256

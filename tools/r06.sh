@@ -68,6 +68,22 @@ case $call in
       done
     done 2>&1 | tee $O/pipe_long.log ;;
   asan)    bash tools/asan_check.sh gpu 2>&1 | tee $O/asan_gpu.log ;;
+  firvar)  # configs[2]: register tile x occupancy of k_fir_ring (variant builds of alz_fir.hip over the tuning objects)
+    for v in tuning fir_r28w3 fir_r32w3 fir_r20w4 tuning; do
+      for m in "" "--fused"; do
+        ALZ_LIBRARY=$R/tools/variants/libalzhip_$v.so timeout 300 python bench.py --workload fir $m --no-cpu-baseline --steps 6 --warmup 2 --full-json - > $O/f.json 2> $O/f.err || tail -2 $O/f.err
+        echo "$v $m: $(python tools/show_line.py $O/f.json | head -1 | cut -c1-150)"
+      done
+    done 2>&1 | tee $O/fir_variants.log ;;
+  pmc)     # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the workloads named by the regex $1 (default: round 6's new ones)
+    bash tools/pmc_workloads.sh r06_pmc "${1:-comb|karplus|iir_order6|maverage|narrow512_time_parallel}" 2>&1 | tee $O/pmc_workloads.log
+    python tools/pmc_table.py $R/gpurun_out/r06_pmc profiles/r05_pmc_traffic_table.json > $O/r06_pmc_traffic_table.json; python - <<PYEOF
+import json
+t = json.load(open("$O/r06_pmc_traffic_table.json"))["workloads"]
+for k, v in sorted(t.items()):
+  print("%-42s traffic / algorithmic %.4f" % (k, v["traffic_over_algorithmic"]))
+PYEOF
+    ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
