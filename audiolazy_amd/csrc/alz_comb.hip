@@ -341,9 +341,9 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
 // linearize()d delay (lazy_filters.py:339-373) is that register's left neighbour: one wavefront shift (v_mov_b32_dpp
 // wave_shr:1, two per double), lane 0 of a slot taking lane 63 of the slot before it and, for the period's first sample,
 // the period's LAST sample of two steps ago.  The LDS round trip that k_comb_cm has between a step and the next is gone
-// from the chain: a step costs its own ~15 instructions per slot.  x still arrives by 1 KiB global -> LDS transfers -- TWELVE
-// chunks ahead of the steps: with three (the first build) every chunk was waited for, 1.2 us each, and the kernel was slower
-// than k_comb_cm -- and y leaves from an LDS ring in 1 KiB stores (both off the chain).  D <= 512 (eight slots), numerator b0
+// from the chain: a step costs its own ~15 instructions per slot.  x still arrives by 1 KiB global -> LDS transfers, three
+// groups of 1024 samples ahead of the steps, and y leaves from an LDS ring in 1 KiB stores (both off the chain; the first
+// builds did this bookkeeping per 256-sample chunk inside the step loop and were SLOWER than k_comb_cm: ~1100 cycles per step).  D <= 512 (eight slots), numerator b0
 // alone, channel-major rows / single strings.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double shr1(double v, double lane0) {
@@ -364,13 +364,15 @@ __device__ __forceinline__ void comb_wait_vm(int n) {    // at most n vector-mem
   }
 #undef ALZ_VMC
 }
-constexpr int kStringAhead = 12;     // chunks of input in flight: a step of one period takes ~0.1 us, a transfer ~2 us to land
-constexpr int kStringXRing = 16 * kCombChunk, kStringYRing = 4 * kCombChunk;
+// k_string: its transfers and stores go in groups of 1024 samples (eight 1 KiB operations), three groups of input in flight --
+// a step of one period takes ~0.1 us, a transfer ~2 us to land -- so the bookkeeping is per 1024 samples, not per step
+constexpr int kStringChunk = 1024, kStringXRing = 4 * kStringChunk, kStringYRing = 2 * kStringChunk;
 
 template <int NFB, int U, bool NT>
 __global__ __launch_bounds__(256) void k_string(SArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CH = kCombChunk;
+  constexpr int SC = kStringChunk;                                       // samples per group of transfers / stores (eight 1 KiB operations)
+  constexpr int MX = kStringXRing - 1, MY = kStringYRing - 1;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)threadIdx.x & 63;
   const int wpb = (int)blockDim.x >> 6;
@@ -385,17 +387,16 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     set = (p.n_sets == 1) ? 0 : c;
   }
   const int D = p.ka[0];
-  const double b0 = p.b[set];
-  const double na1 = -p.a[(int64_t)D * p.n_sets + set];
+  double b0 = p.b[set];
+  double na1 = -p.a[(int64_t)D * p.n_sets + set];
   double na2 = 0.0;
   if constexpr (NFB == 2) na2 = -p.a[(int64_t)(D + 1) * p.n_sets + set];
-  constexpr int MX = kStringXRing - 1, MY = kStringYRing - 1;
-  double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * (kStringXRing + kStringYRing);
-  double *yr = xr + kStringXRing;
+  double *xr = reinterpret_cast<double *>(smem) + (size_t)wave * (kStringXRing + kStringYRing);   // x[t] at xr[t & MX]
+  double *yr = xr + kStringXRing;                                                                 // y[t] at yr[t & MY]
   const unsigned xr_lds = (unsigned)(uintptr_t)xr;
   const double *xc = p.x + in * p.sxc;
   double *yc = p.y + c * p.syc;
-  const int64_t N = p.n;
+  const int N = (int)p.n;                                               // (the launcher keeps blocks below 2^31 samples)
   const int last_lane = (D - 1) & 63;
   // the period before the block: slot u of lane l is y[-D + 64 u + l] = yh[D - 1 - 64 u - l]
   double prev[U], old_last = 0.0;
@@ -405,86 +406,85 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
     prev[u] = idx < D ? p.yh[(int64_t)(D - 1 - idx) * p.channels + c] : 0.0;
   }
   if constexpr (NFB == 2) old_last = p.yh[(int64_t)D * p.channels + c];   // y[-D-1]
-  double b0v = b0, na1v = na1;
-  // (everything loaded so far is in registers NOW: see k_comb_cm)
-  asm volatile("" : "+v"(b0v), "+v"(na1v), "+v"(na2), "+v"(old_last));
+  // (everything loaded so far is in registers NOW: a value still in flight when the loop starts gets its s_waitcnt vmcnt(0)
+  // INSIDE the loop, where it drains the transfers queued ahead)
+  asm volatile("" : "+v"(b0), "+v"(na1), "+v"(na2), "+v"(old_last));
 #pragma unroll
   for (int u = 0; u < U; ++u) asm volatile("" : "+v"(prev[u]));
-  const int64_t n_chunks = (N + CH - 1) / CH;
-  // vector-memory operations are issued in groups of two (a chunk's transfers, a chunk's stores) or, for the ragged last
-  // chunk, by the compiler (waited for in full); `seq` counts the groups, seq_of[c & 15] remembers a fetch's number
-  int seq = 0, seq_of[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int64_t fetched = 0, landed = 0, stored = 0;
-  bool ragged_in_flight = false;
-  auto fetch = [&](int64_t k) {
-    const int64_t t0 = k * CH;
-    if (t0 + CH <= N) {
+  const int n_sc = (N + SC - 1) / SC, full_sc = N / SC;                   // groups; those that are whole
+  // Vector-memory operations of this wave, in issue order: fetch groups F(k) and store groups S(k) of eight operations each
+  // (whole groups; the ragged last group goes through compiler-issued loads / stores and is simply waited for in full).
+  // F(0..2) up front; after the steps of group k: S(k), then F(k + 3).  F(k) has landed when at most the groups issued
+  // after it are outstanding: F(k+1), F(k+2) and S(k-1) .. -- up to four groups, 32 operations.
+  auto fetch = [&](int k) {
+    if (k >= n_sc) return;
+    const int t0 = k * SC;
+    if (k < full_sc) {
 #pragma unroll
-      for (int i = 0; i < CH / 128; ++i)
-        comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & MX) * 8));
-#pragma unroll
-      for (int j = 0; j < 16; ++j) seq_of[j] = (j == ((int)k & 15)) ? seq : seq_of[j];
-      ++seq;
+      for (int i = 0; i < SC / 128; ++i) comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((t0 + 128 * i) & MX) * 8));
     } else {
-      for (int64_t t = t0 + lane; t < N; t += 64) xr[(int)t & MX] = xc[t];
-      ragged_in_flight = true;
+      for (int t = t0 + lane; t < N; t += 64) xr[t & MX] = xc[t];
     }
   };
-  auto store_chunk = [&](int64_t k) {
-    const int64_t t0 = k * CH;
-    if (t0 + CH <= N) {
+  auto store_group = [&](int k) {
+    const int t0 = k * SC;
+    if (k < full_sc) {
 #pragma unroll
-      for (int i = 0; i < CH / 128; ++i) {
-        const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & MY]);
+      for (int i = 0; i < SC / 128; ++i) {
+        const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[(t0 + 128 * i + 2 * lane) & MY]);
         comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
       }
-      ++seq;
     } else {
-      for (int64_t t = t0 + lane; t < N; t += 64) yc[t] = yr[(int)t & MY];
+      for (int t = t0 + lane; t < N; t += 64) yc[t] = yr[t & MY];
     }
   };
-  for (; fetched < n_chunks && fetched < kStringAhead; ++fetched) fetch(fetched);   // (that far ahead of the stores: the x ring holds sixteen)
-  for (int64_t n0 = 0; n0 < N; n0 += D) {
-    const int rem = N - n0 < D ? (int)(N - n0) : D;
-    // the chunks this step reads must have landed
-    const int64_t need = (n0 + rem - 1) / CH;
-    while (landed <= need) {
-      int sq = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sq = (j == ((int)landed & 15)) ? seq_of[j] : sq;
-      if (ragged_in_flight || (landed + 1) * CH > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else comb_wait_vm(2 * (seq - sq - 1));
+  fetch(0);
+  fetch(1);
+  fetch(2);
+  int landed_end = 0, landed = 0, stored = 0;                             // samples whose input has landed; groups landed / stored
+  for (int n0 = 0; n0 < N; n0 += D) {
+    const int rem = N - n0 < D ? N - n0 : D;
+    while (n0 + rem > landed_end) {                                       // (once per group)
+      // groups issued after F(landed): the fetches up to F(stored + 2) and the stores S(landed - 1 .. stored - 1) issued since
+      // (issue order F0 F1 F2 S0 F3 S1 F4 ...: F(j), j >= 3, follows S(j - 3))
+      const int fetches_after = (stored + 2 < n_sc - 1 ? stored + 2 : n_sc - 1) - landed;
+      const int stores_after = landed <= 2 ? stored : stored - (landed - 2);
+      const int after = fetches_after + stores_after;
+      if (landed >= full_sc - 3 || after < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the ragged tail: everything)
+      else comb_wait_vm(8 * after);
       ++landed;
+      landed_end = landed * SC < N ? landed * SC : N;
     }
-    double carry = old_last, nxt[U];
+    double carry = old_last, nxt[U], xv[U], left[U];
     if constexpr (NFB == 2) old_last = lane_of(prev[U - 1], last_lane);   // the period's last sample, before this step replaces it
-    const int tb = (int)n0 + lane;
+    const int tb = n0 + lane;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = 64 * u + lane;
-      const int t = tb + 64 * u;
-      double v = prev[u], left = 0.0;
-      if constexpr (NFB == 2) {                                         // (with every lane active: the shift reads its neighbour's register)
-        left = shr1(prev[u], carry);
+    for (int u = 0; u < U; ++u) xv[u] = xr[(tb + 64 * u) & MX];           // (a slot past the period reads something: never used)
+    if constexpr (NFB == 2) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                                       // (every lane active: the shift reads its neighbour's register)
+        left[u] = shr1(prev[u], carry);
         carry = lane_of(prev[u], 63);
       }
-      if (idx < rem) {
-        v = b0v * xr[t & MX] + na1v * prev[u];
-        if constexpr (NFB == 2) v = v + na2 * left;
-        yr[t & MY] = v;
-      }
-      nxt[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double v = b0 * xv[u] + na1 * prev[u];
+      if constexpr (NFB == 2) v = v + na2 * left[u];
+      const bool on = 64 * u + lane < rem;
+      if (on) yr[(tb + 64 * u) & MY] = v;
+      nxt[u] = on ? v : prev[u];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) prev[u] = nxt[u];
-    // finished chunks leave; the ring then has room for more input
-    while ((stored + 1) * CH <= n0 + rem) {
-      store_chunk(stored);
+    // a finished group leaves; the x ring then has room for one more
+    while ((stored + 1) * SC <= n0 + rem) {
+      store_group(stored);
       ++stored;
-      if (fetched < n_chunks) { fetch(fetched); ++fetched; }
+      fetch(stored + 2);
     }
   }
-  if (stored < n_chunks) store_chunk(stored);                             // the ragged last chunk
+  if (stored < n_sc) store_group(stored);                                 // the ragged last group
 }
 
 // histories after the block, for both delay lines (written to the spare halves of the slabs)
