@@ -194,6 +194,8 @@ constexpr int64_t kTpThreeLaunch = -3;   // internal chunk_len value: the engine
                                          // on which the one-pass kernel gave up)
 // names of the wait sites, for messages (index = word of look_err)
 const char *look_wait_name(int site);
+// compute units of the CURRENT device (asked once per device and thread)
+int device_cus();
 // whether launch_look would take this section and block (shape only; `cus` = the device's CU count)
 bool look_takes(const SectionDev &sec, const BlockIO &io, int cus);
 // whether launch_scan would send this section and block to the one-pass form for the handle's chunk-length setting

@@ -651,8 +651,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     // start stamps in global memory (FArgs): hints, nothing is read through them.
     const int64_t runs_total = (io.n + kRingR - 1) / kRingR;
     int map_sel = ALZ_TUNE("ALZ_FIR_MAP", -1);
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
-                                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int cus = device_cus() > 0 ? device_cus() : 256;               // (per device: round-5 advisor)
     const int64_t per_group = (int64_t)ALZ_FIR_WAVES * 4 * cus / gx;   // waves of one channel group the chip holds at a time
     // Chain width (profiles/NOTES_r05.md 9: widths 2 .. 16 on banks of 2048 .. 32768 channels, 96 .. 512 taps): 8 waves
     // when the chip holds two chains or more per group, 4 when it holds eight waves of it, and chains of 4 WITHOUT pacing
@@ -685,9 +684,11 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
       FirChains *fc = sec.chains;
       const size_t need = (size_t)(Qc * W * Mc + 1) * gx + 8;
       if (paced && fc != nullptr && need > fc->len) {
-        if (fc->flags) (void)hipFree(fc->flags);               // (waits for whatever still polls them)
+        // stream-ordered (round-5 advisor): the old slab is released behind whatever launch still polls it, the new one
+        // exists before this call's kernel -- no device-wide synchronisation inside a process call
+        if (fc->flags) (void)hipFreeAsync(fc->flags, stream);
         fc->flags = nullptr; fc->len = 0;
-        if (hipMalloc((void **)&fc->flags, need * sizeof(unsigned long long)) == hipSuccess &&
+        if (hipMallocAsync((void **)&fc->flags, need * sizeof(unsigned long long), stream) == hipSuccess &&
             hipMemsetAsync(fc->flags, 0, need * sizeof(unsigned long long), stream) == hipSuccess)
           fc->len = need;
         else (void)hipGetLastError();                         // no slab: the chains run free

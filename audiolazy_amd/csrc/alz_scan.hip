@@ -132,7 +132,7 @@ static int grow_scratch(double **ptr, uint64_t *have, uint64_t need) {
 // it; ALZ_TP_AUTO takes it when its workgroups (one per CU: 16 channels x up to 16 chunks in flight) fill most of the
 // chip, i.e. from about 200 channels up; narrower banks fill the chip better as chunks x channels lanes of the
 // three-launch form.
-static int device_cus() {
+int device_cus() {
   thread_local int cached_dev = -1, cached = 0;      // (per thread: handles of different devices may be driven from different threads)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;

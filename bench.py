@@ -993,6 +993,9 @@ def entry(res, world, steps, unit, workload, key=None):
          "parity": res["parity"], "roofline": roof}
   if res.get("timing"):
     out["timing"] = res["timing"]      # timed_batches(): the figures above are the MEDIAN batch's
+    # ... and the contract's own protocol beside it (W warm-up steps, then exactly K steps between two synchronisations:
+    # the calibration run of timed_batches), so that records stay comparable with rounds 1 - 4 and with multi-rank runs
+    out["ms_per_step_contract"] = res["timing"]["calibration_ms_per_step"]
   return out
 
 
