@@ -84,6 +84,10 @@ for k, v in sorted(t.items()):
   print("%-42s traffic / algorithmic %.4f" % (k, v["traffic_over_algorithmic"]))
 PYEOF
     ;;
+  fuzz)    # the GPU-side differential fuzzers against the oracle (round 6's new one first)
+    for f in "fuzz_sparse.py 300 606" "fuzz_timeparallel.py 100 1604" "fuzz_bank.py 200 1605" "fuzz_outer.py 100 1606" "fuzz_stream.py 120 1607"; do
+      echo "== $f"; timeout 900 python tools/$f 2>&1 | tail -6 | cut -c1-400
+    done 2>&1 | tee $O/fuzz_gpu.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
