@@ -290,7 +290,7 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
   if (ALZ_TUNE("ALZ_MID_OFF", 0)) return ALZ_OK;                        // (tuning builds: round 5's lane-per-channel kernels, for A/B timing)
   if (sec.nb <= 3 && sec.na <= 3) return ALZ_OK;                          // (the two-pole streaming kernels' shapes)
   if (!(io.sxc == 1 && io.syc == 1) || io.c_first != 0 || io.c_count != io.channels || io.channels % kMG) return ALZ_OK;
-  if (io.pre_op || io.fused) return ALZ_OK;
+  if (io.pre_op) return ALZ_OK;                                          // (the opt-in FMA mode ALLOWS contraction; this kernel simply does not use it)
   if ((((uintptr_t)io.x | (uintptr_t)io.y) & 15) || ((io.sxn | io.syn) & 1)) return ALZ_OK;
   if (io.mode == ALZ_BANK_OUTER && io.map_input && io.n_inputs % kMG) return ALZ_OK;
   const int K = sec.na - 1;
