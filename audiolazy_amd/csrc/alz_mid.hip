@@ -38,6 +38,7 @@ struct MArgs {
   int64_t channels, n_inputs, n_sets;
   int map_input;
   int far_delay;               // FAR instantiations: the delay S of the far numerator tap (9 <= S <= 256)
+  unsigned pb_mask;            // bit k: numerator tap k is present (a zero tap is absent from the sum: lazy_filters.py:205-206); all ones when dense
   int ns;                      // x ring slots (a power of two: 4, or 8 with a far tap)
   const double *b, *a;
   double *xh, *yh;             // the bank's state [taps - 1][channels]
@@ -137,13 +138,27 @@ __global__ __launch_bounds__(192) void k_mid(MArgs p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xf[j] = *reinterpret_cast<const double *>(xring + ((base + (unsigned)j * 512u) & ring_mask) + cl * 8);
       }
+      if (p.pb_mask == (1u << NB) - 1u) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double acc = bc[0] * xr[4 * j + NB - 1];
+        for (int j = 0; j < 16; ++j) {
+          double acc = bc[0] * xr[4 * j + NB - 1];
 #pragma unroll
-        for (int k = 1; k < NB; ++k) acc = acc + bc[k] * xr[4 * j - k + NB - 1];
-        if constexpr (FAR) acc = acc + bfar * xf[j];
-        *reinterpret_cast<double *>(ps + j * 512) = acc;
+          for (int k = 1; k < NB; ++k) acc = acc + bc[k] * xr[4 * j - k + NB - 1];
+          if constexpr (FAR) acc = acc + bfar * xf[j];
+          *reinterpret_cast<double *>(ps + j * 512) = acc;
+        }
+      } else {
+        // zero taps inside the numerator (a band-pass butter's b = [b0, 0, -2 b0, 0, b0]): absent from the sum, like the
+        // reference's generated statement; the pattern is the bank's (uniform), so the tests are scalar
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          double acc = -0.0;                                             // additive identity: the first present term initialises the sum
+#pragma unroll
+          for (int k = 0; k < NB; ++k)
+            if (p.pb_mask >> k & 1u) acc = acc + bc[k] * xr[4 * j - k + NB - 1];
+          if constexpr (FAR) acc = acc + bfar * xf[j];
+          *reinterpret_cast<double *>(ps + j * 512) = acc;
+        }
       }
     };
     int queued = 0;
@@ -298,8 +313,13 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
   // numerator: dense b_0 .. b_{NB-1}, optionally one far tap behind it
   int nbd = 0, far_delay = 0;
   bool far = false;
+  unsigned pb_mask = 0;
   if (sec.nb <= 9 && sec.present_b == (1u << sec.nb) - 1u) {
     nbd = sec.nb;
+    pb_mask = sec.present_b;
+  } else if (sec.nb >= 4 && sec.nb <= 9 && (sec.present_b >> (sec.nb - 1) & 1u)) {
+    nbd = sec.nb;                                                          // zero taps inside a short numerator (highest tap present)
+    pb_mask = sec.present_b;
   } else if (sec.n_ff >= 2 && sec.n_ff <= 3) {
     nbd = sec.n_ff - 1;
     for (int j = 0; j < nbd; ++j)
@@ -307,6 +327,7 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
     far_delay = sec.tap_b[nbd];
     if (far_delay != sec.nb - 1 || far_delay < 9 || far_delay > 256) return ALZ_OK;
     far = true;
+    pb_mask = (1u << nbd) - 1u;
   } else {
     return ALZ_OK;
   }
@@ -318,7 +339,7 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
   MArgs p;
   p.x = io.x; p.y = io.y; p.ldx = io.sxn; p.ldy = io.syn; p.n_tiles = tiles; p.channels = io.channels;
   p.n_inputs = io.mode == ALZ_BANK_OUTER ? io.n_inputs : 0; p.n_sets = io.n_sets; p.map_input = io.map_input;
-  p.far_delay = far_delay; p.ns = far ? 8 : 4;
+  p.far_delay = far_delay; p.ns = far ? 8 : 4; p.pb_mask = pb_mask;
   p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   const size_t lds = (size_t)kMGuard + (size_t)p.ns * kMTile + (size_t)(kMPRing + kMYRing) * kMTile;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);

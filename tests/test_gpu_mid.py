@@ -139,14 +139,31 @@ def test_outer_bank_and_wide_bank(alz, oracle):
   run_blocks(alz, oracle, rng.uniform(-1, 1, (C, 7)), stable_den(rng, C, 6), [64 * 6], C, "k_mid", rng=rng)
 
 
+def test_band_pass_butterworth_zero_taps_inside_the_numerator(alz, oracle):
+  """scipy.signal.butter(n, [lo, hi], "bandpass"): b = [b0, 0, -n b0, 0, ...] -- zero taps inside a short numerator are absent
+  from the sum (lazy_filters.py:205-206), the denominator is dense: k_mid with the numerator's pattern as a scalar mask."""
+  from scipy import signal
+  rng = np.random.default_rng(12)
+  C = 32
+  for n in (2, 3, 4):
+    ba = [signal.butter(n, [lo, lo + 0.2], "bandpass") for lo in np.linspace(0.1, 0.5, C)]
+    b, a = np.array([x[0] for x in ba]), np.array([x[1] for x in ba])
+    b[np.abs(b) < 1e-300] = 0.0
+    assert np.all(b[:, 1] == 0) and np.all(a[:, 0] == 1.0) and np.all(a[:, 1:] != 0)
+    run_blocks(alz, oracle, b, a, [64 * 6 + 9, 64 * 2, 30], C, "k_mid", rng=rng)
+  # a leading zero tap (a pure delay in front) and a random pattern
+  b = rng.uniform(-1, 1, (C, 6)); b[:, 0] = 0.0; b[:, 3] = 0.0
+  run_blocks(alz, oracle, b, stable_den(rng, C, 5), [64 * 5 + 1, 64], C, "k_mid", rng=rng)
+
+
 def test_shapes_outside_stay_on_the_other_kernels(alz, oracle):
-  """a0 != 1, a zero inside the coefficients, a ragged channel count: the lane-per-channel kernels as before, same doubles."""
+  """a0 != 1, a zero inside the denominator, a ragged channel count: the lane-per-channel kernels as before, same doubles."""
   rng = np.random.default_rng(5)
   C = 32
   a = stable_den(rng, C, 4)
   b = rng.uniform(-1, 1, (C, 5))
   a2 = a.copy(); a2[:, 0] = 2.0
   run_blocks(alz, oracle, b, a2, [64 * 3], C, "k_masked", rng=rng)
-  b3 = b.copy(); b3[:, 2] = 0.0
-  run_blocks(alz, oracle, b3, a, [64 * 3], C, "k_masked", rng=rng)
+  a3 = a.copy(); a3[:, 2] = 0.0                       # a zero inside the DENOMINATOR: the recurrence wave's chain is dense only
+  run_blocks(alz, oracle, b, a3, [64 * 3], C, "k_masked", rng=rng)
   run_blocks(alz, oracle, b[:20], a[:20], [64 * 3], 20, "k_masked", rng=rng)
