@@ -581,6 +581,7 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
       alz::BlockIO probe;
       probe.n = n; probe.pre_op = ALZ_MAP_ABS; probe.channels = h->channels; probe.n_inputs = h->n_inputs; probe.n_sets = h->n_sets;
       probe.mode = h->mode; probe.zero = h->zero; probe.fused = h->fused; probe.stream_once = 0;
+      probe.look_sync = h->look_check == ALZ_LOOK_CHECK_CALL ? 1 : 0;
       probe.x = x_dev; probe.y = y_dev;
       probe.sxn = layout == ALZ_TIME_MAJOR ? ldx : 1; probe.sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
       probe.syn = layout == ALZ_TIME_MAJOR ? ldy : 1; probe.syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
@@ -611,6 +612,7 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
   io.mode = h->mode;
   io.zero = h->zero;
   io.fused = h->fused;
+  io.look_sync = h->look_check == ALZ_LOOK_CHECK_CALL ? 1 : 0;
   io.stream_once = (h->n_sections == 1 && x_dev != y_dev && (uint64_t)n * (uint64_t)h->channels * 8u >= (256ull << 20)) ? 1 : 0;
   int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;

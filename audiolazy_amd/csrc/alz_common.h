@@ -95,6 +95,8 @@ struct BlockIO {
   int fused;          // opt-in FMA contraction in the streaming kernels (not bit-exact)
   int pre_op;         // elementwise stage fused into this section's input reads (ALZ_MAP_ABS) or 0;
                       // honoured by launch_wave and the k_small path of launch_section only
+  int look_sync = 0;    // the process call will wait for a one-pass time-parallel launch (ALZ_LOOK_CHECK_CALL): short blocks are
+                      // then better off in three launches, which nobody has to wait for (scan_takes_one_pass, ALZ_TP_AUTO)
   int stream_once = 0;  // the block is large, read once and its result not read again by this call (single-section
                       // bank): k_duo then moves it with non-temporal loads and stores
 };

@@ -157,6 +157,9 @@ bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk
     wk = wk > 16 ? 16 : wk;
     wk = wk > Kl ? Kl : wk;
     one_pass = wk >= 2 && 4 * groups * wk >= 3 * (int64_t)cus;
+    // the launching call synchronises with a one-pass launch (alz_bank_set_look_check, default): ~60 us per block, more than
+    // a short block's kernels take in either form -- the three-launch form needs no such wait
+    if (io.look_sync && Kl < 128) one_pass = false;
   }
   return one_pass && look_takes(sec, io, cus);
 }

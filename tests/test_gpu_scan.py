@@ -131,16 +131,19 @@ def test_cascade_sections_one_after_the_other(alz, oracle):
 
 def test_engine_choice_of_form(alz, oracle):
   """ALZ_TP_AUTO takes the one-pass form where its workgroups fill the chip (>= 256 channels, either layout since round
-  5), the three-launch form for narrower banks and explicit chunk lengths."""
+  5), the three-launch form for narrower banks and explicit chunk lengths -- and (round 6) for blocks under 128 chunks
+  while the launching call verifies a one-pass launch (the default): that wait costs more than such a block's kernels."""
   import torch
-  for C, layout, chunk, one_pass in ((512, "time", True, True), (64, "time", True, False), (512, "chan", True, True),
-                                     (512, "time", 2048, False), (64, "time", "one-pass", True)):
+  for C, layout, chunk, n, check, one_pass in ((512, "time", True, 1 << 16, "call", True), (64, "time", True, 1 << 16, "call", False),
+                                              (512, "chan", True, 1 << 16, "call", True), (512, "time", 2048, 1 << 16, "call", False),
+                                              (64, "time", "one-pass", 1 << 14, "call", True), (512, "time", True, 1 << 14, "call", False),
+                                              (512, "time", True, 1 << 14, "deferred", True)):
     b, a = resonators(C)
-    n = 1 << 14
     x = np.random.default_rng(C).uniform(-1, 1, (n, C) if layout == "time" else (C, n))
-    bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(chunk)
+    bank = alz.FilterBank([(b, a)], n_inputs=C).set_time_parallel(chunk).set_look_check(check)
     y = bank.process(torch.from_numpy(x).cuda(), layout=layout).cpu().numpy()
-    assert "k_scan" in bank.last_kernel and ("k_look" in bank.last_kernel) == one_pass, (C, layout, chunk, bank.last_kernel)
+    bank.sync()
+    assert "k_scan" in bank.last_kernel and ("k_look" in bank.last_kernel) == one_pass, (C, layout, chunk, n, check, bank.last_kernel)
     ref = oracle.bank([3], [3], b, a, x, layout=layout)
     assert norm_err(y, ref, 0 if layout == "time" else 1) <= 1e-8
 
