@@ -212,6 +212,9 @@ typedef const double __attribute__((address_space(4))) *const_taps_t;
 #ifndef ALZ_FIR_RING_K
 #define ALZ_FIR_RING_K 4
 #endif
+#ifndef ALZ_FIR_I32
+#define ALZ_FIR_I32 0     // (variant builds: 1 = the ring groups' row clamps in 32-bit scalar arithmetic)
+#endif
 #ifndef ALZ_FIR_RING_PF
 #define ALZ_FIR_RING_PF 3
 #endif
@@ -243,6 +246,23 @@ struct RingCtx {
 template <bool EDGE>
 __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, double (&dst)[kRingK]) {
   if constexpr (!EDGE) {
+#if ALZ_FIR_I32
+    // Row arithmetic in 32 bits (round 6; launch_fir keeps blocks below 2^31 rows): gfx9 has no 64-bit scalar compare, so the
+    // clamps below were v_cmp_*_i64 + v_mov_b64 -- most of the 11 % of this kernel's VALU instructions that are not multiply-adds
+    // (profiles/r02_pmc_fir_fma.txt) -- on the unit the multiply-adds need.
+    const int n32 = (int)q.p->n, rb32 = (int)q.row_bytes;
+    int tc = (int)tb;
+    tc = tc < 0 ? 0 : tc;
+    tc = tc > n32 - 1 ? n32 - 1 : tc;                        // a group wholly past the block (window of the last run): never used
+    const char *base = (const char *)q.p->x + (int64_t)tc * q.row_bytes;   // wave-uniform
+    const int rows_left = n32 - tc, max_rows = 0x7fffffff / rb32;
+    const int valid = (rows_left < max_rows ? rows_left : max_rows) * rb32;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, valid, 0x00020000);
+    const int last = (n32 - 1 - tc) < (kRingK - 1) ? (n32 - 1 - tc) : (kRingK - 1);
+#pragma unroll
+    for (int j = 0; j < kRingK; ++j)
+      dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, (j < last ? j : last) * rb32, 0));
+#else
     int64_t tc = tb < 0 ? 0 : tb;
     if (tc > q.p->n - 1) tc = q.p->n - 1;                    // a group wholly past the block (window of the last run): never used
     const char *base = (const char *)q.p->x + tc * q.row_bytes;            // wave-uniform
@@ -255,6 +275,7 @@ __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, do
 #pragma unroll
     for (int j = 0; j < kRingK; ++j)
       dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, (int)((j < last ? j : last) * q.row_bytes), 0));
+#endif
   } else {
     // first row tiles of a block: a row is either inside the block (t >= 0) or a row of the delay line
     // (p.xh[(-t - 1) * channels + c]).  Which one is wave-uniform, so it is a scalar choice of descriptor and

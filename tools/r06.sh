@@ -69,7 +69,7 @@ case $call in
     done 2>&1 | tee $O/pipe_long.log ;;
   asan)    bash tools/asan_check.sh gpu 2>&1 | tee $O/asan_gpu.log ;;
   firvar)  # configs[2]: register tile x occupancy of k_fir_ring (variant builds of alz_fir.hip over the tuning objects)
-    for v in tuning fir_r28w3 fir_r32w3 fir_r20w4 tuning; do
+    for v in ${FIRVARS:-tuning fir_i32 tuning fir_i32}; do
       for m in "" "--fused"; do
         ALZ_LIBRARY=$R/tools/variants/libalzhip_$v.so timeout 300 python bench.py --workload fir $m --no-cpu-baseline --steps 6 --warmup 2 --full-json - > $O/f.json 2> $O/f.err || tail -2 $O/f.err
         echo "$v $m: $(python tools/show_line.py $O/f.json | head -1 | cut -c1-150)"
