@@ -213,7 +213,7 @@ typedef const double __attribute__((address_space(4))) *const_taps_t;
 #define ALZ_FIR_RING_K 4
 #endif
 #ifndef ALZ_FIR_I32
-#define ALZ_FIR_I32 0     // (variant builds: 1 = the ring groups' row clamps in 32-bit scalar arithmetic)
+#define ALZ_FIR_I32 1     // the ring groups' row clamps in 32-bit scalar arithmetic (0: round 5's 64-bit form, for A/B builds)
 #endif
 #ifndef ALZ_FIR_RING_PF
 #define ALZ_FIR_RING_PF 3
@@ -249,7 +249,8 @@ __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, do
 #if ALZ_FIR_I32
     // Row arithmetic in 32 bits (round 6; launch_fir keeps blocks below 2^31 rows): gfx9 has no 64-bit scalar compare, so the
     // clamps below were v_cmp_*_i64 + v_mov_b64 -- most of the 11 % of this kernel's VALU instructions that are not multiply-adds
-    // (profiles/r02_pmc_fir_fma.txt) -- on the unit the multiply-adds need.
+    // (profiles/r02_pmc_fir_fma.txt) -- on the unit the multiply-adds need.  Same box, interleaved runs: 56.5 - 57.1 -> 58.4 - 58.7
+    // Gsamples/s bit-exact, 90.3 - 90.6 -> 95.0 - 95.3 in the FMA mode (profiles/r06_fir_i32_ab.log).
     const int n32 = (int)q.p->n, rb32 = (int)q.row_bytes;
     int tc = (int)tb;
     tc = tc < 0 ? 0 : tc;
@@ -648,7 +649,7 @@ int launch_fir(const SectionDev &sec, const BlockIO &io, hipStream_t stream, boo
     const unsigned gyc = (unsigned)((io.n + kCmOut - 1) / kCmOut);
     if (gyc > 65535u || io.c_count > 0x7fffffff) return ALZ_OK;
     hipLaunchKernelGGL(k_fir_cm, dim3((unsigned)io.c_count, gyc), dim3(64), lds, stream, p);
-  } else if (sec.shared_sets && io.n_inputs * 8 < ((int64_t)1 << 31) && io.channels * 8 < ((int64_t)1 << 31) &&
+  } else if (sec.shared_sets && io.n < ((int64_t)1 << 31) - 4096 && io.n_inputs * 8 < ((int64_t)1 << 31) && io.channels * 8 < ((int64_t)1 << 31) &&
              io.sxn * 8 * kRingK < ((int64_t)1 << 31) &&
              (int64_t)(sec.nb + (kRingPF + 3) * kRingK + 2 * kRingR) * io.sxn * 8 < ((int64_t)1 << 31) &&   // edge runs: 32-bit row offsets
              (int64_t)(sec.nb - 1) * io.channels * 8 < ((int64_t)1 << 31)) {
