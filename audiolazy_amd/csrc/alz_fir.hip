@@ -321,10 +321,9 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
   constexpr int PF = kRingPF;
   ring_load_group<EDGE>(q, t0 - (kb + PF * K) - (K - 1), xr[(4 * NG - PF - PH) % NG]);   // unused after the last blocks
   ring_load_taps(q, kb + K, tap_next);                            // likewise (all 0.0 past the end)
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) {
-    if (tap_absent(tap[kk])) continue;
 #define ALZ_RING_X(j) xr[(((j) / K) + NG - PH) % NG][(j) % K]
+  auto one_tap = [&](auto KK) {
+    constexpr int kk = decltype(KK)::value;
 #pragma unroll
     for (int r = 0; r < R; r += 4) {
       if constexpr (FMA) {
@@ -362,8 +361,18 @@ __device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, 
 #endif
       }
     }
+  };
+  // (one test per tap BLOCK with a second, test-free copy of the K * R multiply-adds was tried in round 6: the two copies cost the
+  // register allocator 900 bytes of scratch per lane -- the per-tap tests stay)
+  if (!tap_absent(tap[0])) one_tap(std::integral_constant<int, 0>{});
+  if constexpr (K > 1) { if (!tap_absent(tap[1])) one_tap(std::integral_constant<int, 1>{}); }
+  if constexpr (K > 2) { if (!tap_absent(tap[2])) one_tap(std::integral_constant<int, 2>{}); }
+  if constexpr (K > 3) { if (!tap_absent(tap[3])) one_tap(std::integral_constant<int, 3>{}); }
+  if constexpr (K > 4) { if (!tap_absent(tap[4])) one_tap(std::integral_constant<int, 4>{}); }
+  if constexpr (K > 5) { if (!tap_absent(tap[5])) one_tap(std::integral_constant<int, 5>{}); }
+  if constexpr (K > 6) { if (!tap_absent(tap[6])) one_tap(std::integral_constant<int, 6>{}); }
+  if constexpr (K > 7) { if (!tap_absent(tap[7])) one_tap(std::integral_constant<int, 7>{}); }
 #undef ALZ_RING_X
-  }
 }
 
 // NG is even: the two tap buffers swap roles with the parity of the phase
