@@ -279,17 +279,23 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
   if constexpr (NFB > 0)
     for (int k = lane; k < ka[NFB - 1]; k += 64) yr[(-1 - k) & MY] = p.yh[(int64_t)k * p.channels + c];
   const int64_t n_chunks = (p.n + CH - 1) / CH;
+  // A few channels of a TIME-major block (stereo rows [N, 2]: sxn = channels) come through the same kernel with strided
+  // plain loads / stores: no 16-byte pieces, the transfers are not queued ahead -- still lanes over the delay line instead
+  // of one lane per channel.
+  const int64_t sxn = p.sxn, syn = p.syn;
+  const bool dma_in = sxn == 1, wide_out = syn == 1;
   // chunk k of the input into the x ring: whole chunks by global -> LDS transfers (nothing waits here), the ragged last
   // one by plain loads
   auto fetch = [&](int64_t k) {
     if (k >= n_chunks) return;
     const int64_t t0 = k * CH;
-    if (t0 + CH <= p.n) {
+    if (dma_in && t0 + CH <= p.n) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i)
         comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((int)(t0 + 128 * i) & MX) * 8));
     } else {
-      for (int64_t t = t0 + lane; t < p.n; t += 64) xr[(int)t & MX] = xc[t];
+      const int64_t te = t0 + CH < p.n ? t0 + CH : p.n;
+      for (int64_t t = t0 + lane; t < te; t += 64) xr[(int)t & MX] = xc[t * sxn];
     }
   };
   fetch(0);
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
     // chunk k has landed when at most the transfers and stores issued after it are outstanding: F(k) S(k-2) F(k+1) S(k-1)
     // -- two operations each; near the end of the block (ragged chunk: compiler-issued loads) simply everything
     // (the first two iterations have fewer behind them: everything)
-    if (k >= 2 && k + 3 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (dma_in && wide_out && k >= 2 && k + 3 < n_chunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     fetch(k + 2);
     const int64_t t_end = (k + 1) * CH < p.n ? (k + 1) * CH : p.n;
@@ -321,14 +327,15 @@ __global__ __launch_bounds__(256) void k_comb_cm(SArgs p) {
     }
     // the finished chunk leaves from the ring
     const int64_t t0 = k * CH;
-    if (t0 + CH <= p.n) {
+    if (wide_out && t0 + CH <= p.n) {
 #pragma unroll
       for (int i = 0; i < CH / 128; ++i) {
         const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[((int)t0 + 128 * i + 2 * lane) & MY]);
         comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
       }
     } else {
-      for (int64_t t = t0 + lane; t < p.n; t += 64) yc[t] = yr[(int)t & MY];
+      const int64_t te = t0 + CH < p.n ? t0 + CH : p.n;
+      for (int64_t t = t0 + lane; t < te; t += 64) yc[t * syn] = yr[(int)t & MY];
     }
   }
 }
@@ -416,26 +423,31 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
   // (whole groups; the ragged last group goes through compiler-issued loads / stores and is simply waited for in full).
   // F(0..2) up front; after the steps of group k: S(k), then F(k + 3).  F(k) has landed when at most the groups issued
   // after it are outstanding: F(k+1), F(k+2) and S(k-1) .. -- up to four groups, 32 operations.
+  // (a few channels of a time-major block -- stereo rows [N, 2] -- take the strided plain path for every group: see k_comb_cm)
+  const int64_t sxn = p.sxn, syn = p.syn;
+  const bool dma_in = sxn == 1, wide_out = syn == 1, queued = dma_in && wide_out;
   auto fetch = [&](int k) {
     if (k >= n_sc) return;
     const int t0 = k * SC;
-    if (k < full_sc) {
+    if (dma_in && k < full_sc) {
 #pragma unroll
       for (int i = 0; i < SC / 128; ++i) comb_dma16<NT>(xc + t0 + 128 * i + 2 * lane, xr_lds + (unsigned)(((t0 + 128 * i) & MX) * 8));
     } else {
-      for (int t = t0 + lane; t < N; t += 64) xr[t & MX] = xc[t];
+      const int te = t0 + SC < N ? t0 + SC : N;
+      for (int t = t0 + lane; t < te; t += 64) xr[t & MX] = xc[(int64_t)t * sxn];
     }
   };
   auto store_group = [&](int k) {
     const int t0 = k * SC;
-    if (k < full_sc) {
+    if (wide_out && k < full_sc) {
 #pragma unroll
       for (int i = 0; i < SC / 128; ++i) {
         const dbl2 v = *reinterpret_cast<const dbl2 *>(&yr[(t0 + 128 * i + 2 * lane) & MY]);
         comb_store16<NT>(yc + t0 + 128 * i + 2 * lane, v);
       }
     } else {
-      for (int t = t0 + lane; t < N; t += 64) yc[t] = yr[t & MY];
+      const int te = t0 + SC < N ? t0 + SC : N;
+      for (int t = t0 + lane; t < te; t += 64) yc[(int64_t)t * syn] = yr[t & MY];
     }
   };
   fetch(0);
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(256) void k_string(SArgs p) {
       const int fetches_after = (stored + 2 < n_sc - 1 ? stored + 2 : n_sc - 1) - landed;
       const int stores_after = landed <= 2 ? stored : stored - (landed - 2);
       const int after = fetches_after + stores_after;
-      if (landed >= full_sc - 3 || after < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the ragged tail: everything)
+      if (!queued || landed >= full_sc - 3 || after < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the ragged tail, strided rows: everything)
       else comb_wait_vm(8 * after);
       ++landed;
       landed_end = landed * SC < N ? landed * SC : N;
@@ -573,11 +585,15 @@ static CombPlan plan_comb(const SectionDev &sec, const BlockIO &io) {
   if (io.x == io.y && !(sec.n_ff == 1 && sec.tap_b[0] == 0)) return pl;      // (in place: no input history may be read back)
   if (io.mode == ALZ_BANK_OUTER && io.x == io.y) return pl;
   if (((uintptr_t)io.x | (uintptr_t)io.y) & 15) return pl;
-  const bool cm = io.sxn == 1 && io.syn == 1;
   const bool tm = io.sxc == 1 && io.syc == 1;
+  // a few channels of a time-major block (stereo rows [N, 2], ragged counts up to 64): the wave-per-channel kernels with strided
+  // plain loads and stores -- lanes over the delay line still beat a lane per channel by far
+  const bool narrow_tm = tm && !(io.sxn == 1 && io.syn == 1) && io.c_count <= 64 && (io.c_count < 16 || io.c_count % 16 != 0) &&
+                         io.mode != ALZ_BANK_OUTER;
+  const bool cm = (io.sxn == 1 && io.syn == 1) || narrow_tm;
   if (cm) {
     // a wave per channel; 16-byte pieces of a channel's row
-    if (io.channels > 1 && ((io.sxc | io.syc) & 1)) return pl;
+    if (!narrow_tm && io.channels > 1 && ((io.sxc | io.syc) & 1)) return pl;
     // a few strings whose period fits a wave's registers: steps of one period, no LDS round trip between them
     if (io.c_count <= 256 && dmin <= 512 && sec.n_ff == 1 && sec.tap_b[0] == 0 && sec.n_fb >= 1 &&
         (sec.n_fb == 1 || sec.tap_a[1] == sec.tap_a[0] + 1) && !ALZ_TUNE("ALZ_STRING_OFF", 0)) {

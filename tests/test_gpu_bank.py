@@ -502,6 +502,34 @@ def test_one_string_lanes_over_the_delay(alz, oracle, D):
         at += len(x)
 
 
+@pytest.mark.parametrize("C", [2, 5, 17, 40])
+@pytest.mark.parametrize("shape,D", [("fb", 24), ("lin", 109), ("lin", 441), ("fb", 700), ("ff", 300), ("mixed", 109)])
+def test_comb_on_a_few_channels_of_time_major_rows(alz, oracle, C, shape, D):
+  """Stereo rows [N, 2] (and other channel counts that are not whole groups of 16, up to 64) of a time-major block: the
+  wave-per-channel kernels with strided loads and stores -- lanes over the delay line -- instead of round 1's lane per channel;
+  bit-exact across blocks, in place where the numerator is b0 alone."""
+  import torch
+  rng = np.random.default_rng(C * 1000 + D)
+  b, a = _comb_case(shape, D, C, rng)
+  nb, na = b.shape[1], a.shape[1]
+  lens = [3 * D + 37, D // 2 + 3, 600, 256, 1]
+  xs = [rng.uniform(-1, 1, (m, C)) for m in lens]
+  xh0 = rng.uniform(-1, 1, (C, max(nb - 1, 1)))
+  yh0 = rng.uniform(-1, 1, (C, max(na - 1, 1)))
+  ref = oracle.bank([nb], [na], b, a, np.concatenate(xs), layout="time", xh=xh0.copy(), yh=yh0.copy())
+  want = "k_string" if (D <= 512 and shape in ("fb", "lin")) else "k_comb_cm"
+  for inplace in ((False, True) if nb == 1 else (False,)):
+    bank = alz.FilterBank([(b, a)], n_inputs=C)
+    bank.set_state(xh0, yh0)
+    at = 0
+    for x in xs:
+      xd = torch.from_numpy(x).cuda()
+      y = bank.process(xd, layout="time", out=xd if inplace else None)
+      assert bank.last_kernel == want, (bank.last_kernel, want)
+      assert same_bits(y.cpu().numpy(), ref[at:at + x.shape[0]]), (shape, D, C, inplace, at)
+      at += x.shape[0]
+
+
 def test_comb_outer_bank_and_wide_block(alz, oracle):
   """A comb per (set, input) pair -- an OUTER bank reading by input index -- and a block wide and long enough for every
   workgroup / wave to run many steps (4096 channels x 4096 samples, D = 441: bench.py's comb_fb shape, shortened)."""
