@@ -597,8 +597,7 @@ static CombPlan plan_comb(const SectionDev &sec, const BlockIO &io) {
     // a few strings whose period fits a wave's registers: steps of one period, no LDS round trip between them
     if (io.c_count <= 256 && dmin <= 512 && sec.n_ff == 1 && sec.tap_b[0] == 0 && sec.n_fb >= 1 &&
         (sec.n_fb == 1 || sec.tap_a[1] == sec.tap_a[0] + 1) && !ALZ_TUNE("ALZ_STRING_OFF", 0)) {
-      int wpb = io.c_count < 4 ? (int)io.c_count : 4;
-      if (io.c_count >= 16 && wpb > 2) wpb = 2;
+      const int wpb = io.c_count < 2 ? 1 : 2;                          // (48 KiB of rings per wave)
       pl.ok = true; pl.cm = true; pl.string = true; pl.u = (dmin + 63) / 64; pl.threads = 64 * wpb; pl.T = dmin; pl.ring = kStringYRing; pl.xring = kStringXRing;
       pl.lds = (size_t)(kStringXRing + kStringYRing) * 8 * wpb;
       pl.grid = (unsigned)((io.c_count + wpb - 1) / wpb);
