@@ -318,6 +318,7 @@ struct CScanArgs {
                                // blocks, and channel-major ones whose single input stream is broadcast)
   int x_tm;                    // the block is time-major (x[t * ldx + in]) rather than channel-major (x[in * ldx + t])
   int first_is_z;              // slot 0 of vyh holds z_0 (the dot-product zero-state pass): the fix starts at chunk 0 from the bank's state
+  int xcd_map;                 // k_cdot3: workgroups that share a band group (its slice of the response table) on ONE XCD
 };
 
 __device__ __forceinline__ int64_t cs_slot(const CScanArgs &p, int64_t c, int64_t j) { return p.slot_tm ? j * p.C + c : c * p.K + j; }
@@ -684,9 +685,19 @@ __global__ __launch_bounds__(64 * SPLIT) void k_cdot3(CScanArgs p, const double 
   static_assert((NS * 8) % SPLIT == 0, "the final sums are shared out over the waves");
   const int lane = threadIdx.x & 63;
   const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  // Workgroups are dealt to the eight XCDs by their linear index mod 8 (x fastest): with the launch's natural order the four chunk
+  // groups of a band group sit on four XCDs and each pulls that band group's slice of the response table through its own L2.
+  // xcd_map (grid.y a multiple of 8): XCD e takes the band groups y = e (mod 8), every chunk group of them -- a slice is fetched
+  // by one XCD.
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (p.xcd_map) {
+    const unsigned id = bx + gridDim.x * by, per = gridDim.y >> 3, loc = id >> 3;
+    by = (id & 7u) + 8u * (loc % per);
+    bx = loc / per;
+  }
+  const int64_t j = (int64_t)bx * 64 + lane;
   const int64_t ngrp = p.n_sets / NS;
-  const int64_t in = (int64_t)blockIdx.y / ngrp, set0 = ((int64_t)blockIdx.y - in * ngrp) * NS;
+  const int64_t in = (int64_t)by / ngrp, set0 = ((int64_t)by - in * ngrp) * NS;
   const int64_t Ls = p.L / SPLIT, m0 = seg * Ls;
   const int nsteps = (int)(Ls / 16);
   const double *xrow = p.x + in * p.ldx + j * p.L;
@@ -899,6 +910,7 @@ int launch_scan_cascade(const SectionDev *secs, int nsec, const BlockIO &io, hip
     const void *dot_fn = lines ? (const void *)k_cdot3<SPLIT> : (const void *)k_cdot<NS, SPLIT>;
     rc = ensure_dynamic_lds(dot_fn, lds);
     if (rc) return rc;
+    p.xcd_map = (((io.n_sets / NS) * io.n_inputs) % 8 == 0 && ALZ_TUNE("ALZ_CDOT_XCD", 1) != 0) ? 1 : 0;
     if (lines)
       hipLaunchKernelGGL((k_cdot3<SPLIT>), dim3((unsigned)(K / 64), (unsigned)((io.n_sets / NS) * io.n_inputs)), dim3(64 * SPLIT),
                          lds, stream, p, (const double *)scratch->hr, (const double *)scratch->edge);
