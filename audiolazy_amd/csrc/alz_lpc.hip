@@ -294,12 +294,18 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
   double acc[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) acc[i] = 0.0;
-  double hist[H * 16];                        // hist[k] = x[16*c - 1 - k] ... kept as previous chunks
+  // The chunk being summed and the H chunks before it live in H + 1 register sets that ROTATE by name (the chunk loop is unrolled
+  // H + 1 times): round 5 copied the finished chunk into a reversed history array every chunk -- 16 v_mov_b64 per chunk, 3 % of the
+  // VALU instructions of a kernel that is bound by VALU issue (round 6).
+  double buf[H + 1][16];
 #pragma unroll
-  for (int k = 0; k < H * 16; ++k) hist[k] = 0.0;
+  for (int h = 0; h <= H; ++h)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[h][k] = 0.0;
 
   for (int c0 = 0; c0 < kLpcRing - 1 && c0 < nchunks; ++c0) queue(c0);
-  for (int c = 0; c < nchunks; ++c) {
+  // chunk c: samples into `cur`; `p1` / `p2` hold chunks c - 1 / c - 2 (x[16 c + d], d < 0, is p1[16 + d] or p2[32 + d])
+  auto do_chunk = [&](int c, double (&cur)[16], const double (&p1)[16], const double (&p2)[16]) {
     if (c + kLpcRing - 1 < nchunks) queue(c + kLpcRing - 1);
     // transfers issued after chunk c's: chunks c+1 .. c+kLpcRing-1 (those that exist)
     const int after = (nchunks - 1 - c < kLpcRing - 1) ? (nchunks - 1 - c) : kLpcRing - 1;
@@ -315,7 +321,6 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
       default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
     }
     const char *slot = smem + (c % kLpcRing) * 8192 + lane * 128;
-    double cur[16];
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {
       typedef double d2 __attribute__((ext_vector_type(2)));
@@ -324,8 +329,8 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
       cur[2 * pc + 1] = v.y;
     }
     const int valid = L - 16 * c;             // samples of this chunk inside the frame (>= 1)
-    // x[m - i] is inside this chunk (u >= i) or in the history (hist[k] = x[16c - 1 - k]); only the
-    // first H chunks have lags that reach before the start of the frame (checked form)
+    // x[m - i] is inside this chunk (u >= i) or in one of the chunks before it; only the first H chunks have lags that reach
+    // before the start of the frame (checked form)
     auto chunk = [&](auto checked, auto full) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
           const double xm = cur[u];
 #pragma unroll
           for (int i = 0; i < P; ++i) {
-            const double xe = (u - i >= 0) ? cur[u - i >= 0 ? u - i : 0] : hist[(i - u - 1) < H * 16 ? (i - u - 1) : 0];
+            const int d = u - i;              // (folded: u and i are unrolled loop indices)
+            const double xe = d >= 0 ? cur[d >= 0 ? d : 0] : d >= -16 ? p1[d >= -16 && d < 0 ? 16 + d : 0] : p2[d < -16 && d >= -32 ? 32 + d : 0];
             if constexpr (decltype(checked)::value) {
               if (u - i >= 0 || 16 * c + u - i >= 0) acc[i] = FMA ? __builtin_fma(xe, xm, acc[i]) : acc[i] + xe * xm;
             } else {
@@ -353,11 +359,17 @@ __global__ __launch_bounds__(64) void k_acorr_stage(const double *__restrict__ s
     if (c < H) chunk(std::true_type{}, std::false_type{});
     else chunk(std::false_type{}, std::false_type{});
 #endif
-    // history for the next chunk
-#pragma unroll
-    for (int k = H * 16 - 1; k >= 16; --k) hist[k] = hist[k - 16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hist[k] = cur[15 - k];
+  };
+  static_assert(H == 1 || H == 2, "one or two chunks of history");
+  for (int c = 0; c < nchunks; c += H + 1) {
+    if constexpr (H == 1) {
+      do_chunk(c, buf[0], buf[1], buf[1]);
+      if (c + 1 < nchunks) do_chunk(c + 1, buf[1], buf[0], buf[0]);
+    } else {
+      do_chunk(c, buf[0], buf[2], buf[1]);
+      if (c + 1 < nchunks) do_chunk(c + 1, buf[1], buf[0], buf[2]);
+      if (c + 2 < nchunks) do_chunk(c + 2, buf[2], buf[1], buf[0]);
+    }
   }
   if constexpr (LEV == 0) {
     if (live) {
