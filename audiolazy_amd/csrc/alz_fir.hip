@@ -231,6 +231,19 @@ __device__ __forceinline__ bool tap_absent(double t) {
   return sh == 0;
 }
 
+// Round 6, second half: the four taps of a block as ONE s_load_dwordx8 requested a whole block ahead, and the in-run row groups
+// without clamps.  hipcc had sunk `ring_load_taps(kb + K)` to the head of the block that uses it -- s_load + s_waitcnt lgkmcnt(0)
+// back to back, a scalar-cache round trip per 192 multiply-adds with the wave standing still (two waves per SIMD: the other one alone
+// fills ~80 % of it) -- and every group load of an interior run recomputed a 64-bit row product and three clamps that can never
+// bind there (~30 scalar instructions per block, in order, in the same wave that feeds the VALU).  0: the round-6 first-half form.
+#ifndef ALZ_FIR_PFTAPS
+#define ALZ_FIR_PFTAPS 1
+#endif
+typedef double fir_dbl4 __attribute__((ext_vector_type(4)));
+#define ALZ_FIR_SLOAD(d, ptr) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(d) : "s"(ptr) : "memory")
+#define ALZ_FIR_SWAIT(d) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d) : : "memory")
+#define ALZ_FIR_SWAIT2(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1) : : "memory")
+
 struct RingCtx {
   const FArgs *p;
   int64_t in, c, row_bytes;
@@ -302,6 +315,140 @@ __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, do
   }
 }
 
+#if ALZ_FIR_PFTAPS
+static_assert(kRingK == 4, "the prefetched tap block is one s_load_dwordx8");
+// one tap block (taps kb .. kb + K - 1) at ring phase PH: window row j lives in group
+// (j / K - PH) mod NG; group (-PF - PH) mod NG is free and takes the first rows of block kb + PF * K.
+// `tapv` was requested while the block before this one ran (ring_run: before the loop) and is waited for here;
+// `tapv_next` is requested here.  `gb` (interior runs): the address of the first row of the group this block requests --
+// it moves K rows towards the past per block and never leaves the input block (rows >= 0: `reach` in k_fir_ring;
+// rows <= t0 - PF K < n), so the descriptor is the bare address and the four row offsets are loop invariants.
+template <int PH, bool FMA, bool EDGE>
+__device__ __forceinline__ void ring_step(const RingCtx &q, int64_t t0, int kb, double (&xr)[kRingG][kRingK],
+                                          double (&acc)[kRingR], fir_dbl4 &tapv, fir_dbl4 &tapv_next, const char *&gb) {
+  constexpr int R = kRingR, K = kRingK, NG = kRingG;
+  constexpr int PF = kRingPF;
+  if constexpr (EDGE) {
+    ring_load_group<EDGE>(q, t0 - (kb + PF * K) - (K - 1), xr[(4 * NG - PF - PH) % NG]);   // unused after the last blocks
+  } else {
+    const int rb32 = (int)q.row_bytes;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gb, 0, 0x7fffffff, 0x00020000);
+    double (&dst)[K] = xr[(4 * NG - PF - PH) % NG];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      dst[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, q.lane_off, j * rb32, 0));
+    gb -= (int64_t)K * q.row_bytes;
+  }
+  ALZ_FIR_SWAIT(tapv);                                            // this block's taps (requested a block ago)
+  ALZ_FIR_SLOAD(tapv_next, q.taps + kb + K);                      // the next block's (all 0.0 past the end: padded array + the test below)
+  double tap[K];
+  {
+    const int nb = q.p->nb;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) tap[kk] = (kb + kk < nb) ? tapv[kk] : 0.0;
+  }
+#define ALZ_RING_X(j) xr[(((j) / K) + NG - PH) % NG][(j) % K]
+  auto one_tap = [&](auto KK) {
+    constexpr int kk = decltype(KK)::value;
+#pragma unroll
+    for (int r = 0; r < R; r += 4) {
+      if constexpr (FMA) {
+        // opt-in throughput mode (alz_bank_set_fused): one v_fma_f64 per tap and output, same ascending
+        // tap order, one rounding per term instead of two -- not the reference's doubles
+        acc[r] = __builtin_fma(tap[kk], ALZ_RING_X(r - kk + (K - 1)), acc[r]);
+        acc[r + 1] = __builtin_fma(tap[kk], ALZ_RING_X(r + 1 - kk + (K - 1)), acc[r + 1]);
+        acc[r + 2] = __builtin_fma(tap[kk], ALZ_RING_X(r + 2 - kk + (K - 1)), acc[r + 2]);
+        acc[r + 3] = __builtin_fma(tap[kk], ALZ_RING_X(r + 3 - kk + (K - 1)), acc[r + 3]);
+      } else {
+#if ALZ_FIR_MG == 2
+        {
+          const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
+          const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
+          acc[r] = acc[r] + m0;
+          acc[r + 1] = acc[r + 1] + m1;
+        }
+        {
+          const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
+          const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
+          acc[r + 2] = acc[r + 2] + m2;
+          acc[r + 3] = acc[r + 3] + m3;
+        }
+#else
+        const double m0 = tap[kk] * ALZ_RING_X(r - kk + (K - 1));
+        const double m1 = tap[kk] * ALZ_RING_X(r + 1 - kk + (K - 1));
+        const double m2 = tap[kk] * ALZ_RING_X(r + 2 - kk + (K - 1));
+        const double m3 = tap[kk] * ALZ_RING_X(r + 3 - kk + (K - 1));
+        acc[r] = acc[r] + m0;
+        acc[r + 1] = acc[r + 1] + m1;
+        acc[r + 2] = acc[r + 2] + m2;
+        acc[r + 3] = acc[r + 3] + m3;
+#endif
+      }
+    }
+  };
+  if (!tap_absent(tap[0])) one_tap(std::integral_constant<int, 0>{});
+  if (!tap_absent(tap[1])) one_tap(std::integral_constant<int, 1>{});
+  if (!tap_absent(tap[2])) one_tap(std::integral_constant<int, 2>{});
+  if (!tap_absent(tap[3])) one_tap(std::integral_constant<int, 3>{});
+#undef ALZ_RING_X
+}
+
+// NG is even: the two tap buffers swap roles with the parity of the phase
+static_assert(kRingG % 2 == 0, "the tap buffers alternate with the phase");
+template <int PH, bool FMA, bool EDGE>
+__device__ __forceinline__ void ring_steps(const RingCtx &q, int64_t t0, int &kb, double (&xr)[kRingG][kRingK],
+                                           double (&acc)[kRingR], fir_dbl4 &tap_a, fir_dbl4 &tap_b, const char *&gb,
+                                           bool &done) {
+  if constexpr (PH < kRingG) {
+    if (!done) {
+      if constexpr (PH % 2 == 0) ring_step<PH, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b, gb);
+      else ring_step<PH, FMA, EDGE>(q, t0, kb, xr, acc, tap_b, tap_a, gb);
+      kb += kRingK;
+      done = kb >= q.p->nb;
+    }
+    ring_steps<PH + 1, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b, gb, done);
+  }
+}
+
+#ifndef ALZ_FIR_WAVES
+#define ALZ_FIR_WAVES 2
+#endif
+// One run of R output rows per lane.  EDGE = false: every row the run touches (t0 - nb - K .. t0 + R - 1) lies
+// inside the block, so the window comes through buffer loads only -- no per-lane row pointers, no history
+// selects in the tap loop (that code kept ~16 more VGPRs live across the loop: the bit-exact instantiation
+// spilled 36 bytes per lane at R = 48).  EDGE = true: the first row tiles of a block, which reach into the
+// delay line (p.xh), and nothing else.
+template <bool FMA, bool EDGE>
+__device__ __forceinline__ void ring_run(const FArgs &p, const RingCtx &q, int64_t t0, bool live, double a0) {
+  constexpr int R = kRingR, K = kRingK, NG = kRingG;
+  double acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = -0.0;
+  double xr[NG][K];
+  fir_dbl4 tap_a, tap_b;
+  ALZ_FIR_SLOAD(tap_a, q.taps);
+  // logical group g holds rows t0 - (K - 1) + g K ..: g = 0 .. R / K are the window of block 0, g = -1 .. -(PF - 1)
+  // the first rows of blocks 1 .. PF - 1 (already in flight); logical g lives in physical (g + NG) % NG at phase 0
+#pragma unroll
+  for (int g = R / K; g >= -(kRingPF - 1); --g)
+    ring_load_group<EDGE>(q, t0 - (K - 1) + (int64_t)g * K, xr[(g + NG) % NG]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) xr[(NG - kRingPF) % NG][j] = 0.0;   // (the slot the first step loads into)
+  int kb = 0;
+  bool done = false;
+  const char *gb = (const char *)p.x + (t0 - (int64_t)kRingPF * K - (K - 1)) * q.row_bytes;   // (interior runs only)
+  asm volatile("" : "=s"(tap_b));                              // (no request yet: whatever it holds is never used)
+  while (!done) ring_steps<0, FMA, EDGE>(q, t0, kb, xr, acc, tap_a, tap_b, gb, done);
+  ALZ_FIR_SWAIT2(tap_a, tap_b);                                // the request behind the last block lands before its registers go
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = t0 + r;
+      if (t < p.n) p.y[t * p.syn + q.c] = p.div ? acc[r] / a0 : acc[r];
+    }
+  }
+}
+#else
 // one tap block (taps kb .. kb + K - 1) at ring phase PH: window row j lives in group
 // (j / K - PH) mod NG; group (-PF - PH) mod NG is free and takes the first rows of block kb + PF * K
 __device__ __forceinline__ void ring_load_taps(const RingCtx &q, int kb, double (&tap)[kRingK]) {
@@ -432,6 +579,8 @@ __device__ __forceinline__ void ring_run(const FArgs &p, const RingCtx &q, int64
     }
   }
 }
+
+#endif
 
 template <bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_FIR_WAVES, ALZ_FIR_WAVES)))
