@@ -88,6 +88,19 @@ PYEOF
     for f in "fuzz_sparse.py 300 606" "fuzz_timeparallel.py 100 1604" "fuzz_bank.py 200 1605" "fuzz_outer.py 100 1606" "fuzz_stream.py 120 1607"; do
       echo "== $f"; timeout 900 python tools/$f 2>&1 | tail -6 | cut -c1-400
     done 2>&1 | tee $O/fuzz_gpu.log ;;
+  lpcab)   # LPC modes through variant libraries, interleaved (LIBS="shipped lev_old ..."; MODES overrides the mode list), then the LPC tests
+    IFS=';' read -ra modes <<< "${MODES:---lpc-exact;--lpc-frames 1048576 --lpc-exact;;--lpc-frames 1048576}"
+    for rep in 1 2; do
+      for lib in ${LIBS:-shipped lev_old}; do
+        for m in "${modes[@]}"; do
+          if [ $lib = shipped ]; then unset ALZ_LIBRARY; else export ALZ_LIBRARY=$R/tools/variants/libalzhip_$lib.so; fi
+          timeout 300 python bench.py --workload lpc $m --no-cpu-baseline --no-secondary --steps 200 --warmup 50 --full-json - > $O/l.json 2> $O/l.err || tail -3 $O/l.err
+          echo "$lib [$m]: $(python tools/show_line.py $O/l.json | head -1 | cut -c1-120)"
+        done
+      done
+    done 2>&1 | tee $O/lpc_ab.log
+    unset ALZ_LIBRARY
+    timeout 900 python -m pytest tests/test_gpu_lpc.py tests/test_gpu_fullwidth.py -x -q -k "lpc or LPC or frames or levinson" 2>&1 | tail -3 | tee -a $O/lpc_ab.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
