@@ -196,6 +196,11 @@ __device__ __forceinline__ void section_chunk(double (&v)[W], const double (&bc)
 #ifndef ALZ_PIPE_PHASE
 #define ALZ_PIPE_PHASE 1
 #endif
+// where in a group stage s issues its hand-over's LDS operations: hex digit 3 - s of ALZ_PIPE_PHMAP (0x0123: stage s at slot s)
+#ifndef ALZ_PIPE_PHMAP
+#define ALZ_PIPE_PHMAP 0x0123
+#endif
+constexpr int c_pipe_slot(int stage) { return ALZ_PIPE_PHASE ? ((ALZ_PIPE_PHMAP >> (4 * (3 - stage))) & 0xf) : 0; }
 constexpr int c_popcount(unsigned v) { int n = 0; for (int k = 0; k < 8; ++k) n += (v >> k) & 1u; return n; }
 constexpr int c_kth_tap(unsigned pb, int n) {      // delay of the n-th present tap
   for (int k = 0; k < 8; ++k)
@@ -277,7 +282,7 @@ __device__ __forceinline__ void section_tile_hook(const double (&v)[16], const d
   for (int j = 0; j < 8; ++j) {
     // the hand-over's LDS operations of this group, at the place PH selects
     auto lds_ops = [&](int slot) {
-      if (slot == (ALZ_PIPE_PHASE ? PH : 0)) {
+      if (slot == c_pipe_slot(PH)) {
         hook(j);
         ALZ_PIN();
       }

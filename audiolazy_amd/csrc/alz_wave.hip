@@ -386,6 +386,11 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_FMA_ORDER
 #define ALZ_DUO_FMA_ORDER 0
 #endif
+// Which FMA instantiations have the storing wave.  Round 6 (profiles/r06_duo_fma_storer.log, 4096 channels x 2^20, one box,
+// interleaved): CHANNEL-major with non-temporal tiles 349 - 350 Gsamples/s (0.70) against 323 for the two-wave FMA kernel; TIME-major
+// 298 - 304 against the default kernel's 323 - 326 (and 269 with the paced pass on top) -- so the channel-major non-temporal FMA
+// instantiations get the third wave, the time-major ones keep their form and launch_wave keeps the default kernel for that shape.
+constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || (cm && nt); }
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
@@ -407,8 +412,8 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
 template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0, bool NT = false>
-__global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
-  constexpr bool STORER = ALZ_DUO_STORER && (!FMA || ALZ_DUO_FMA3) && !NOSTORE;    // a third wave stores the finished tiles
+__global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT)) && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
+  constexpr bool STORER = ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT)) && !NOSTORE;    // a third wave stores the finished tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = 16, T = 64;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -831,7 +836,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // tile, not by the recurrence, and the default kernel has the storing wave, the non-temporal tiles and the paced pass
   // for it: 306 - 326 Gsamples/s against the FMA kernel's 295 - 304 (profiles/NOTES_r04.md 5, NOTES_r05.md 10).  Everywhere
   // else the FMA kernels are 2 - 12 % ahead.  The default kernel's doubles are within every contract of the mode.
-  const bool fused = io.fused && !(g == 16 && !cm && !ch && groups >= 256 && groups <= 320);
+  const bool fused = io.fused && (ALZ_DUO_FMA3 || !(g == 16 && !cm && !ch && groups >= 256 && groups <= 320));   // (variant builds with the storing wave in the FMA kernels: no exception)
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = ALZ_TUNE("ALZ_DUO", 1);
   const bool nostore = ch && ch->nostore;
@@ -842,7 +847,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
   const bool prefer_single = g == 16 && lanes >= single_from && !ch;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
-  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
+  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
@@ -859,13 +864,13 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
                    : (cm ? pick_duo_pattern<true, false, false, false, 1>(sec.present_b, sec.present_a)
                          : pick_duo_pattern<false, false, false, false, 1>(sec.present_b, sec.present_a));
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
+    if (fused && nt_tiles && cm)
+      duo_fma = true, duo = pick_duo_pattern<true, true, false, false, 0, true>(sec.present_b, sec.present_a);
 #if ALZ_DUO_FMA3
-    if (fused && nt_tiles)
-      duo_fma = true, duo = cm ? pick_duo_pattern<true, true, false, false, 0, true>(sec.present_b, sec.present_a)
-                               : pick_duo_pattern<false, true, false, false, 0, true>(sec.present_b, sec.present_a);
-    else
+    else if (fused && nt_tiles)
+      duo_fma = true, duo = pick_duo_pattern<false, true, false, false, 0, true>(sec.present_b, sec.present_a);
 #endif
-    if (fused)
+    else if (fused)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
     else
@@ -917,7 +922,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
     if (rc) return rc;
   }
   if (ch && ch->n_chunks > 65535) return ALZ_OK;
-  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? ((ALZ_DUO_STORER && (!duo_fma || ALZ_DUO_FMA3) && !nostore) ? 192 : 128) : 64), lds,
+  hipLaunchKernelGGL(fn, dim3((unsigned)groups, (unsigned)(ch ? ch->n_chunks : 1)), dim3(duo ? ((ALZ_DUO_STORER && (!duo_fma || duo_fma_storer(cm, nt_tiles)) && !nostore) ? 192 : 128) : 64), lds,
                      stream, p);
   ALZ_HIP_CHECK(hipGetLastError());
   *done_samples = tiles * t;

@@ -256,6 +256,37 @@ def test_cfg2_full_block_length_on_strided_channels(alz, oracle, bench):
   assert same_bits(got, ref)
 
 
+@pytest.mark.parametrize("C,N", [(4096, 1 << 14), (512, 1 << 17), (1040, 70000)])
+def test_fused_channel_major_streaming_block_storing_wave(alz, oracle, bench, C, N):
+  """The opt-in FMA mode on channel-major blocks of 256 MiB and more (round 6): k_duo's fused instantiation with the storing
+  wave and non-temporal tiles (349 against 323 Gsamples/s at 4096 channels).  Strided channels over the whole block within
+  the mode's tolerance, a second block continuing the stream, and the same doubles as the two-wave FMA kernel gives on a
+  block below the streaming size (the recurrence is the same code: only who stores differs)."""
+  import torch
+  if C * N * 8 < (256 << 20):
+    N = ((256 << 20) // (8 * C) // 64 + 1) * 64
+  b, a = bench.resonator_coefs(C)
+  x = _gpu_noise((C, N), 21)
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  bank.reset()
+  y = bank.process(x, layout="chan")
+  assert "fma" in bank.last_kernel, bank.last_kernel
+  y2 = bank.process(x, layout="chan")                        # the same input again, from the carried state
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 24).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  got = torch.cat([y.index_select(0, idx), y2.index_select(0, idx)], dim=1).cpu().numpy()
+  xs = x.index_select(0, idx).cpu().numpy()
+  ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate([xs, xs], axis=1), layout="chan")
+  assert norm_err(got, ref, 1) <= 1e-10 and not same_bits(got, ref)
+  # a short block (two-wave FMA kernel) from a fresh state: bitwise the head of the long block's result
+  short = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  short.reset()
+  n0 = 4096
+  ys = short.process(x[:, :n0].contiguous(), layout="chan")
+  assert "fma" in short.last_kernel
+  assert torch.equal(ys, y[:, :n0])
+
+
 @pytest.mark.parametrize("mode", [True, "one-pass"])
 def test_narrow_bank_time_parallel_full_block_length(alz, oracle, bench, mode):
   """The time-parallel modes over a whole 2^20-sample block of the 512-channel shard (2048 chunk boundaries in the

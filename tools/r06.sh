@@ -101,6 +101,28 @@ PYEOF
     done 2>&1 | tee $O/lpc_ab.log
     unset ALZ_LIBRARY
     timeout 900 python -m pytest tests/test_gpu_lpc.py tests/test_gpu_fullwidth.py -x -q -k "lpc or LPC or frames or levinson" 2>&1 | tail -3 | tee -a $O/lpc_ab.log ;;
+  duofma)  # configs[1] in the opt-in FMA mode: k_duo's fused instantiations with the storing wave / non-temporal tiles / paced pass (variant
+           # builds of alz_wave.hip: -DALZ_DUO_FMA3=1 [-DALZ_DUO_FMA_ORDER=1] [-DALZ_PACE_ALL=1]) against the shipped rule (default kernel)
+    for rep in 1 2; do
+      for lib in ${LIBS:-shipped duo_fma3 duo_fma3o duo_fma3op}; do
+        for m in "--fused" "--fused --layout chan"; do
+          if [ $lib = shipped ]; then unset ALZ_LIBRARY; else export ALZ_LIBRARY=$R/tools/variants/libalzhip_$lib.so; fi
+          timeout 300 python bench.py --workload biquad $m --no-cpu-baseline --no-secondary --steps 10 --warmup 3 --full-json - > $O/l.json 2> $O/l.err || tail -3 $O/l.err
+          echo "$lib [$m]: $(python tools/show_line.py $O/l.json | head -1 | cut -c1-170)"
+        done
+      done
+    done 2>&1 | tee $O/duo_fma.log ;;
+  pipeph)  # configs[3]: where in a group each stage wave of k_pipe issues its hand-over's LDS operations (variant builds of alz_casc.hip,
+           # -DALZ_PIPE_PHMAP=0x....; libalzhip_pipe_ph<map>.so), warm-chip protocol, interleaved
+    for rep in 1 2; do
+      for lib in ${LIBS:-shipped pipe_ph0222 pipe_ph0202 pipe_ph2222 pipe_ph0212 pipe_ph0321 pipe_ph0220}; do
+        for m in "" ${MODES:-"--fused"}; do
+          if [ $lib = shipped ]; then unset ALZ_LIBRARY; else export ALZ_LIBRARY=$R/tools/variants/libalzhip_$lib.so; fi
+          timeout 300 python bench.py --workload gammatone $m --no-cpu-baseline --no-secondary --steps 60 --warmup 30 --full-json - > $O/l.json 2> $O/l.err || tail -3 $O/l.err
+          echo "$lib [$m]: $(python tools/show_line.py $O/l.json | head -1 | cut -c1-140)"
+        done
+      done
+    done 2>&1 | tee $O/pipe_phase.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
