@@ -327,6 +327,30 @@ def test_fir_shared_taps_kernels_shapes(alz, oracle, nb, N, gain):
   assert same_bits(bank.process(x2), whole[N:])
 
 
+@pytest.mark.parametrize("nb1,nb2", [(17, 21), (18, 3), (130, 27)])
+def test_fir_ring_section_followed_by_another_sections_taps(alz, oracle, nb1, nb2):
+  """k_fir_ring requests the taps of a block one block ahead (round 6) and reads whole blocks of four: past the end of a section
+  whose tap count is not a multiple of four that is the NEXT section's taps in the coefficient slab -- non-zero numbers that must
+  not enter the sum.  A feedback-free section of nb1 taps followed by a second section, bit for bit, with a continuation block."""
+  rng = np.random.default_rng(nb1 * 31 + nb2)
+  C, N = 70, 700
+  b1, b2 = rng.uniform(-1, 1, nb1), rng.uniform(1, 2, nb2)    # (the second section's taps: all well away from zero)
+  a2 = np.array([1.0]) if nb2 > 3 else np.array([1.0, -0.5, 0.25])
+  x = rng.uniform(-1, 1, (N, C))
+  bank = alz.FilterBank([(b1, [1.0]), (b2, a2)], n_inputs=C)
+  bank.reset()
+  y = bank.process(x)
+  x2 = rng.uniform(-1, 1, (50, C))
+  y2 = bank.process(x2)
+  whole = oracle.bank([nb1, nb2], [1, len(a2)], np.concatenate([b1, b2]), np.concatenate([[1.0], a2]), np.concatenate([x, x2]))
+  assert same_bits(y, whole[:N]) and same_bits(y2, whole[N:])
+  # the first section alone runs on the ring kernel (what the cascade's first stage is)
+  alone = alz.FilterBank([(b1, [1.0])], n_inputs=C)
+  alone.reset()
+  alone.process(x)
+  assert alone.last_kernel == "k_fir_ring"
+
+
 def test_fir_per_channel_taps_zero_taps_and_gain(alz, oracle):
   rng = np.random.default_rng(77)
   C, N, nb = 96, 400, 40
