@@ -123,6 +123,18 @@ PYEOF
         done
       done
     done 2>&1 | tee $O/pipe_phase.log ;;
+  cascskew) # k_casc: the sections of a cascade in one skewed sweep (shipped) against section after section (-DALZ_CASC_SKEW=0): the
+           # one-stream filterbank in time-parallel mode (both layouts) and a bank wide enough for the single-wave cascade (256 streams)
+    timeout 900 python -m pytest tests -x -q -m gpu -k "casc or cscan or outer or cfg4 or gammatone or cascade" > $O/casc_tests.log 2>&1; echo "cascade tests rc=$?"; tail -3 $O/casc_tests.log
+    for rep in 1 2; do
+      for lib in ${LIBS:-shipped casc_noskew}; do
+        for m in "--streams 1 --log2-samples 20 --time-parallel 1 --bank-layout chan" "--streams 1 --log2-samples 20 --time-parallel 1 --bank-layout time" "--streams 256 --bank-layout chan" "--streams 256 --bank-layout time"; do
+          if [ $lib = shipped ]; then unset ALZ_LIBRARY; else export ALZ_LIBRARY=$R/tools/variants/libalzhip_$lib.so; fi
+          timeout 300 python bench.py --workload gammatone $m --no-cpu-baseline --no-secondary --steps 30 --warmup 10 --full-json - > $O/l.json 2> $O/l.err || tail -3 $O/l.err
+          echo "$lib [$m]: $(python tools/show_line.py $O/l.json | head -1 | cut -c1-170)"
+        done
+      done
+    done 2>&1 | tee $O/casc_skew.log ;;
   suite)   suite; smoke ;;
   final)   suite; smoke; driver; stats ;;
   py)      timeout ${T:-900} python "$@" 2>&1 | tee $O/py_$(basename $1 .py).log | tail -${TAIL:-40} ;;
