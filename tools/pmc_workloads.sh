@@ -46,3 +46,5 @@ run comb_fb_chan --workload comb --layout chan
 run karplus_one_string --workload comb --channels 1 --log2-samples 22 --comb-delay 109 --comb-linearized --layout chan
 run iir_order6 --workload butter6
 run maverage_recursive_256 --workload maverage256
+run biquad_chan --layout chan
+run biquad_chan_fma --layout chan --fused
