@@ -53,6 +53,7 @@ struct CArgs {
   // and input index follow the real channel; state lives in per-virtual-channel arrays (channels = all vc).
   int64_t kchunks, ldx_outer, ldy_outer;
   int nostore;   // the zero-state pass: run for the end state only
+  int stagger;   // channel-major blocks: workgroup g starts g * stagger ticks (10 ns) late (alz_common.h: stagger_start)
   // chunk-major virtual channels (k_casc only): vc = chunk * creal + real_channel, so a 64-channel group is 64 adjacent
   // real channels of ONE chunk (creal % 64 == 0).  Time-major blocks: whole 512-byte row pieces in x and y, chunk_len
   // rows further down per chunk.  Channel-major blocks with ONE input stream (BC): 64 output rows, chunk_len samples in.
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(64) void k_casc(CArgs p) {
   const bool outer = p.mode == ALZ_BANK_OUTER;
   const int64_t set = c_set(p, c);
   const CGroup grp = c_group(p, c0);
+  stagger_start((unsigned)p.stagger, blockIdx.x & 63u);
 
   int64_t x_off, y_off, x_chunk, y_chunk, x_tile, y_tile;
   const double *xb = p.x;                                // BC: the group's input stream at its chunk's first row
@@ -847,6 +849,7 @@ __global__ __launch_bounds__(64 * (4 / SPW + 2), G == 32 ? 4 : 1) void k_pipe(CA
   const int64_t set = c_set(p, c);
   const CGroup grp = c_group(p, c0);
   const int64_t nt = p.n_tiles;
+  stagger_start((unsigned)p.stagger, blockIdx.x & 63u);
   // stage w reads tile t - LAG w (and, overlapped, computes tile t - LAG w - 1) in interval t;
   // the storer writes out tile t - store_lag; every wave passes the same n_iv barriers
   constexpr int store_lag = DEPHASE ? 5 : LAG * NW;
@@ -1389,6 +1392,9 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   p.dbg = dbg_env;
   p.kchunks = 0; p.ldx_outer = 0; p.ldy_outer = 0; p.nostore = 0;
   p.chunk_tm = 0; p.creal = io.channels; p.chunk_len = 0;
+  // (stagger_start, alz_common.h: the one-stream filterbank's channel-major replay -- 1024 lone waves in lock-step over rows 8 MiB
+  // apart -- gains 2 % from 64 start phases 0.1 us apart, 415 - 418 -> 423 - 426 Gsamples/s; k_pipe and the time-major forms gain nothing)
+  p.stagger = ALZ_TUNE("ALZ_CASC_STAGGER", (bcast && cm && !pipe) ? 10 : 0);
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;

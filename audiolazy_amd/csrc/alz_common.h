@@ -30,6 +30,21 @@
 
 namespace alz {
 
+#if defined(__HIPCC__)
+// Lock-step and power-of-two rows (round 6, profiles/NOTES_r06.md 8.7).  The workgroups of a recurrence kernel leave their start
+// together and advance at the same step rate, so at every moment all of them touch the same offset n of their own rows -- on a
+// channel-major block whose rows lie 2^k bytes apart that is the same few HBM channels for the whole chip, and which ones the
+// reads and the writes collide on depends on where the caller's two buffers happen to lie (the same kernel on the same shape:
+// 12.3 ms in one process, 16.8 in another).  Workgroup g therefore starts g * ticks of the 100 MHz clock late: the chip's
+// accesses spread over a window of the rows instead of a point, whatever the placement.  Costs the last workgroup's delay once.
+__device__ __forceinline__ void stagger_start(unsigned ticks, unsigned group) {
+  if (ticks != 0u) {
+    const long long until = (long long)wall_clock64() + (long long)group * (long long)ticks;
+    while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+  }
+}
+#endif
+
 // thread-local last-error message (alz_last_error)
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);

@@ -58,6 +58,7 @@ struct WArgs {
   // All three are 0 in an ordinary launch (gridDim.y == 1).
   int64_t chunk_x, chunk_y, chunk_c;
   int aux_pace;   // k_duo, one-pole banks that fill the chip: pauses (x 64 cycles) between the quarters of AUX's feed-forward pass
+  int stagger;    // k_duo, channel-major: workgroup g starts g * stagger ticks (10 ns) late (0: all together) -- see launch_wave
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -425,6 +426,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
   const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
+  if constexpr (CM) stagger_start((unsigned)p.stagger, blockIdx.x);
   char *xring = smem;
   // p and y rings are written and read only by this kernel's own lanes, so their layout is free:
   // channel-major keeps 16 bytes after EVERY channel (a half-wave -- 16 channels x 2 lane groups --
@@ -911,6 +913,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
   p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
+  // Channel-major blocks of a bank that fills the chip about once: the workgroups start 0.2 us apart (stagger_start, alz_common.h) --
+  // in lock-step every workgroup touches the same offset of its own row, rows lie a power of two apart, and where the input and
+  // the output block lie relative to each other then decides between 12.3 and 16.8 ms for the same launch (4096 channels x 2^20,
+  // FMA mode; profiles/NOTES_r06.md 8.7: with the stagger 12.3 ms for every placement tried, on every box).  Long blocks only:
+  // the last workgroup's delay (groups x 0.2 us) is paid once.
+  p.stagger = (duo && cm && !ch && groups >= 64 && groups <= 512 && tiles >= 8192) ? ALZ_TUNE("ALZ_DUO_STAGGER", 20) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
