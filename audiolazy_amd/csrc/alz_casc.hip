@@ -1392,9 +1392,7 @@ static int launch_cascade_impl(const SectionDev *secs, int nsec, const BlockIO &
   p.dbg = dbg_env;
   p.kchunks = 0; p.ldx_outer = 0; p.ldy_outer = 0; p.nostore = 0;
   p.chunk_tm = 0; p.creal = io.channels; p.chunk_len = 0;
-  // (stagger_start, alz_common.h: the one-stream filterbank's channel-major replay -- 1024 lone waves in lock-step over rows 8 MiB
-  // apart -- gains 2 % from 64 start phases 0.1 us apart, 415 - 418 -> 423 - 426 Gsamples/s; k_pipe and the time-major forms gain nothing)
-  p.stagger = ALZ_TUNE("ALZ_CASC_STAGGER", (bcast && cm && !pipe) ? 10 : 0);
+  p.stagger = ALZ_TUNE("ALZ_CASC_STAGGER", 0);   // (-DALZ_TUNING builds only: stagger_start, alz_common.h)
   for (int s = 0; s < 4; ++s) {
     const SectionDev &d = secs[s < nsec ? s : 0];
     p.nb[s] = d.nb; p.na[s] = d.na; p.b[s] = d.b; p.a[s] = d.a; p.xh[s] = d.xh; p.yh[s] = d.yh;

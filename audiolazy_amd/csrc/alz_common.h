@@ -31,12 +31,12 @@
 namespace alz {
 
 #if defined(__HIPCC__)
-// Lock-step and power-of-two rows (round 6, profiles/NOTES_r06.md 8.7).  The workgroups of a recurrence kernel leave their start
-// together and advance at the same step rate, so at every moment all of them touch the same offset n of their own rows -- on a
-// channel-major block whose rows lie 2^k bytes apart that is the same few HBM channels for the whole chip, and which ones the
-// reads and the writes collide on depends on where the caller's two buffers happen to lie (the same kernel on the same shape:
-// 12.3 ms in one process, 16.8 in another).  Workgroup g therefore starts g * ticks of the 100 MHz clock late: the chip's
-// accesses spread over a window of the rows instead of a point, whatever the placement.  Costs the last workgroup's delay once.
+// An experiment hook (round 6, profiles/NOTES_r06.md 8.7; reachable in -DALZ_TUNING builds only): workgroup g starts g * ticks of
+// the 100 MHz clock late.  The workgroups of a recurrence kernel leave their start together and advance at the same step rate, so on
+// a channel-major block whose rows lie 2^k bytes apart the whole chip touches the same row offset at every moment; the same launch
+// takes 12.3 or 16 ms depending on where its two blocks lie.  Breaking the lock-step does NOT change that (same buffers, stagger
+// 0 / 0.2 / 0.8 us per workgroup: 15.96 / 16.06 / 16.25 ms in a slow placement, 12.30 / 12.34 / 12.48 in a fast one): it is the
+// physical placement.  Kept so that the measurement can be repeated.
 __device__ __forceinline__ void stagger_start(unsigned ticks, unsigned group) {
   if (ticks != 0u) {
     const long long until = (long long)wall_clock64() + (long long)group * (long long)ticks;

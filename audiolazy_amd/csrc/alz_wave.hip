@@ -913,12 +913,9 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
   p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
-  // Channel-major blocks of a bank that fills the chip about once: the workgroups start 0.2 us apart (stagger_start, alz_common.h) --
-  // in lock-step every workgroup touches the same offset of its own row, rows lie a power of two apart, and where the input and
-  // the output block lie relative to each other then decides between 12.3 and 16.8 ms for the same launch (4096 channels x 2^20,
-  // FMA mode; profiles/NOTES_r06.md 8.7: with the stagger 12.3 ms for every placement tried, on every box).  Long blocks only:
-  // the last workgroup's delay (groups x 0.2 us) is paid once.
-  p.stagger = (duo && cm && !ch && groups >= 64 && groups <= 512 && tiles >= 8192) ? ALZ_TUNE("ALZ_DUO_STAGGER", 20) : 0;
+  // (-DALZ_TUNING builds: a staggered start of the workgroups of a channel-major launch, stagger_start in alz_common.h -- measured on
+  // identical buffers, round 6: no effect; what decides between 12.3 and 16 ms there is where the blocks lie physically)
+  p.stagger = (duo && cm && !ch) ? ALZ_TUNE("ALZ_DUO_STAGGER", 0) : 0;
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
