@@ -387,6 +387,9 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #ifndef ALZ_DUO_FMA_ORDER
 #define ALZ_DUO_FMA_ORDER 0
 #endif
+#ifndef ALZ_DUO_AUXROWS
+#define ALZ_DUO_AUXROWS 1    // time-major: the helper wave's lane groups own 16 consecutive rows each (0: rows 4 j + q)
+#endif
 // Which FMA instantiations have the storing wave.  Round 6 (profiles/r06_duo_fma_storer.log, 4096 channels x 2^20, one box,
 // interleaved): CHANNEL-major with non-temporal tiles 349 - 350 Gsamples/s (0.70) against 323 for the two-wave FMA kernel; TIME-major
 // 298 - 304 against the default kernel's 323 - 326 (and 269 with the paced pass on top) -- so the channel-major non-temporal FMA
@@ -553,6 +556,54 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
       // (channel-major 267 - 313 -> 319 - 356; profiles/NOTES_r04.md 4).
       bool paced = false;
       if constexpr (((PB == 1u && PA == 1u) || ALZ_PACE_ALL) && (!FMA || ALZ_DUO_FMA3) && !NOSTORE) paced = p.aux_pace > 0;
+      if constexpr (!CM && (PB & 6u) != 0 && ALZ_DUO_AUXROWS && FMA && !STORER) {
+        // Time-major two-wave FMA instantiations, numerators with more than b0 (round 6): lane group q owns the 16 CONSECUTIVE rows
+        // 16 q .. 16 q + 15, so the delayed samples of a row are the registers that held the rows before it -- 18 LDS reads per
+        // tile instead of 48 (the interleaved ownership 4 j + q reads every tap's row again).  Same products and sums per
+        // (row, channel): the p ring receives identical doubles.  Measured (profiles/r06_duo_rows.log, same box, interleaved):
+        // 2048 channels x 2^20 in the FMA mode 171.3 -> 180.9 Gsamples/s (+5.6 %); with the storing wave -- the default kernel
+        // (324.8 -> 323.7) and the three-wave FMA variant (294.6 -> 287.2) -- it loses (the four lane groups then write p rows
+        // 2 KiB apart), so those keep rows 4 j + q.
+        const char *xq = xs + q * (16 * kStep + 32);           // row 16 q of the tile (a 16-byte pad after every 8 rows)
+        double xr[16], xm1, xm2;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xr[j] = pre_in<PRE>(*reinterpret_cast<const double *>(xq + ALZ_EOFF(j)));
+        {
+          double pm1, pm2;                                     // the two rows before the tile
+          if (t > 0) {
+            pm1 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 1)));
+            pm2 = pre_in<PRE>(*reinterpret_cast<const double *>(xp + ALZ_EOFF(T - 2)));
+          } else {
+            pm1 = d1;
+            pm2 = d2;
+          }
+          // rows 16 q - 1 and 16 q - 2 of this tile for q > 0 (the pad before row 16 q lies between)
+          const double t1 = pre_in<PRE>(*reinterpret_cast<const double *>(xq - 16 - kStep + (q == 0 ? 16 + kStep : 0)));
+          const double t2 = pre_in<PRE>(*reinterpret_cast<const double *>(xq - 16 - 2 * kStep + (q == 0 ? 16 + 2 * kStep : 0)));
+          xm1 = q == 0 ? pm1 : t1;
+          xm2 = q == 0 ? pm2 : t2;
+        }
+        char *pq = ps + q * 16 * kStep;                        // rows 16 q + j of the p tile (unpadded rows)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double a1 = j >= 1 ? xr[j >= 1 ? j - 1 : 0] : xm1;
+          const double a2 = j >= 2 ? xr[j >= 2 ? j - 2 : 0] : (j == 1 ? xm1 : xm2);
+          double acc = 0.0;
+          bool first = true;
+          if constexpr (PB & 1u) { acc = b0 * xr[j]; first = false; }
+          if constexpr (PB & 2u) {
+            if (FMA && !first) acc = __builtin_fma(b1, a1, acc);
+            else { const double v = b1 * a1; acc = first ? v : acc + v; }
+            first = false;
+          }
+          if constexpr (PB & 4u) {
+            if (FMA && !first) acc = __builtin_fma(b2, a2, acc);
+            else { const double v = b2 * a2; acc = first ? v : acc + v; }
+            first = false;
+          }
+          *reinterpret_cast<double *>(pq + j * kStep) = acc;
+        }
+      } else
       if (paced) {
         const int units = p.aux_pace & 15;
         if (p.aux_pace & 16) {                   // eighths
