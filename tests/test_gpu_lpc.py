@@ -211,17 +211,18 @@ def test_exact_mode_vs_oracle_all_frames(lpc, order):
   assert same_bits(e[ok], re[ok])
 
 
-@pytest.mark.parametrize("order", [16, 8, 12])
-def test_exact_mode_waves_that_leave_the_regular_step(lpc, order):
+@pytest.mark.parametrize("order,waves", [(16, 5), (8, 5), (12, 5), (16, 256), (8, 256)])
+def test_exact_mode_waves_that_leave_the_regular_step(lpc, order, waves):
   """The dense Levinson-Durbin's select-free step (round 6) is taken while EVERY lane of a wave is regular; these frames make single
   lanes irregular at different steps, in different waves: an impulse (every reflection coefficient exactly zero: the dense
   coefficient list shrinks from step 1 on), two pulses three samples apart (zeros at steps 1 - 2, not at 3), a silent frame
   (ParCorError at step 1), a frame that is silent but for its last sample, and a constant frame -- each among random frames,
-  with a ragged last wave.  Coefficients, error and status of every frame against the oracle, bit for bit."""
+  with a ragged last wave.  Coefficients, error and status of every frame against the oracle, bit for bit.  5 waves: lags and
+  Levinson-Durbin in two launches (k_levinson_dense, partial last wave); 256 waves: the one-launch staged kernel."""
   from oracle import oracle
   from audiolazy_amd import _ffi
   rng = np.random.default_rng(100 + order)
-  F, L = 64 * 5 + 7, 96
+  F, L = 64 * waves + 7, 96
   sig = rng.uniform(-1, 1, F * L)
   def frame(i):
     return sig[i * L:(i + 1) * L]
@@ -229,7 +230,7 @@ def test_exact_mode_waves_that_leave_the_regular_step(lpc, order):
   frame(70)[:] = 0.0; frame(70)[10] = 1.0; frame(70)[13] = 0.5   # wave 1: lags 1, 2 exactly zero
   frame(131)[:] = 0.0                                        # wave 2: silent
   frame(200)[:] = 0.0; frame(200)[L - 1] = -0.75             # wave 3
-  frame(322)[:] = 0.25                                       # ragged last wave: constant
+  frame(F - 5)[:] = 0.25                                     # ragged last wave: constant
   c, e, st = lpc.kautocor_frames(sig, L, order, exact=True)
   rc, re, rs = oracle.kautocor_frames(sig, F, L, L, order)
   assert np.array_equal(st, rs) and st[131] == _ffi.E_PARCOR
