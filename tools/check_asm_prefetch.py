@@ -1,32 +1,45 @@
 #!/usr/bin/env python3
-"""k_fir_ring requests a block's taps with a hand-written s_load_dwordx8 and waits for them a block later.  The compiler does not
-know that the destination registers are in flight in between: this script reads a device assembly listing of alz_fir.hip
-(hipcc -S --cuda-device-only) and reports any instruction that touches the destination SGPRs of such a load before the next
-`s_waitcnt lgkmcnt(0)` along the fall-through path (conditional branches are scanned straight through, an unconditional one ends
-the scan).   usage: tools/check_asm_prefetch.py fir.s"""
+"""k_fir_ring (alz_fir.hip) and k_cdot3 (alz_scan.hip) request scalar operands with hand-written s_load_dwordx8 / x16 and wait
+for them a block of arithmetic later.  The compiler does not know that the destination registers are in flight in between: this
+script reads a device assembly listing (hipcc -S --cuda-device-only) and reports any instruction that touches the destination
+SGPRs of such a request before the next `s_waitcnt lgkmcnt(0)` along the fall-through path (conditional branches are scanned
+straight through, an unconditional one ends the scan).   usage: tools/check_asm_prefetch.py file.s"""
 import re, sys
 lines = open(sys.argv[1]).read().split("\n")
 bad = n = open_ends = 0
-for i, l in enumerate(lines):
-  m = re.match(r"\s+s_load_dwordx8 s\[(\d+):(\d+)\], s\[\d+:\d+\], 0x0", l)
-  if not (m and ";;#ASMSTART" in lines[i - 1]):
+i = 0
+while i < len(lines):
+  if ";;#ASMSTART" not in lines[i]:
+    i += 1
     continue
-  lo, hi = int(m.group(1)), int(m.group(2))
+  j = i + 1
+  dst = []
+  while j < len(lines) and ";;#ASMEND" not in lines[j]:
+    m = re.match(r"\s+s_load_dwordx(?:8|16) s\[(\d+):(\d+)\], s\[\d+:\d+\], 0x0", lines[j])
+    if m:
+      dst.append((int(m.group(1)), int(m.group(2))))
+    j += 1
+  i = j + 1
+  if not dst:
+    continue
   n += 1
-  for j in range(i + 1, min(len(lines), i + 4000)):
-    t = lines[j]
+  for k in range(j + 1, min(len(lines), j + 6000)):
+    t = lines[k]
     if "s_waitcnt lgkmcnt(0)" in t:
       break
     if re.match(r"\s+(s_branch|s_endpgm|s_setpc_b64)\b", t):   # the listing's next line is another path: not followed
       open_ends += 1
       break
-    if t.strip().startswith(";") or "s_load_dwordx8" in t:
+    if t.strip().startswith(";") or not t.startswith("\t"):
       continue
-    hit = any(not (int(b) < lo or int(a) > hi) for a, b in re.findall(r"s\[(\d+):(\d+)\]", t)) or \
-          any(lo <= int(r) <= hi for r in re.findall(r"\bs(\d+)\b", t))
+    hit = False
+    for lo, hi in dst:
+      if any(not (int(b) < lo or int(a) > hi) for a, b in re.findall(r"s\[(\d+):(\d+)\]", t)) or \
+         any(lo <= int(r) <= hi for r in re.findall(r"\bs(\d+)\b", t)):
+        hit = True
     if hit:
       bad += 1
-      print("touched before the wait: line %d: %s" % (j + 1, t.strip()))
+      print("touched before the wait: line %d: %s" % (k + 1, t.strip()))
       break
-print("hand-written tap loads: %d, violations: %d (scans that ended at an unconditional branch: %d)" % (n, bad, open_ends))
+print("hand-written scalar requests: %d, violations: %d (scans that ended at an unconditional branch: %d)" % (n, bad, open_ends))
 sys.exit(1 if bad or n == 0 else 0)
