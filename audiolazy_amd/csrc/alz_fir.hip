@@ -315,6 +315,10 @@ __device__ __forceinline__ void ring_load_group(const RingCtx &q, int64_t tb, do
   }
 }
 
+#if ALZ_FIR_PFTAPS && ALZ_FIR_RING_K != 4
+#undef ALZ_FIR_PFTAPS
+#define ALZ_FIR_PFTAPS 0      // (tile variants with another tap-block length: the round-6 first-half form)
+#endif
 #if ALZ_FIR_PFTAPS
 static_assert(kRingK == 4, "the prefetched tap block is one s_load_dwordx8");
 // one tap block (taps kb .. kb + K - 1) at ring phase PH: window row j lives in group
