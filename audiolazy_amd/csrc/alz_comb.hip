@@ -36,6 +36,8 @@ static constexpr int kMaxTaps = 8;      // per side
 static constexpr int kMinDelay = 16;    // smallest feedback delay these kernels accept
 static constexpr int kBatch = 8;        // k_sparse: rows per batch (< kMinDelay)
 
+constexpr int kCombPaceGBps = 5900;          // k_comb_tm's common step clock (launch_sparse)
+
 struct SArgs {
   const double *x;
   double *y;
@@ -50,6 +52,7 @@ struct SArgs {
   const double *xh, *yh;        // histories: xh[k*C + c] = x[-1-k]
   int T;                        // k_comb_*: samples per step (<= the shortest feedback delay)
   int ring, xring;              // k_comb_tm: rows of the y ring; k_comb_cm: samples of the y / x ring (powers of two)
+  int step_pace;                // k_comb_tm: the common step clock (alz_common.h pace_wait; 0: free-running)
 };
 
 __global__ __launch_bounds__(64) void k_sparse(SArgs p) {
@@ -171,7 +174,10 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
   }
   if constexpr (NFB > 0) __syncthreads();
   int q0 = 0;                                                           // n0 mod R
-  for (int64_t n0 = 0; n0 < N; n0 += T) {
+  const long long pace0 = p.step_pace > 0 ? (long long)wall_clock64() : 0;
+  long long step = 0;
+  for (int64_t n0 = 0; n0 < N; n0 += T, ++step) {
+    if (p.step_pace > 0) pace_wait(pace0, step, p.step_pace);
     // the next step's input rows first: they travel while this step is computed
     dbl2 xn[U][NFF > 0 ? NFF : 1];
 #pragma unroll
@@ -664,6 +670,11 @@ int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, 
   for (int j = 0; j < kMaxTaps; ++j) { p.kb[j] = sec.tap_b[j]; p.ka[j] = sec.tap_a[j]; }
   p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
   p.T = pl.T; p.ring = pl.ring; p.xring = pl.xring;
+  // k_comb_tm's workgroups on one step clock (alz_common.h pace_wait; grid x 16 channels x T rows x 16 B per step) while they are all
+  // resident (one per CU).  4096 channels x 2^18, D = 441 (profiles/r06_pace_others.log, r06_pace2.log): free-running 284 - 300
+  // Gsamples/s, 5600 GB/s 301 - 313, 5900 306 - 311, 6200 314 - 317, 6500 325 / 296 (the knee).
+  const int cus = device_cus() > 0 ? device_cus() : 256;
+  p.step_pace = (pl.ok && !pl.cm && !pl.string && (int)pl.grid <= cus) ? tile_pace16((long long)pl.grid * 256ll * pl.T, ALZ_TUNE("ALZ_COMB_PACE_GBPS", kCombPaceGBps)) : 0;
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const int64_t nx = (int64_t)(sec.nb - 1) * io.channels, ny = (int64_t)(sec.na - 1) * io.channels;
   double *xh_new = sec.xh + nx, *yh_new = sec.yh + ny;

@@ -43,7 +43,20 @@ __device__ __forceinline__ void stagger_start(unsigned ticks, unsigned group) {
     while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
   }
 }
+// The common tile clock (round 6, alz_wave.hip launch_wave_impl: profiles/r06_duo_tilepace*.log).  A time-major block streams whole rows
+// only while the workgroups of a launch touch the same rows together; free-running they drift apart.  The wave that requests a
+// workgroup's tiles therefore asks for tile i no earlier than i x pace after ITS OWN start (pace16: 1/16 ticks of the 100 MHz clock per
+// tile, from tile_pace16 below; 0: free-running).  A wave that is late does not wait: a slower box or a shared GPU degrades to the
+// free-running rate, not below it.
+__device__ __forceinline__ void pace_wait(long long t0, long long i, int pace16) {
+  const long long due = t0 + ((i * (long long)pace16) >> 4);
+  while ((long long)wall_clock64() < due) __builtin_amdgcn_s_sleep(1);
+}
 #endif
+// pace of a launch whose workgroups together move bytes_per_step per tile step, at gbps (GB/s; <= 0: no pacing): 1/16 ticks of 10 ns
+inline int tile_pace16(long long bytes_per_step, int gbps) {
+  return gbps > 0 ? (int)((bytes_per_step * 16ll * 100ll + gbps * 500ll) / (gbps * 1000ll)) : 0;
+}
 
 // thread-local last-error message (alz_last_error)
 void set_error(const std::string &msg);

@@ -42,6 +42,7 @@ struct MArgs {
   int ns;                      // x ring slots (a power of two: 4, or 8 with a far tap)
   const double *b, *a;
   double *xh, *yh;             // the bank's state [taps - 1][channels]
+  int tile_pace;               // the common tile clock (alz_common.h pace_wait; 0: free-running)
 };
 
 template <bool NT>
@@ -167,7 +168,9 @@ __global__ __launch_bounds__(192) void k_mid(MArgs p) {
     feed_forward(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
     for (int64_t i = 0; i < nt; ++i) {
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);
       if (i + 3 < nt) queue_tile(i + 3);
       if (i + 1 < nt) {
         int after = 0;                                                               // transfers issued after tile i + 1's
@@ -341,6 +344,8 @@ int launch_mid(const SectionDev &sec, const BlockIO &io, hipStream_t stream, int
   p.n_inputs = io.mode == ALZ_BANK_OUTER ? io.n_inputs : 0; p.n_sets = io.n_sets; p.map_input = io.map_input;
   p.far_delay = far_delay; p.ns = far ? 8 : 4; p.pb_mask = pb_mask;
   p.b = sec.b; p.a = sec.a; p.xh = sec.xh; p.yh = sec.yh;
+  // (tuning builds: the workgroups on one tile clock)
+  p.tile_pace = tile_pace16((io.channels / kMG) * (long long)kMG * kMT * 16ll, ALZ_TUNE("ALZ_MID_PACE_GBPS", 0));
   const size_t lds = (size_t)kMGuard + (size_t)p.ns * kMTile + (size_t)(kMPRing + kMYRing) * kMTile;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;

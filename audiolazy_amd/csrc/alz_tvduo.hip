@@ -49,6 +49,7 @@ struct TDArgs {
   int n_dma;                // 1 KiB coefficient transfers per tile = ceil(series taps / 2)
   const double *dma_src[3][2];
   double *xh, *yh;
+  int tile_pace;            // the common tile clock (alz_common.h pace_wait; 0: free-running)
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(192) void k_tvduo(TDArgs p) {
     prepare_tile(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
     for (int64_t i = 0; i < nt; ++i) {
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);
       if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's loads: the loads of tiles i+2 .. i+kXRing-1
@@ -413,6 +416,8 @@ int launch_tvduo(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy
     p.dma_src[d][0] = list[2 * d < ns ? 2 * d : 0];
     p.dma_src[d][1] = list[2 * d + 1 < ns ? 2 * d + 1 : (2 * d < ns ? 2 * d : 0)];
   }
+  // (tuning builds: the workgroups of a time-major launch on one tile clock)
+  p.tile_pace = cm ? 0 : tile_pace16((channels / 16) * 16384ll, ALZ_TUNE("ALZ_TVDUO_PACE_GBPS", 0));
   const size_t py_slot = cm ? (size_t)16 * (64 * 8 + 16) : (size_t)kSlot;
   const size_t lds = (size_t)kXRing * kSlot + (size_t)(kPRing + kYRing) * py_slot + (size_t)kXRing * kRawSlot +
                      (size_t)kPRing * kPairSlot;

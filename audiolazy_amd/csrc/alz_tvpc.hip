@@ -35,6 +35,8 @@ constexpr int kXRing = 4, kPRing = 3, kYRing = 2, kSRing = 3;
 constexpr int kSlot = 8192 + kChunks * 16;   // x / p / y / b-series slot: a tile + 16 bytes of pad per 1 KiB chunk
 constexpr int kASlot = 8192;                 // a-series slot: unpadded rows of 128 bytes (the recurrence wave's layout)
 
+constexpr int kTvpcPaceGBps = 5600;          // the common tile clock, 5 % under the knee (launch_tvpc)
+
 struct PCArgs {
   const double *x;
   double *y;
@@ -46,6 +48,7 @@ struct PCArgs {
   int64_t lds_[5];
   int bslot[3], aslot[2];   // ring index of a series tap among the b / a series taps
   double *xh, *yh;
+  int tile_pace;            // the common tile clock (alz_common.h pace_wait; 0: free-running)
 };
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
@@ -249,8 +252,10 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
     prepare_tile(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // start of interval 0: p of tile 0 ready, series tile 1 in
+    const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
     for (int64_t i = 0; i < nt; ++i) {
       if (i >= 1) store_tile(i - 1);
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);
       if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;
@@ -432,6 +437,14 @@ int launch_tvpc(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy,
   if (!fn) return ALZ_OK;
   p.x = x; p.y = y; p.ldx = ldx; p.ldy = ldy; p.n_tiles = n / 64; p.channels = channels;
   p.nb = nb; p.na = na; p.xh = xh; p.yh = yh;
+  // The workgroups on one tile clock (alz_common.h pace_wait): a tile step of the launch moves 16 x 64 x 8 B x (x, y and the series)
+  // per group.  4096 channels x 2^18, three series, two runs (profiles/r06_pace_others.log, r06_pace2.log): free-running 112 - 115
+  // Gsamples/s, 5200 GB/s 130, 5500 137, 5800 138 - 144 (0.72 of 8 TB/s), 6000 118 / 136 (the knee), 6200 and more 110 - 111; every
+  // block length gains (2^14 +21 %, 2^16 +25 %, 2^19 +26 %); 2048 channels +- 0.  The clock only means something while all groups
+  // are resident (one workgroup per CU: ~147 KiB of LDS): 320 and 512 groups on it lost 20 - 37 % (the second round of workgroups),
+  // so they run free.
+  const int cus = device_cus() > 0 ? device_cus() : 256;
+  p.tile_pace = channels / 16 <= cus ? tile_pace16((channels / 16) * 8192ll * (2 + nsb + nsa), ALZ_TUNE("ALZ_TVPC_PACE_GBPS", kTvpcPaceGBps)) : 0;
   const size_t lds = (size_t)(kXRing + kPRing + kYRing) * kSlot + (size_t)nsb * kSRing * kSlot + (size_t)nsa * kSRing * kASlot;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;

@@ -59,6 +59,7 @@ struct WArgs {
   int64_t chunk_x, chunk_y, chunk_c;
   int aux_pace;   // k_duo, one-pole banks that fill the chip: pauses (x 64 cycles) between the quarters of AUX's feed-forward pass
   int stagger;    // k_duo, channel-major: workgroup g starts g * stagger ticks (10 ns) late (0: all together) -- see launch_wave
+  int tile_pace;  // k_duo: the helper wave requests tile i + 3 no earlier than tile_pace / 16 ticks (10 ns) x i after its start (0: free-running)
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -392,9 +393,15 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 #endif
 // Which FMA instantiations have the storing wave.  Round 6 (profiles/r06_duo_fma_storer.log, 4096 channels x 2^20, one box,
 // interleaved): CHANNEL-major with non-temporal tiles 349 - 350 Gsamples/s (0.70) against 323 for the two-wave FMA kernel; TIME-major
-// 298 - 304 against the default kernel's 323 - 326 (and 269 with the paced pass on top) -- so the channel-major non-temporal FMA
-// instantiations get the third wave, the time-major ones keep their form and launch_wave keeps the default kernel for that shape.
-constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || (cm && nt); }
+// free-running 298 - 307 against the default kernel's 323 - 326 -- but 358 (0.72) once every workgroup's helper wave requests its
+// tiles on ONE clock (WArgs::tile_pace, profiles/r06_duo_tilepace.log): a time-major block streams whole rows only while the
+// workgroups touch the same rows together.  So the non-temporal FMA instantiations of both layouts have the third wave.
+constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || nt; }
+#ifndef ALZ_DUO_PACE_GBPS
+#define ALZ_DUO_PACE_GBPS 5750
+#endif
+static constexpr int kDuoPaceGBps = ALZ_DUO_PACE_GBPS;   // the common tile clock of the time-major FMA kernel, see launch_wave
+static constexpr int kDuoPaceGBpsShared = 5200;          // the same when some CUs hold two workgroups (257 - 320 groups)
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
@@ -415,6 +422,19 @@ static constexpr int kDuoSlot = ALZ_DUO_SLOT;   // ring slot stride (tile + pads
 // DIV = true divides the finished sum by a0 (``(...) / gain``, lazy_filters.py:236-240): the banks
 // whose a0 is not 1 -- the correctly rounded division is a ~12-instruction dependent sequence, so
 // it has its own instantiation.
+// per-wave cycle accounting (variant builds: -DALZ_DUO_TIMING; a clock read waits for the wave's outstanding LDS operations, so "work"
+// includes that): work = barrier exit -> barrier entry, wait = inside the barrier, per tile
+#ifdef ALZ_DUO_TIMING
+#define DUO_CLOCK_DECL long long dc_work = 0, dc_wait = 0, dc_last = __builtin_readcyclecounter(); long long dc_n = 0;
+#define DUO_BARRIER() do { const long long c0_ = __builtin_readcyclecounter(); __builtin_amdgcn_s_barrier(); \
+    const long long c1_ = __builtin_readcyclecounter(); dc_work += c0_ - dc_last; dc_wait += c1_ - c0_; dc_last = c1_; ++dc_n; } while (0)
+#define DUO_CLOCK_REPORT(who) do { if (blockIdx.x == 5 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && dc_n > 1000) printf("k_duo %s%s%s wave %s: %.1f cycles of work + %.1f in the barrier per tile (%lld tiles)\n", \
+    CM ? "chan" : "time", FMA ? " fma" : "", STORER ? " 3 waves" : " 2 waves", who, (double)dc_work / (double)dc_n, (double)dc_wait / (double)dc_n, dc_n); } while (0)
+#else
+#define DUO_CLOCK_DECL
+#define DUO_BARRIER() __builtin_amdgcn_s_barrier()
+#define DUO_CLOCK_REPORT(who) do {} while (0)
+#endif
 template <bool CM, unsigned PB, unsigned PA, bool FMA, bool DIV = false, bool NOSTORE = false, int PRE = 0, bool NT = false>
 __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT)) && !NOSTORE) ? 192 : 128) void k_duo(WArgs p) {
   constexpr bool STORER = ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT)) && !NOSTORE;    // a third wave stores the finished tiles
@@ -429,6 +449,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
   const int64_t in0 = (p.n_inputs && p.map_input) ? c0 % p.n_inputs : c0;   // OUTER bank: inputs of this group
   const int64_t set = p.n_inputs ? c / p.n_inputs : ((p.n_sets == 1) ? 0 : c);
   const int64_t nt = p.n_tiles;
+  DUO_CLOCK_DECL
   if constexpr (CM) stagger_start((unsigned)p.stagger, blockIdx.x);
   char *xring = smem;
   // p and y rings are written and read only by this kernel's own lanes, so their layout is free:
@@ -655,10 +676,11 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
       for (int64_t i = 0; i < nt; ++i) {
         if (!NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
+        if (!ALZ_DBG(p, 8)) DUO_BARRIER();
       }
       if (!NOSTORE) store_tile(nt - 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DUO_CLOCK_REPORT("STORE");
       return;
     }
     for (int t = 0; t < kXRing - 1 && t < nt && !ALZ_DBG(p, 1); ++t) queue_tile(t);
@@ -666,8 +688,10 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
     feed_forward(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
     for (int64_t i = 0; i < nt; ++i) {
       if (!STORER && !NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);   // all workgroups keep to one clock (alz_common.h)
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
@@ -680,8 +704,9 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
         if (!ALZ_DBG(p, 2)) feed_forward(i + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();
+      if (!ALZ_DBG(p, 8)) DUO_BARRIER();
     }
+    DUO_CLOCK_REPORT("AUX");
     if (!STORER && !NOSTORE) store_tile(nt - 1);
     // input history for the next block: the last two x samples (held by the q == 3 lanes)
     if (!NOSTORE && q == 3) {
@@ -785,8 +810,9 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!ALZ_DBG(p, 8)) __builtin_amdgcn_s_barrier();        // y of tile i done, p of tile i+1 ready
+      if (!ALZ_DBG(p, 8)) DUO_BARRIER();                       // y of tile i done, p of tile i+1 ready
     }
+    DUO_CLOCK_REPORT("REC");
     if (lane < G) {
       if (p.na > 1) p.yh[0 * p.channels + sc] = m1;
       if (p.na > 2) p.yh[1 * p.channels + sc] = m2;
@@ -885,11 +911,15 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   if (groups == 0 || tiles == 0) return ALZ_OK;
   if (ch && tiles * t != ch->chunk_len) return ALZ_OK;
   // The opt-in FMA mode ALLOWS contraction; it does not have to be used where it loses.  A time-major bank that fills the
-  // chip with one two-wave workgroup per CU (256 - 320 groups of 16 channels) is bound by the helper wave's pass over the
-  // tile, not by the recurrence, and the default kernel has the storing wave, the non-temporal tiles and the paced pass
-  // for it: 306 - 326 Gsamples/s against the FMA kernel's 295 - 304 (profiles/NOTES_r04.md 5, NOTES_r05.md 10).  Everywhere
-  // else the FMA kernels are 2 - 12 % ahead.  The default kernel's doubles are within every contract of the mode.
-  const bool fused = io.fused && (ALZ_DUO_FMA3 || !(g == 16 && !cm && !ch && groups >= 256 && groups <= 320));   // (variant builds with the storing wave in the FMA kernels: no exception)
+  // chip with one workgroup per CU (256 - 320 groups of 16 channels) is bound by the helper wave's pass over the tile, not
+  // by the recurrence: the default kernel (storing wave, non-temporal tiles, paced pass) does 306 - 326 Gsamples/s there
+  // against the two-wave FMA kernel's 295 - 304 (profiles/NOTES_r04.md 5, NOTES_r05.md 10).  A block of streaming size has
+  // the three-wave FMA kernel on a common tile clock instead (tile_pace below: 358); smaller or in-place blocks of that
+  // width keep the default kernel, whose doubles are within every contract of the mode.  Everywhere else the FMA kernels
+  // are 2 - 12 % ahead.
+  const bool chip_wide_tm = g == 16 && !cm && !ch && groups >= 256 && groups <= 320;
+  const bool paced_tm = chip_wide_tm && io.fused && io.stream_once && !io.pre_op && !sec.any_div && ALZ_TUNE("ALZ_DUO_NT", 1) != 0 && ALZ_TUNE("ALZ_DUO_PACED_FMA", 1) != 0;
+  const bool fused = io.fused && (ALZ_DUO_FMA3 || !chip_wide_tm || paced_tm);   // (variant builds with the storing wave in every FMA kernel: no exception)
   // small banks: the two-wave kernel (recurrence wave + helper wave per 16 channels)
   static const int duo_env = ALZ_TUNE("ALZ_DUO", 1);
   const bool nostore = ch && ch->nostore;
@@ -900,7 +930,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
   const bool prefer_single = g == 16 && lanes >= single_from && !ch;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
-  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
+  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm || paced_tm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {
@@ -919,10 +949,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   } else if (g == 16 && ((duo_env && !prefer_single) || ch)) {
     if (fused && nt_tiles && cm)
       duo_fma = true, duo = pick_duo_pattern<true, true, false, false, 0, true>(sec.present_b, sec.present_a);
-#if ALZ_DUO_FMA3
-    else if (fused && nt_tiles)
+    else if (fused && nt_tiles)   // (shipped build: only the chip-wide streaming blocks, paced_tm above)
       duo_fma = true, duo = pick_duo_pattern<false, true, false, false, 0, true>(sec.present_b, sec.present_a);
-#endif
     else if (fused)
       duo_fma = true, duo = cm ? pick_duo_pattern<true, true>(sec.present_b, sec.present_a)
                                : pick_duo_pattern<false, true>(sec.present_b, sec.present_a);
@@ -967,6 +995,24 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // (-DALZ_TUNING builds: a staggered start of the workgroups of a channel-major launch, stagger_start in alz_common.h -- measured on
   // identical buffers, round 6: no effect; what decides between 12.3 and 16 ms there is where the blocks lie physically)
   p.stagger = (duo && cm && !ch) ? ALZ_TUNE("ALZ_DUO_STAGGER", 0) : 0;
+  // Time-major FMA kernel with the storing wave on a chip-wide streaming block: every workgroup's helper wave requests tile i + 3
+  // no earlier than i x pace after its own start, pace = the time in which the whole launch's tile row (groups x 16 KiB in + out)
+  // passes at kDuoPaceGBps.  Free-running, the workgroups drift apart and the rows they touch spread over DRAM pages: 307
+  // Gsamples/s; on the clock 358 (4096 channels x 2^20, profiles/r06_duo_tilepace.log: 70 ticks of 10 ns per tile is faster than
+  // the memory system follows -- nobody waits, 320 - 323 --, 73 holds, each tick more costs 0.9 %).  A workgroup that is late
+  // does not wait, so a slower box or a shared GPU degrades to the free-running rate, not below it.
+  // Second box, same source (profiles/r06_duo_tilepace_shipped_form.log): 5500 GB/s 343, 5750 357 - 358, 5850 363, 5900 360 / 328 (the
+  // knee), 6000 324; 2^18 samples 351 against 285 free-running; 2^14 samples (256 tiles) 308 - 315 against 318 - 329, 2^16 292 - 295
+  // against 298 - 301, 2^17 338 - 339 against 329 - 335 (the start-up ramp): blocks under 2048 tiles run free.  320 groups (two workgroups on 64 of the CUs) follow a slower clock: 5120 channels
+  // 232 free-running, 243 - 249 at 5000 - 5300, 243 at 5750.  Overshooting costs 10 %, a per-cent of margin 0.9 %: kDuoPaceGBps
+  // stays 2.5 % under the knee.
+  p.tile_pace = 0;
+  if (duo && duo_fma && nt_tiles && !cm && tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", 2048) &&
+      groups <= 2 * (device_cus() > 0 ? device_cus() : 256)) {                  // (all groups resident: two workgroups' LDS per CU)
+    const int gbps = ALZ_TUNE("ALZ_DUO_PACE_GBPS", groups <= 256 ? kDuoPaceGBps : kDuoPaceGBpsShared);
+    p.tile_pace = tile_pace16(groups * 16384ll, gbps);
+  }
+  if (duo && !ch && ALZ_TUNE("ALZ_DUO_TILEPACE", -1) >= 0) p.tile_pace = ALZ_TUNE("ALZ_DUO_TILEPACE", -1);
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)

@@ -1024,7 +1024,7 @@ def short_parity(p):
 # The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
 # the tail of the line still holds configs[2..4].
 SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
-                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
+                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "biquad_fma", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
                    "timevar_shared", "timevar_per_channel",
                    "gammatone_one_stream", "gammatone_one_stream_time_parallel", "gammatone_one_stream_time_parallel_tm", "lpc_1m", "lpc_1m_bit_identical",
                    "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
@@ -1243,6 +1243,15 @@ def main():
             args.fused = False
           secondary["biquad_chan_fma"] = entry(r, 1, 5, "Gsamples/s", "the same in the opt-in FMA mode (alz_bank_set_fused): k_duo's fused "
                                                "instantiation with the storing wave and non-temporal tiles", key="biquad_chan_fma")
+          # configs[1] itself (time-major) in the opt-in FMA mode: the three-wave fused kernel on a common tile clock
+          args.fused = True
+          try:
+            r = wl_biquad(ctx, args, alz, 4096, N, 0, 4096, 5, 1, check=True, layout="time")
+          finally:
+            args.fused = False
+          secondary["biquad_fma"] = entry(r, 1, 5, "Gsamples/s", "configs[1] (time-major) in the opt-in FMA mode (alz_bank_set_fused): k_duo's fused "
+                                          "instantiation with the storing wave and non-temporal tiles, the workgroups' tile requests "
+                                          "on one clock (alz_wave.hip, tile_pace)", key="biquad_fma")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel"), (8192, "narrow512_time_parallel_three_launch"),
                             (1, "narrow512_time_parallel_chan")):

@@ -69,7 +69,7 @@ def test_cfg2_biquad_bank_4096_channels_vs_oracle(alz, oracle, bench, layout):
 
 def test_cfg2_fused_mode_within_contract(alz, oracle, bench):
   import torch
-  C, N = 4096, 8192
+  C, N = 4096, 4096
   b, a = bench.resonator_coefs(C)
   x = np.random.default_rng(3).uniform(-1, 1, (N, C))
   bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
@@ -77,8 +77,9 @@ def test_cfg2_fused_mode_within_contract(alz, oracle, bench):
   y = bank.process(torch.from_numpy(x).cuda()).cpu().numpy()
   ref = oracle.bank([3], [3], b, a, x)
   assert norm_err(y, ref, 0) <= 1e-10
-  # the mode ALLOWS the contraction: a time-major bank of one two-wave workgroup per CU is bound by its helper wave and
-  # keeps the default kernel (faster there: launch_wave), the channel-major one takes the FMA kernel
+  # the mode ALLOWS the contraction: a time-major bank of one two-wave workgroup per CU is bound by its helper wave and,
+  # below the streaming block size (256 MiB: test_fused_time_major_streaming_block_common_tile_clock), keeps the default
+  # kernel (faster there: launch_wave); the channel-major one takes the FMA kernel
   assert bank.last_kernel == "k_duo<16>" and same_bits(y, ref), bank.last_kernel
   bank.reset()
   yc = bank.process(torch.from_numpy(np.ascontiguousarray(x.T)).cuda(), layout="chan").cpu().numpy()
@@ -285,6 +286,41 @@ def test_fused_channel_major_streaming_block_storing_wave(alz, oracle, bench, C,
   ys = short.process(x[:, :n0].contiguous(), layout="chan")
   assert "fma" in short.last_kernel
   assert torch.equal(ys, y[:, :n0])
+
+
+@pytest.mark.parametrize("C,N", [(4096, 1 << 14), (5120, 8200), (4144, 70000)])
+def test_fused_time_major_streaming_block_common_tile_clock(alz, oracle, bench, C, N):
+  """The opt-in FMA mode on TIME-major blocks of 256 MiB and more of a bank that fills the chip (256 - 320 groups of 16 channels,
+  round 6): k_duo's fused instantiation with the storing wave and non-temporal tiles, every workgroup's tile requests on one
+  clock (358 against the default kernel's 325 Gsamples/s at 4096 channels x 2^20).  The pacing must not touch the values:
+  strided channels over the whole block within the mode's tolerance, a second block continuing the stream, bitwise the
+  doubles the channel-major fused kernel gives for the same signal; blocks below the streaming size keep the default kernel."""
+  import torch
+  b, a = bench.resonator_coefs(C)
+  x = _gpu_noise((N, C), 23)
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  bank.reset()
+  y = bank.process(x, layout="time")
+  assert bank.last_kernel.startswith("k_duo<16,fma>"), bank.last_kernel     # (+ the kernel of a ragged tail)
+  y2 = bank.process(x, layout="time")                        # the same input again, from the carried state
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 24).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  got = torch.cat([y.index_select(1, idx), y2.index_select(1, idx)], dim=0).cpu().numpy()
+  xs = x.index_select(1, idx).cpu().numpy()
+  ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate([xs, xs], axis=0), layout="time")
+  assert norm_err(got, ref, 0) <= 1e-10 and not same_bits(got, ref)
+  del y2
+  chan = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  chan.reset()
+  yc = chan.process(x.t().contiguous(), layout="chan")
+  assert "fma" in chan.last_kernel
+  whole = N // 64 * 64                                       # (the ragged tail is another kernel's, with its own contraction)
+  assert torch.equal(yc[:, :whole].t(), y[:whole])
+  del yc
+  short = alz.FilterBank([(b, a)], n_inputs=C).set_fused(True)
+  short.reset()
+  short.process(x[:2048].contiguous(), layout="time")
+  assert short.last_kernel == "k_duo<16>", short.last_kernel
 
 
 @pytest.mark.parametrize("mode", [True, "one-pass"])

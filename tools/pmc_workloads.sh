@@ -48,3 +48,4 @@ run iir_order6 --workload butter6
 run maverage_recursive_256 --workload maverage256
 run biquad_chan --layout chan
 run biquad_chan_fma --layout chan --fused
+run biquad_fma --fused
