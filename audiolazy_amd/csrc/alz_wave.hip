@@ -223,8 +223,10 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
       dma16<ALZ_WAVE_NT != 0>(xg + t * x_tile + j * x_chunk, lds0 + t * kSlotBytes + j * 1040);
   }
 
+  const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
   for (int64_t i = 0; i < nt; ++i) {
     const int slot = (int)(i % kRing);
+    if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);   // (tuning builds: the common tile clock, alz_common.h)
     // refill the slot freed by tile i-1 with tile i+kRing-1
     const int64_t tn = i + kRing - 1;
     if (tn < nt && !ALZ_DBG(p, 1)) {
@@ -401,7 +403,9 @@ constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || nt; }
 #define ALZ_DUO_PACE_GBPS 5750
 #endif
 static constexpr int kDuoPaceGBps = ALZ_DUO_PACE_GBPS;   // the common tile clock of the time-major FMA kernel, see launch_wave
-static constexpr int kDuoPaceGBpsShared = 5200;          // the same when some CUs hold two workgroups (257 - 320 groups)
+static constexpr int kDuoPaceGBpsOnePole = 5900;         // ... of the one-pole banks' bit-exact kernel (followed up to 6100 and more)
+static constexpr int kDuoPaceGBpsShared = 5000;          // 257 - 416 groups: some CUs hold two workgroups
+static constexpr int kDuoPaceGBpsTwo = 5600;             // 417 - 512 groups: (nearly) all do
 #ifndef ALZ_DUO_SLOT
 #define ALZ_DUO_SLOT (8192 + kChunks * 16)
 #endif
@@ -986,33 +990,48 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   }
   static const int dbg_env = ALZ_DBG_ENV();
   p.dbg = dbg_env;
-  // One-pole banks that fill the chip once, long blocks: AUX's feed-forward pass in quarters with 2 x 64-cycle pauses.
-  // Measured on three boxes (profiles/r04_duo_patterns.log): 4096 channels x 2^20 time-major +2 / +13 / +10 ... 16 %,
-  // channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three pauses are better on one box and worse on the
-  // others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a chip of workgroups a quarter: excluded.
-  p.aux_pace = (duo && !ch && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
+  // The common tile clock (alz_common.h pace_wait), time-major streaming blocks of a launch that fills the chip with one or two
+  // resident workgroups per CU: the helper wave requests tile i + 3 no earlier than i x pace after its own start, pace = the
+  // time in which the whole launch's tile row (groups x 16 KiB in + out) passes at the rate below.  Free-running, the workgroups
+  // drift apart and the rows they touch spread over DRAM pages; a workgroup that is late does not wait, so a slower box or a
+  // shared GPU degrades to the free-running rate, not below it.  Measured (GB/s of the clock -> Gsamples/s):
+  //  * 256 groups, FMA kernel with the storing wave, 2^20 samples (profiles/r06_duo_tilepace*.log, two boxes): free 303 - 308,
+  //    5500 343, 5750 357 - 358, 5850 363, 5900 360 / 328 (the knee), 6000 324; 2^18 samples 351 against 285; 2^14 (256 tiles)
+  //    308 - 315 against 318 - 329, 2^16 292 - 295 against 298 - 301, 2^17 338 - 339 against 329 - 335 (the start-up ramp): blocks
+  //    under 2048 tiles run free.  Overshooting costs 10 %, a per-cent of margin 0.9 %: 2.5 % under the knee.
+  //  * 256 groups, one-pole banks bit-exact (envelope: |x| -> lowpass; profiles/r06_pace3.log, r06_pace4.log): the paced pass of
+  //    round 4 (aux_pace) 305 - 315; the clock INSTEAD of it 5500 343, 5700 356, 5900 366 - 368, 6100 378 - 379; 2^16 samples 328 -
+  //    335 against 293 - 296, 2^17 345 against 308, 2^18 353 against 309.
+  //  * 256 groups, two-pole banks bit-exact: 327 with or without (the recurrence wave's issue rate bounds them): no clock.
+  //  * 257 - 512 groups (some or all CUs hold two workgroups), 2^19 samples, bit-exact (r06_pace4.log): 4608 channels 215 - 232 ->
+  //    224 - 236; 5120 211 - 229 -> 244 - 249 at 4800, 237 - 243 at 5200; 5632 224 - 245 -> 266 - 274 (4800 - 5200), 256 - 263 (5600);
+  //    6144 240 - 255 -> 289 - 294 (4800 - 5200); 7168 252 - 269 -> 300 (4800), 310 - 318 (5200), 312 - 320 (5600); 7680 270 - 272 ->
+  //    300, 324, 327 - 334.  FMA mode the same: 5120 206 - 219 -> 247 - 251, 7168 270 - 272 -> 309 - 315.  One-pole, 5120: 217 -> 249 - 254.
+  p.tile_pace = 0;
+  {
+    const int cus = device_cus() > 0 ? device_cus() : 256;
+    const bool one_pole = sec.present_b == 1u && sec.present_a == 1u;
+    if (duo && !cm && !ch && io.stream_once && !sec.any_div && groups >= cus && groups <= 2 * cus && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0) {
+      int gbps = 0, min_tiles = 2048;
+      if (groups > cus) gbps = groups <= cus + 5 * cus / 8 ? kDuoPaceGBpsShared : kDuoPaceGBpsTwo;
+      else if (duo_fma) gbps = nt_tiles ? kDuoPaceGBps : 0;
+      else if (one_pole) gbps = kDuoPaceGBpsOnePole, min_tiles = 1024;
+      gbps = ALZ_TUNE("ALZ_DUO_PACE_GBPS", gbps);
+      if (tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", min_tiles)) p.tile_pace = tile_pace16(groups * 16384ll, gbps);
+    }
+  }
+  // One-pole banks that fill the chip once, long blocks NOT on the clock (in place, or under the streaming size): AUX's
+  // feed-forward pass in quarters with 2 x 64-cycle pauses.  Measured on three boxes (profiles/r04_duo_patterns.log): 4096
+  // channels x 2^20 time-major +2 / +13 / +10 ... 16 %, channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three
+  // pauses are better on one box and worse on the others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a
+  // chip of workgroups a quarter: excluded.
+  p.aux_pace = (duo && !ch && p.tile_pace == 0 && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // (-DALZ_TUNING builds: a staggered start of the workgroups of a channel-major launch, stagger_start in alz_common.h -- measured on
   // identical buffers, round 6: no effect; what decides between 12.3 and 16 ms there is where the blocks lie physically)
   p.stagger = (duo && cm && !ch) ? ALZ_TUNE("ALZ_DUO_STAGGER", 0) : 0;
-  // Time-major FMA kernel with the storing wave on a chip-wide streaming block: every workgroup's helper wave requests tile i + 3
-  // no earlier than i x pace after its own start, pace = the time in which the whole launch's tile row (groups x 16 KiB in + out)
-  // passes at kDuoPaceGBps.  Free-running, the workgroups drift apart and the rows they touch spread over DRAM pages: 307
-  // Gsamples/s; on the clock 358 (4096 channels x 2^20, profiles/r06_duo_tilepace.log: 70 ticks of 10 ns per tile is faster than
-  // the memory system follows -- nobody waits, 320 - 323 --, 73 holds, each tick more costs 0.9 %).  A workgroup that is late
-  // does not wait, so a slower box or a shared GPU degrades to the free-running rate, not below it.
-  // Second box, same source (profiles/r06_duo_tilepace_shipped_form.log): 5500 GB/s 343, 5750 357 - 358, 5850 363, 5900 360 / 328 (the
-  // knee), 6000 324; 2^18 samples 351 against 285 free-running; 2^14 samples (256 tiles) 308 - 315 against 318 - 329, 2^16 292 - 295
-  // against 298 - 301, 2^17 338 - 339 against 329 - 335 (the start-up ramp): blocks under 2048 tiles run free.  320 groups (two workgroups on 64 of the CUs) follow a slower clock: 5120 channels
-  // 232 free-running, 243 - 249 at 5000 - 5300, 243 at 5750.  Overshooting costs 10 %, a per-cent of margin 0.9 %: kDuoPaceGBps
-  // stays 2.5 % under the knee.
-  p.tile_pace = 0;
-  if (duo && duo_fma && nt_tiles && !cm && tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", 2048) &&
-      groups <= 2 * (device_cus() > 0 ? device_cus() : 256)) {                  // (all groups resident: two workgroups' LDS per CU)
-    const int gbps = ALZ_TUNE("ALZ_DUO_PACE_GBPS", groups <= 256 ? kDuoPaceGBps : kDuoPaceGBpsShared);
-    p.tile_pace = tile_pace16(groups * 16384ll, gbps);
-  }
   if (duo && !ch && ALZ_TUNE("ALZ_DUO_TILEPACE", -1) >= 0) p.tile_pace = ALZ_TUNE("ALZ_DUO_TILEPACE", -1);
+  if (!ch && !cm && ALZ_TUNE("ALZ_WAVE_PACE_GBPS", 0) > 0) p.tile_pace = tile_pace16(groups * 16384ll, ALZ_TUNE("ALZ_WAVE_PACE_GBPS", 0));   // (any kernel of this file)
   // one wave per workgroup; when the whole launch fits one wave per CU, ask for enough LDS
   // that no two workgroups share a CU (each wave then owns a SIMD and a CU's memory path)
   size_t lds = duo ? (size_t)kXRing * kDuoSlot + (size_t)(kPRing + kYRing) * (cm ? 16 * (64 * 8 + 16) : kDuoSlot)
