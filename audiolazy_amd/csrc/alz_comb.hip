@@ -175,9 +175,11 @@ __global__ __launch_bounds__(512) void k_comb_tm(SArgs p) {
   if constexpr (NFB > 0) __syncthreads();
   int q0 = 0;                                                           // n0 mod R
   const long long pace0 = p.step_pace > 0 ? (long long)wall_clock64() : 0;
+
+  long long pace_shift = 0;
   long long step = 0;
   for (int64_t n0 = 0; n0 < N; n0 += T, ++step) {
-    if (p.step_pace > 0) pace_wait(pace0, step, p.step_pace);
+    if (p.step_pace > 0) pace_wait(pace0, step, p.step_pace, pace_shift);
     // the next step's input rows first: they travel while this step is computed
     dbl2 xn[U][NFF > 0 ? NFF : 1];
 #pragma unroll

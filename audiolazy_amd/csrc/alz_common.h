@@ -48,14 +48,28 @@ __device__ __forceinline__ void stagger_start(unsigned ticks, unsigned group) {
 // workgroup's tiles therefore asks for tile i no earlier than i x pace after ITS OWN start (pace16: 1/16 ticks of the 100 MHz clock per
 // tile, from tile_pace16 below; 0: free-running).  A wave that is late does not wait: a slower box or a shared GPU degrades to the
 // free-running rate, not below it.
-__device__ __forceinline__ void pace_wait(long long t0, long long i, int pace16) {
-  const long long due = t0 + ((i * (long long)pace16) >> 4);
-  while ((long long)wall_clock64() < due) __builtin_amdgcn_s_sleep(1);
+// (`pace`: bits 0 - 19 the pace in 1/16 ticks, bits 20 - 30 FORGIVE in ticks, tuning builds only.  FORGIVE > 0: a wave more than that
+// behind its schedule does not run free until it has caught up -- its schedule restarts from now (`shift`), so it still requests no
+// more than a tile per pace.  Measured (profiles/r06_pace7_forgiving_clock.log, 8 / 40 / 150 ticks against the fixed clock, three
+// kernels, rates below and above the knee): no difference anywhere -- what the clock buys is the workgroups being on the SAME rows,
+// not a limit on the request rate.  A clock that shifts all workgroups by the largest lateness any of them reports (one word per
+// launch, scalar atomic max: r06_pace6_feedback_ratchet.log) was worse than no clock: the maximum over 256 workgroups of every
+// transient only ever grows.  So: a fixed clock, with margin.)
+__device__ __forceinline__ void pace_wait(long long t0, long long i, int pace, long long &shift) {
+  const int pace16 = pace & 0xFFFFF, forgive = pace >> 20;
+  const long long due = t0 + ((i * (long long)pace16) >> 4) + shift;
+  const long long now = (long long)wall_clock64();
+  if (now < due) {
+    do __builtin_amdgcn_s_sleep(1); while ((long long)wall_clock64() < due);
+  } else if (forgive > 0 && now - due > forgive) {
+    shift += now - due;
+  }
 }
 #endif
 // pace of a launch whose workgroups together move bytes_per_step per tile step, at gbps (GB/s; <= 0: no pacing): 1/16 ticks of 10 ns
 inline int tile_pace16(long long bytes_per_step, int gbps) {
-  return gbps > 0 ? (int)((bytes_per_step * 16ll * 100ll + gbps * 500ll) / (gbps * 1000ll)) : 0;
+  const int pace16 = gbps > 0 ? (int)((bytes_per_step * 16ll * 100ll + gbps * 500ll) / (gbps * 1000ll)) : 0;
+  return pace16 > 0 && pace16 < (1 << 20) ? (pace16 | (ALZ_TUNE("ALZ_PACE_FORGIVE", 0) << 20)) : 0;
 }
 
 // thread-local last-error message (alz_last_error)

@@ -266,8 +266,10 @@ __global__ __launch_bounds__(192) void k_tvduo(TDArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
+
+    long long pace_shift = 0;
     for (int64_t i = 0; i < nt; ++i) {
-      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);
       if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's loads: the loads of tiles i+2 .. i+kXRing-1

@@ -253,9 +253,11 @@ __global__ __launch_bounds__(192) void k_tvpc(PCArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                            // start of interval 0: p of tile 0 ready, series tile 1 in
     const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
+
+    long long pace_shift = 0;
     for (int64_t i = 0; i < nt; ++i) {
       if (i >= 1) store_tile(i - 1);
-      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);
       if (i + kXRing - 1 < nt) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         const int64_t last = (i + kXRing - 1 < nt - 1) ? i + kXRing - 1 : nt - 1;

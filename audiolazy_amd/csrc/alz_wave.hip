@@ -224,9 +224,11 @@ __global__ __launch_bounds__(64) void k_wave(WArgs p) {
   }
 
   const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
+
+  long long pace_shift = 0;
   for (int64_t i = 0; i < nt; ++i) {
     const int slot = (int)(i % kRing);
-    if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);   // (tuning builds: the common tile clock, alz_common.h)
+    if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);   // (tuning builds: the common tile clock, alz_common.h)
     // refill the slot freed by tile i-1 with tile i+kRing-1
     const int64_t tn = i + kRing - 1;
     if (tn < nt && !ALZ_DBG(p, 1)) {
@@ -400,10 +402,10 @@ static constexpr int kXRing = ALZ_DUO_XRING, kPRing = 3, kYRing = 2;
 // workgroups touch the same rows together.  So the non-temporal FMA instantiations of both layouts have the third wave.
 constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || nt; }
 #ifndef ALZ_DUO_PACE_GBPS
-#define ALZ_DUO_PACE_GBPS 5750
+#define ALZ_DUO_PACE_GBPS 5600
 #endif
 static constexpr int kDuoPaceGBps = ALZ_DUO_PACE_GBPS;   // the common tile clock of the time-major FMA kernel, see launch_wave
-static constexpr int kDuoPaceGBpsOnePole = 5900;         // ... of the one-pole banks' bit-exact kernel (followed up to 6100 and more)
+static constexpr int kDuoPaceGBpsOnePole = 5750;         // ... of the one-pole banks' bit-exact kernel (followed up to 6100 on four boxes, not on a fifth)
 static constexpr int kDuoPaceGBpsShared = 5000;          // 257 - 416 groups: some CUs hold two workgroups
 static constexpr int kDuoPaceGBpsTwo = 5600;             // 417 - 512 groups: (nearly) all do
 #ifndef ALZ_DUO_SLOT
@@ -693,9 +695,11 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
+
+    long long pace_shift = 0;
     for (int64_t i = 0; i < nt; ++i) {
       if (!STORER && !NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
-      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace);   // all workgroups keep to one clock (alz_common.h)
+      if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);   // all workgroups keep to one clock (alz_common.h)
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
@@ -932,7 +936,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // the single-wave kernel overtakes the two-wave one once a CU holds more than two workgroups' worth
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
-  const bool prefer_single = g == 16 && lanes >= single_from && !ch;
+  // ... unless the block is of streaming size and exactly two workgroups per CU make up the launch (8192 channels: 512 groups): on
+  // the common tile clock (tile_pace below) the two-wave kernel does 348 - 368 Gsamples/s against k_wave<16>'s 300 - 305
+  // (profiles/r06_pace5.log; free-running it is the slower one, 282 - 289)
+  const bool duo_clocked_wide = g == 16 && !cm && !ch && io.stream_once && !sec.any_div && !io.pre_op &&
+                                lanes <= 32ll * (device_cus() > 0 ? device_cus() : 256) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
+  const bool prefer_single = g == 16 && lanes >= single_from && !ch && !(lanes == single_from && duo_clocked_wide);
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
   const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm || paced_tm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
@@ -998,7 +1007,9 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   //  * 256 groups, FMA kernel with the storing wave, 2^20 samples (profiles/r06_duo_tilepace*.log, two boxes): free 303 - 308,
   //    5500 343, 5750 357 - 358, 5850 363, 5900 360 / 328 (the knee), 6000 324; 2^18 samples 351 against 285; 2^14 (256 tiles)
   //    308 - 315 against 318 - 329, 2^16 292 - 295 against 298 - 301, 2^17 338 - 339 against 329 - 335 (the start-up ramp): blocks
-  //    under 2048 tiles run free.  Overshooting costs 10 %, a per-cent of margin 0.9 %: 2.5 % under the knee.
+  //    under 2048 tiles run free.  Four more boxes (r06_pace_check.log, r06_pace6_feedback_ratchet.log, r06_pace7_forgiving_clock.log):
+  //    5750 356 - 359 on two of them, 292 / 348 on one, 303 once in three first runs on another; 6000 never followed.  Overshooting
+  //    costs 10 - 18 %, a per-cent of margin 0.9 %: the shipped rate is 5600 (349), 4 - 5 % under the usual knee.
   //  * 256 groups, one-pole banks bit-exact (envelope: |x| -> lowpass; profiles/r06_pace3.log, r06_pace4.log): the paced pass of
   //    round 4 (aux_pace) 305 - 315; the clock INSTEAD of it 5500 343, 5700 356, 5900 366 - 368, 6100 378 - 379; 2^16 samples 328 -
   //    335 against 293 - 296, 2^17 345 against 308, 2^18 353 against 309.

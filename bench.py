@@ -1024,7 +1024,7 @@ def short_parity(p):
 # The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
 # the tail of the line still holds configs[2..4].
 SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
-                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "biquad_fma", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
+                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "biquad_fma", "biquad_8192", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
                    "timevar_shared", "timevar_per_channel",
                    "gammatone_one_stream", "gammatone_one_stream_time_parallel", "gammatone_one_stream_time_parallel_tm", "lpc_1m", "lpc_1m_bit_identical",
                    "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
@@ -1252,6 +1252,12 @@ def main():
           secondary["biquad_fma"] = entry(r, 1, 5, "Gsamples/s", "configs[1] (time-major) in the opt-in FMA mode (alz_bank_set_fused): k_duo's fused "
                                           "instantiation with the storing wave and non-temporal tiles, the workgroups' tile requests "
                                           "on one clock (alz_wave.hip, tile_pace)", key="biquad_fma")
+        # twice configs[1]'s channels on one GPU (the same bytes per launch: 8192 channels x 2^19 samples): two workgroups per CU, so the
+        # recurrence waves' issue rate no longer bounds the bit-exact kernel -- the memory system does, on the common tile clock
+        if not args.fused:
+          r = wl_biquad(ctx, args, alz, 8192, 1 << 19, 0, 8192, 5, 1, check=True, layout="time")
+          secondary["biquad_8192"] = entry(r, 1, 5, "Gsamples/s", "configs[1]'s bank at twice the width: 8192 channels x 2^19 samples, bit-exact "
+                                           "(k_duo, two workgroups per CU on the common tile clock)", key="biquad_8192")
         if hasattr(alz.FilterBank, "set_time_parallel"):
           for mode, key in ((0, "narrow512_bit_exact"), (1, "narrow512_time_parallel"), (8192, "narrow512_time_parallel_three_launch"),
                             (1, "narrow512_time_parallel_chan")):

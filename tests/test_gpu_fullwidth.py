@@ -323,6 +323,40 @@ def test_fused_time_major_streaming_block_common_tile_clock(alz, oracle, bench, 
   assert short.last_kernel == "k_duo<16>", short.last_kernel
 
 
+@pytest.mark.parametrize("C,N,kind", [(4096, 1 << 17, "one-pole"), (4096, 70000, "one-pole-abs"), (5120, 1 << 17, "one-pole"),
+                                      (6144, 1 << 17, "biquad"), (7680, 131072 + 40, "biquad"), (8192, 1 << 17, "biquad")])
+def test_time_major_streaming_blocks_on_the_tile_clock_bit_exact(alz, oracle, bench, C, N, kind):
+  """Bit-exact banks whose time-major streaming blocks run on the common tile clock (round 6, alz_wave.hip launch_wave_impl): one-pole
+  banks that fill the chip (308 -> 358 Gsamples/s; with and without |x| fused into the loads) and two-pole banks of 257 - 512
+  groups (+2 ... +23 %; 8192 channels: the two-wave kernel instead of k_wave<16>).  The clock only decides WHEN a tile is requested:
+  strided channels over the whole block and a second block continuing the stream, bit for bit against the oracle."""
+  import torch
+  if kind == "biquad":
+    b, a = bench.resonator_coefs(C)
+    nb, na = 3, 3
+  else:
+    cut = np.geomspace(2 * np.pi * 5 / 48000., 2 * np.pi * 200 / 48000., C)
+    filts = [alz.lowpass(float(c)) for c in cut]
+    b, a = np.array([f.numlist for f in filts]), np.array([f.denlist for f in filts])
+    nb, na = 1, 2
+  x = _gpu_noise((N, C), 29)
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  if kind == "one-pole-abs":
+    bank.set_input_map("abs")
+  bank.reset()
+  y = bank.process(x, layout="time")
+  assert bank.last_kernel.startswith("k_duo<16>"), bank.last_kernel
+  y2 = bank.process(x, layout="time")                        # the same input again, from the carried state
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 24).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  got = torch.cat([y.index_select(1, idx), y2.index_select(1, idx)], dim=0).cpu().numpy()
+  xs = x.index_select(1, idx).cpu().numpy()
+  if kind == "one-pole-abs":
+    xs = np.abs(xs)
+  ref = oracle.bank([nb], [na], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate([xs, xs], axis=0), layout="time")
+  assert same_bits(got, ref)
+
+
 @pytest.mark.parametrize("mode", [True, "one-pass"])
 def test_narrow_bank_time_parallel_full_block_length(alz, oracle, bench, mode):
   """The time-parallel modes over a whole 2^20-sample block of the 512-channel shard (2048 chunk boundaries in the

@@ -15,7 +15,7 @@ ALG = {  # algorithmic bytes per step, as bench.py defines them
   "narrow512_time_parallel_three_launch": 16.0 * 512 * 2 ** 20,
   "comb_fb": 16.0 * 4096 * 2 ** 18, "comb_fb_chan": 16.0 * 4096 * 2 ** 18, "karplus_one_string": 16.0 * 2 ** 22,
   "iir_order6": 16.0 * 4096 * 2 ** 18, "maverage_recursive_256": 16.0 * 4096 * 2 ** 18,
-  "biquad_chan": 16.0 * 4096 * 2 ** 20, "biquad_chan_fma": 16.0 * 4096 * 2 ** 20, "biquad_fma": 16.0 * 4096 * 2 ** 20}
+  "biquad_chan": 16.0 * 4096 * 2 ** 20, "biquad_chan_fma": 16.0 * 4096 * 2 ** 20, "biquad_fma": 16.0 * 4096 * 2 ** 20, "biquad_8192": 16.0 * 8192 * 2 ** 19}
 # FETCH_SIZE x 2 per the guide's gfx950 note -- for every kernel: round 5 read a known byte count in k_fir_ring's shape
 # (8 B / lane buffer loads, 512-byte row pieces 64 KiB apart: tools/ubench_fetch8.hip, profiles/r05_fetch8_calibration.log)
 # and the counter reported half of it, as it does for 16 B / lane streams (TCC_EA0_RDREQ x 64 B, the requests are 128 B).

@@ -49,3 +49,4 @@ run maverage_recursive_256 --workload maverage256
 run biquad_chan --layout chan
 run biquad_chan_fma --layout chan --fused
 run biquad_fma --fused
+run biquad_8192 --channels 8192 --log2-samples 19
