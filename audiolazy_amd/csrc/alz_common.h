@@ -65,7 +65,41 @@ __device__ __forceinline__ void pace_wait(long long t0, long long i, int pace, l
     shift += now - due;
   }
 }
+// (experiment, tuning builds, k_duo only; profiles/r06_convoy.log, r06_convoy2.log.  Result: it does hold the order without a rate --
+// one-pole banks 368 - 374 Gsamples/s at Q = 16, S = 2 ... 8 against the shipped clock's 359 and the best clock's 375 -- but every
+// checkpoint is a scalar load's latency in the wave that requests the tiles: the FMA bank, whose helper wave is its limit, gets 337 -
+// 342 against the clock's 350 (and 316 - 321 with clock AND convoy), 8192 channels gain nothing (257 - 286 against 350), short
+// intervals are ruinous (Q = 2: 73) and the one-pole figure is not monotonic in Q (Q = 32: 323 - 332, Q = 64: 297).  Added to the clock
+// it does stop the one-pole banks' collapse at rates past the knee (355 - 359 at 6000 - 7000 GB/s instead of 290) but not the others'.
+// Not shipped; the place for it would be the storing wave, which has the time.)
+// A CONVOY instead of a clock -- no rate to choose.  Every Q-th tile is a checkpoint; a wave announces the
+// checkpoints it reaches in a ring of 64 counters (scalar atomic add) and passes checkpoint c only when ALL `groups` workgroups have
+// reached checkpoint c - S, so no workgroup is more than (S + 1) Q tiles ahead of the slowest.  cfg = Q | S << 8.  The wait is bounded:
+// a wave that has waited 100 us stops synchronising for the rest of the launch (`off`).)
+__device__ __forceinline__ void convoy_sync(unsigned *ring, int cfg, unsigned groups, long long i, bool &off) {
+  const int Q = cfg & 255, S = (cfg >> 8) & 255;
+  if (off || (i % Q) != 0) return;
+  const long long c = i / Q;
+  const unsigned one = 1u;
+  asm volatile("s_atomic_add %0, %1, 0x0" : : "s"(one), "s"(ring + (c & 63) * 16) : "memory");
+  if (c < S) return;
+  const long long w = c - S;
+  const unsigned target = groups * (unsigned)(w / 64 + 1);
+  const unsigned *slot = ring + (w & 63) * 16;
+  long long t0 = 0;
+  for (;;) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(slot) : "memory");
+    if (v >= target) return;
+    const long long now = (long long)wall_clock64();
+    if (t0 == 0) t0 = now;
+    else if (now - t0 > 10000) { off = true; return; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
 #endif
+// the counter ring of one convoy launch on `stream` (64 counters, a 64-byte line each), zeroed in stream order; nullptr: none (alz_scan.hip)
+unsigned *convoy_ring(hipStream_t stream);
 // pace of a launch whose workgroups together move bytes_per_step per tile step, at gbps (GB/s; <= 0: no pacing): 1/16 ticks of 10 ns
 inline int tile_pace16(long long bytes_per_step, int gbps) {
   const int pace16 = gbps > 0 ? (int)((bytes_per_step * 16ll * 100ll + gbps * 500ll) / (gbps * 1000ll)) : 0;

@@ -145,6 +145,26 @@ int device_cus() {
   return cached;
 }
 
+unsigned *convoy_ring(hipStream_t stream) {
+  constexpr int kRings = 8;                           // launches in flight that may each own a ring
+  constexpr size_t kRingBytes = 64 * 64;
+  thread_local int cached_dev = -1;
+  thread_local char *rings = nullptr;
+  thread_local unsigned next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (dev != cached_dev || !rings) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    char *w = nullptr;
+    if (hipMalloc((void **)&w, kRings * kRingBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (kept for the process)
+    rings = w; cached_dev = dev; next = 0;
+  }
+  char *ring = rings + (size_t)(next++ % kRings) * kRingBytes;
+  if (hipMemsetAsync(ring, 0, kRingBytes, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return reinterpret_cast<unsigned *>(ring);
+}
+
 bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk_len) {
   if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform) || sec.any_div || sec.na < 2) return false;
   if (io.c_first != 0 || io.c_count != io.channels || io.channels % 16) return false;

@@ -60,6 +60,9 @@ struct WArgs {
   int aux_pace;   // k_duo, one-pole banks that fill the chip: pauses (x 64 cycles) between the quarters of AUX's feed-forward pass
   int stagger;    // k_duo, channel-major: workgroup g starts g * stagger ticks (10 ns) late (0: all together) -- see launch_wave
   int tile_pace;  // k_duo: the helper wave requests tile i + 3 no earlier than tile_pace / 16 ticks (10 ns) x i after its start (0: free-running)
+  unsigned *convoy;      // (experiment, tuning builds) the counter ring of alz_common.h convoy_sync, nullptr: none
+  int convoy_cfg;
+  unsigned convoy_groups;
 };
 
 // one 1 KiB DMA chunk: every lane supplies its own 16-byte global source, the data lands
@@ -697,9 +700,13 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
     const long long pace0 = p.tile_pace > 0 ? (long long)wall_clock64() : 0;
 
     long long pace_shift = 0;
+    [[maybe_unused]] bool convoy_off = false;
     for (int64_t i = 0; i < nt; ++i) {
       if (!STORER && !NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
       if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);   // all workgroups keep to one clock (alz_common.h)
+#ifdef ALZ_TUNING   // (experiment, profiles/r06_convoy*.log: not in the shipped kernels)
+      if (p.convoy) convoy_sync(p.convoy, p.convoy_cfg, p.convoy_groups, i, convoy_off);
+#endif
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
         // operations issued after tile i+1's DMA: the DMA of tiles i+2 .. i+kXRing-1 and the stores
@@ -1031,12 +1038,18 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
       if (tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", min_tiles)) p.tile_pace = tile_pace16(groups * 16384ll, gbps);
     }
   }
+  p.convoy = nullptr; p.convoy_cfg = 0; p.convoy_groups = (unsigned)groups;
+  if (p.tile_pace > 0 && ALZ_TUNE("ALZ_CONVOY", 0) > 0) {       // (experiment: the convoy in place of the clock, same launches)
+    p.convoy = convoy_ring(stream);
+    p.convoy_cfg = ALZ_TUNE("ALZ_CONVOY", 0);
+    if (p.convoy && ALZ_TUNE("ALZ_CONVOY_CLOCK", 0) == 0) p.tile_pace = 0;     // (ALZ_CONVOY_CLOCK=1: the clock AND the convoy)
+  }
   // One-pole banks that fill the chip once, long blocks NOT on the clock (in place, or under the streaming size): AUX's
   // feed-forward pass in quarters with 2 x 64-cycle pauses.  Measured on three boxes (profiles/r04_duo_patterns.log): 4096
   // channels x 2^20 time-major +2 / +13 / +10 ... 16 %, channel-major +14 / +20 %, 2^18 +1 ... 13 %, 5120 channels +6 %; three
   // pauses are better on one box and worse on the others; blocks of 2^16 and banks of 6144 - 7680 channels lose 1 - 3 %, half a
   // chip of workgroups a quarter: excluded.
-  p.aux_pace = (duo && !ch && p.tile_pace == 0 && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
+  p.aux_pace = (duo && !ch && p.tile_pace == 0 && !p.convoy && groups >= 256 && groups <= 320 && tiles >= 2048 && (!fused || ALZ_DUO_FMA3) && ((sec.present_b == 1u && sec.present_a == 1u) || ALZ_PACE_ALL))
                    ? ALZ_TUNE("ALZ_DUO_AUXPACE", 2) : 0;
   // (-DALZ_TUNING builds: a staggered start of the workgroups of a channel-major launch, stagger_start in alz_common.h -- measured on
   // identical buffers, round 6: no effect; what decides between 12.3 and 16 ms there is where the blocks lie physically)
