@@ -71,7 +71,9 @@ __device__ __forceinline__ void pace_wait(long long t0, long long i, int pace, l
 // 342 against the clock's 350 (and 316 - 321 with clock AND convoy), 8192 channels gain nothing (257 - 286 against 350), short
 // intervals are ruinous (Q = 2: 73) and the one-pole figure is not monotonic in Q (Q = 32: 323 - 332, Q = 64: 297).  Added to the clock
 // it does stop the one-pole banks' collapse at rates past the knee (355 - 359 at 6000 - 7000 GB/s instead of 290) but not the others'.
-// Not shipped; the place for it would be the storing wave, which has the time.)
+// With the checkpoint in the storing wave instead (cfg bit 16; the per-tile barrier holds the workgroup; r06_convoy3.log) the FMA bank
+// does reach 355 - 360 at Q = 8, S = 2 ... 4 -- and the one-pole banks fall to 317 - 359, 6144 channels to 134 - 250 against the clock's
+// 282, 8192 channels stay at the free-running 239 - 280: which (Q, S) works depends on the shape.  Not shipped.)
 // A CONVOY instead of a clock -- no rate to choose.  Every Q-th tile is a checkpoint; a wave announces the
 // checkpoints it reaches in a ring of 64 counters (scalar atomic add) and passes checkpoint c only when ALL `groups` workgroups have
 // reached checkpoint c - S, so no workgroup is more than (S + 1) Q tiles ahead of the slowest.  cfg = Q | S << 8.  The wait is bounded:

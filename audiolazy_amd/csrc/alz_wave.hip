@@ -682,8 +682,12 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
     if (STORER && wave == 2) {
       // the storing wave: tile i - 1 while REC works on tile i
       __builtin_amdgcn_s_barrier();
+      [[maybe_unused]] bool convoy_off_s = false;
       for (int64_t i = 0; i < nt; ++i) {
         if (!NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
+#ifdef ALZ_TUNING   // (experiment: the convoy's checkpoint in THIS wave, which has the time -- cfg bit 16; the barrier below holds the workgroup)
+        if (p.convoy && (p.convoy_cfg & 0x10000)) convoy_sync(p.convoy, p.convoy_cfg, p.convoy_groups, i, convoy_off_s);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!ALZ_DBG(p, 8)) DUO_BARRIER();
       }
@@ -705,7 +709,7 @@ __global__ __launch_bounds__((ALZ_DUO_STORER && (!FMA || duo_fma_storer(CM, NT))
       if (!STORER && !NOSTORE && i >= 1 && !ALZ_DBG(p, 4)) store_tile(i - 1);
       if (p.tile_pace > 0) pace_wait(pace0, i, p.tile_pace, pace_shift);   // all workgroups keep to one clock (alz_common.h)
 #ifdef ALZ_TUNING   // (experiment, profiles/r06_convoy*.log: not in the shipped kernels)
-      if (p.convoy) convoy_sync(p.convoy, p.convoy_cfg, p.convoy_groups, i, convoy_off);
+      if (p.convoy && !(STORER && (p.convoy_cfg & 0x10000))) convoy_sync(p.convoy, p.convoy_cfg, p.convoy_groups, i, convoy_off);
 #endif
       if (i + kXRing - 1 < nt && !ALZ_DBG(p, 1)) queue_tile(i + kXRing - 1);
       if (i + 1 < nt) {
