@@ -16,5 +16,6 @@ case ${1:-cpu} in
   gpu) unset LD_PRELOAD; export ALZ_LIBRARY=$R/tools/variants/libalzhip_ubsan.so
        python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok under host UBSan')" 2>&1 | tail -3
        python -m pytest tests/test_gpu_scan.py tests/test_gpu_mid.py tests/test_gpu_bank.py tests/test_gpu_host_path.py -x -q -m gpu 2>&1 | tail -5
+       python -m pytest tests/test_gpu_fullwidth.py -x -q -m gpu -k "clock" 2>&1 | tail -3     # (round 6, third session: the launchers of the clocked shapes)
        python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --channels 512 --log2-samples 14 --full-json - 2>&1 | tail -2 | cut -c1-300 ;;
 esac
