@@ -676,6 +676,8 @@ int launch_sparse(const SectionDev &sec, const BlockIO &io, hipStream_t stream, 
   // resident (one per CU).  4096 channels x 2^18, D = 441 (profiles/r06_pace_others.log, r06_pace2.log): free-running 284 - 300
   // Gsamples/s, 5600 GB/s 301 - 313, 5900 306 - 311, 6200 314 - 317, 6500 325 / 296 (the knee).
   const int cus = device_cus() > 0 ? device_cus() : 256;
+  // (several full rounds of workgroups on the clock, as k_tvpc has them: 8192 channels 313 - 316 -> 289 / 314, 12288 channels 293 - 310 -> 325,
+  // 7680 channels 299 - 302 -> 305 - 313, profiles/r06_pace_rounds.log: not a clear gain here, so launches above the CU count run free)
   p.step_pace = (pl.ok && !pl.cm && !pl.string && (int)pl.grid <= cus) ? tile_pace16((long long)pl.grid * 256ll * pl.T, ALZ_TUNE("ALZ_COMB_PACE_GBPS", kCombPaceGBps)) : 0;
   const unsigned gx = (unsigned)((io.c_count + 63) / 64);
   const int64_t nx = (int64_t)(sec.nb - 1) * io.channels, ny = (int64_t)(sec.na - 1) * io.channels;

@@ -108,6 +108,16 @@ inline int tile_pace16(long long bytes_per_step, int gbps) {
   return pace16 > 0 && pace16 < (1 << 20) ? (pace16 | (ALZ_TUNE("ALZ_PACE_FORGIVE", 0) << 20)) : 0;
 }
 
+// Workgroups of a launch that run TOGETHER when a CU holds one of them: all of them up to the CU count; of a larger launch the CU count
+// when its rounds are full ones (the last round at least 3/4 of a full one: each round starts where the one before -- kept in step by
+// the clock -- ends, and paces itself from its own start), 0 otherwise (a short last round would be throttled to a clock sized for a
+// full one: 320 and 512 groups on a clock for all of them lost 20 - 37 %, profiles/r06_pace2.log).
+inline long long paced_groups_one_per_cu(long long groups, int cus) {
+  if (groups <= cus) return groups;
+  const long long last = groups % cus;
+  return (last == 0 || 4 * last >= 3ll * cus) ? cus : 0;
+}
+
 // thread-local last-error message (alz_last_error)
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);

@@ -443,10 +443,13 @@ int launch_tvpc(const double *x, double *y, int64_t n, int64_t ldx, int64_t ldy,
   // per group.  4096 channels x 2^18, three series, two runs (profiles/r06_pace_others.log, r06_pace2.log): free-running 112 - 115
   // Gsamples/s, 5200 GB/s 130, 5500 137, 5800 138 - 144 (0.72 of 8 TB/s), 6000 118 / 136 (the knee), 6200 and more 110 - 111; every
   // block length gains (2^14 +21 %, 2^16 +25 %, 2^19 +26 %); 2048 channels +- 0.  The clock only means something while all groups
-  // are resident (one workgroup per CU: ~147 KiB of LDS): 320 and 512 groups on it lost 20 - 37 % (the second round of workgroups),
-  // so they run free.
+  // are resident (one workgroup per CU: ~147 KiB of LDS): 320 and 512 groups on a clock sized for all of them lost 20 - 37 %.  Sized
+  // for ONE round of workgroups instead (paced_groups_one_per_cu: each round starts where the one before, kept in step, ends and
+  // paces itself from its own start) launches of full rounds gain as well: 8192 channels 114 - 119 -> 139.5 - 139.8, 7680 channels
+  // (a last round of 224) 113 - 115 -> 130 - 131, 12288 channels 112 - 115 -> 115 - 118; launches with a short last round (5120, 6144
+  // channels) run free (profiles/r06_pace_rounds.log).
   const int cus = device_cus() > 0 ? device_cus() : 256;
-  p.tile_pace = channels / 16 <= cus ? tile_pace16((channels / 16) * 8192ll * (2 + nsb + nsa), ALZ_TUNE("ALZ_TVPC_PACE_GBPS", kTvpcPaceGBps)) : 0;
+  p.tile_pace = tile_pace16(paced_groups_one_per_cu(channels / 16, cus) * 8192ll * (2 + nsb + nsa), ALZ_TUNE("ALZ_TVPC_PACE_GBPS", kTvpcPaceGBps));
   const size_t lds = (size_t)(kXRing + kPRing + kYRing) * kSlot + (size_t)nsb * kSRing * kSlot + (size_t)nsa * kSRing * kASlot;
   const int rc = ensure_dynamic_lds((const void *)fn, (int)lds);
   if (rc) return rc;
