@@ -907,6 +907,14 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   int g = 64;
   if (lanes < 64 * 256) g = 32;
   if (lanes < 48 * 256) g = 16;
+  // ... except time-major streaming blocks of whole ROUNDS of 512 two-wave workgroups (8192, 16 384, 24 576, 32 768 channels on 256 CUs):
+  // on the common tile clock (tile_pace below; each round starts where the one before, kept in step, ends) k_duo does 341 - 350
+  // Gsamples/s bit-exact against k_wave<16>'s 300 - 305 at 8192 channels and k_wave<64>'s 330 / 306 / 319 at 16 384 / 24 576 / 32 768
+  // (profiles/r06_pace5.log, r06_duo_rounds.log; free-running it is the slower one)
+  const int64_t round_lanes = 32ll * (device_cus() > 0 ? device_cus() : 256);
+  const bool clocked_rounds = !cm && !ch && io.stream_once && !sec.any_div && !io.pre_op && lanes % round_lanes == 0 &&
+                              lanes / round_lanes <= ALZ_TUNE("ALZ_DUO_ROUNDS_MAX", 4) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
+  if (clocked_rounds) g = 16;
   static const int g_env = ALZ_TUNE("ALZ_G", 0);   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
   if (sec.any_div) g = 16;      // a0 != 1 somewhere: only the two-wave kernel has the dividing form
@@ -947,12 +955,9 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // the single-wave kernel overtakes the two-wave one once a CU holds more than two workgroups' worth
   // of channels (profiles/r02_bank_width_sweep.log: 8192 channels 297 vs 288, 12288 283 vs 253)
   static const int single_from = ALZ_TUNE("ALZ_DUO_MAX_LANES", 8192);
-  // ... unless the block is of streaming size and exactly two workgroups per CU make up the launch (8192 channels: 512 groups): on
-  // the common tile clock (tile_pace below) the two-wave kernel does 348 - 368 Gsamples/s against k_wave<16>'s 300 - 305
-  // (profiles/r06_pace5.log; free-running it is the slower one, 282 - 289)
-  const bool duo_clocked_wide = g == 16 && !cm && !ch && io.stream_once && !sec.any_div && !io.pre_op &&
-                                lanes <= 32ll * (device_cus() > 0 ? device_cus() : 256) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
-  const bool prefer_single = g == 16 && lanes >= single_from && !ch && !(lanes == single_from && duo_clocked_wide);
+  // ... unless the launch is whole rounds of workgroups on the tile clock (clocked_rounds above)
+  const bool duo_clocked_wide = g == 16 && clocked_rounds;
+  const bool prefer_single = g == 16 && lanes >= single_from && !ch && !duo_clocked_wide;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
   const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm || paced_tm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
@@ -1033,13 +1038,16 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   {
     const int cus = device_cus() > 0 ? device_cus() : 256;
     const bool one_pole = sec.present_b == 1u && sec.present_a == 1u;
-    if (duo && !cm && !ch && io.stream_once && !sec.any_div && groups >= cus && groups <= 2 * cus && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0) {
+    int64_t groups_paced = groups;
+    const bool rounds = groups > 2 * cus && groups % (2 * cus) == 0;      // (several full rounds of two workgroups per CU)
+    if (duo && !cm && !ch && io.stream_once && !sec.any_div && groups >= cus && (groups <= 2 * cus || rounds) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0) {
       int gbps = 0, min_tiles = 2048;
-      if (groups > cus) gbps = groups <= cus + 5 * cus / 8 ? kDuoPaceGBpsShared : kDuoPaceGBpsTwo;
+      if (rounds) groups_paced = 2 * cus, gbps = kDuoPaceGBpsTwo;
+      else if (groups > cus) gbps = groups <= cus + 5 * cus / 8 ? kDuoPaceGBpsShared : kDuoPaceGBpsTwo;
       else if (duo_fma) gbps = nt_tiles ? kDuoPaceGBps : 0;
       else if (one_pole) gbps = kDuoPaceGBpsOnePole, min_tiles = 1024;
       gbps = ALZ_TUNE("ALZ_DUO_PACE_GBPS", gbps);
-      if (tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", min_tiles)) p.tile_pace = tile_pace16(groups * 16384ll, gbps);
+      if (tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", min_tiles)) p.tile_pace = tile_pace16(groups_paced * 16384ll, gbps);
     }
   }
   p.convoy = nullptr; p.convoy_cfg = 0; p.convoy_groups = (unsigned)groups;

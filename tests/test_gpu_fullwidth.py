@@ -324,11 +324,11 @@ def test_fused_time_major_streaming_block_common_tile_clock(alz, oracle, bench, 
 
 
 @pytest.mark.parametrize("C,N,kind", [(4096, 1 << 17, "one-pole"), (4096, 70000, "one-pole-abs"), (5120, 1 << 17, "one-pole"),
-                                      (6144, 1 << 17, "biquad"), (7680, 131072 + 40, "biquad"), (8192, 1 << 17, "biquad")])
+                                      (6144, 1 << 17, "biquad"), (7680, 131072 + 40, "biquad"), (8192, 1 << 17, "biquad"), (16384, 1 << 17, "biquad")])
 def test_time_major_streaming_blocks_on_the_tile_clock_bit_exact(alz, oracle, bench, C, N, kind):
   """Bit-exact banks whose time-major streaming blocks run on the common tile clock (round 6, alz_wave.hip launch_wave_impl): one-pole
   banks that fill the chip (308 -> 358 Gsamples/s; with and without |x| fused into the loads) and two-pole banks of 257 - 512
-  groups (+2 ... +23 %; 8192 channels: the two-wave kernel instead of k_wave<16>).  The clock only decides WHEN a tile is requested:
+  groups (+2 ... +23 %; 8192 channels and its multiples up to 32 768, in rounds of 512 workgroups: the two-wave kernel instead of k_wave<16 / 64>).  The clock only decides WHEN a tile is requested:
   strided channels over the whole block and a second block continuing the stream, bit for bit against the oracle."""
   import torch
   if kind == "biquad":
