@@ -60,6 +60,7 @@ __device__ __forceinline__ void pace_wait(long long t0, long long i, int pace, l
   const long long due = t0 + ((i * (long long)pace16) >> 4) + shift;
   const long long now = (long long)wall_clock64();
   if (now < due) {
+    if (due - now > (1ll << 18)) return;       // (no tile step of these kernels is 2.6 ms: a schedule that far ahead is not one to keep)
     do __builtin_amdgcn_s_sleep(1); while ((long long)wall_clock64() < due);
   } else if (forgive > 0 && now - due > forgive) {
     shift += now - due;
@@ -103,8 +104,12 @@ __device__ __forceinline__ void convoy_sync(unsigned *ring, int cfg, unsigned gr
 // the counter ring of one convoy launch on `stream` (64 counters, a 64-byte line each), zeroed in stream order; nullptr: none (alz_scan.hip)
 unsigned *convoy_ring(hipStream_t stream);
 // pace of a launch whose workgroups together move bytes_per_step per tile step, at gbps (GB/s; <= 0: no pacing): 1/16 ticks of 10 ns
+// (the ticks are those of the device's wall clock -- s_memrealtime: 100 MHz on gfx950, asked of the runtime per device; a device that
+// does not say runs free: a mis-scaled clock would THROTTLE, the waits are not bounded)
+int device_wall_clock_khz();
 inline int tile_pace16(long long bytes_per_step, int gbps) {
-  const int pace16 = gbps > 0 ? (int)((bytes_per_step * 16ll * 100ll + gbps * 500ll) / (gbps * 1000ll)) : 0;
+  const long long khz = gbps > 0 ? device_wall_clock_khz() : 0;
+  const int pace16 = khz > 0 ? (int)((bytes_per_step * 16ll * khz / 1000ll + gbps * 500ll) / (gbps * 1000ll)) : 0;
   return pace16 > 0 && pace16 < (1 << 20) ? (pace16 | (ALZ_TUNE("ALZ_PACE_FORGIVE", 0) << 20)) : 0;
 }
 

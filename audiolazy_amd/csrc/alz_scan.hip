@@ -165,6 +165,19 @@ unsigned *convoy_ring(hipStream_t stream) {
   return reinterpret_cast<unsigned *>(ring);
 }
 
+int device_wall_clock_khz() {
+  thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cached_dev) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) { (void)hipGetLastError(); khz = 0; }
+    cached = khz;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
 bool scan_takes_one_pass(const SectionDev &sec, const BlockIO &io, int64_t chunk_len) {
   if (!(sec.nb <= 3 && sec.na <= 3 && sec.uniform) || sec.any_div || sec.na < 2) return false;
   if (io.c_first != 0 || io.c_count != io.channels || io.channels % 16) return false;
