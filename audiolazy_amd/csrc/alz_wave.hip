@@ -1034,6 +1034,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   //    224 - 236; 5120 211 - 229 -> 244 - 249 at 4800, 237 - 243 at 5200; 5632 224 - 245 -> 266 - 274 (4800 - 5200), 256 - 263 (5600);
   //    6144 240 - 255 -> 289 - 294 (4800 - 5200); 7168 252 - 269 -> 300 (4800), 310 - 318 (5200), 312 - 320 (5600); 7680 270 - 272 ->
   //    300, 324, 327 - 334.  FMA mode the same: 5120 206 - 219 -> 247 - 251, 7168 270 - 272 -> 309 - 315.  One-pole, 5120: 217 -> 249 - 254.
+  //  * whole rounds of 512 groups (16 384, 24 576, 32 768 channels; the clock sized for ONE round, each round starting where the one
+  //    before -- kept in step -- ends; r06_duo_rounds.log): 346 - 348 / 347 / 341 bit-exact against k_wave<64>'s 330 / 306 / 319.
   p.tile_pace = 0;
   {
     const int cus = device_cus() > 0 ? device_cus() : 256;
