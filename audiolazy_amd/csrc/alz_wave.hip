@@ -912,8 +912,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // Gsamples/s bit-exact against k_wave<16>'s 300 - 305 at 8192 channels and k_wave<64>'s 330 / 306 / 319 at 16 384 / 24 576 / 32 768
   // (profiles/r06_pace5.log, r06_duo_rounds.log; free-running it is the slower one)
   const int64_t round_lanes = 32ll * (device_cus() > 0 ? device_cus() : 256);
-  const bool clocked_rounds = !cm && !ch && io.stream_once && !sec.any_div && !io.pre_op && lanes % round_lanes == 0 &&
-                              lanes / round_lanes <= ALZ_TUNE("ALZ_DUO_ROUNDS_MAX", 4) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
+  // (a block of that size processed in place, or between the sections of a cascade: ONE round only -- 8192 channels 302 -> 349.5 in both
+  // modes; 16 384 and 32 768 channels in rounds lose there, 289 - 292 / 263 - 265 against k_wave<64>'s 323 / 305: profiles/r06_pace_inplace2.log)
+  const bool big_block = !ch && (uint64_t)io.n * (uint64_t)io.channels * 8u >= (256ull << 20);
+  const int64_t rounds_max = io.stream_once ? ALZ_TUNE("ALZ_DUO_ROUNDS_MAX", 4) : (big_block ? 1 : 0);
+  const bool clocked_rounds = !cm && !ch && !sec.any_div && !io.pre_op && lanes % round_lanes == 0 &&
+                              lanes / round_lanes <= rounds_max && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
   if (clocked_rounds) g = 16;
   static const int g_env = ALZ_TUNE("ALZ_G", 0);   // tuning override
   if (g_env == 16 || g_env == 32 || g_env == 64) g = g_env;
@@ -1042,7 +1046,11 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
     const bool one_pole = sec.present_b == 1u && sec.present_a == 1u;
     int64_t groups_paced = groups;
     const bool rounds = groups > 2 * cus && groups % (2 * cus) == 0;      // (several full rounds of two workgroups per CU)
-    if (duo && !cm && !ch && io.stream_once && !sec.any_div && groups >= cus && (groups <= 2 * cus || rounds) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0) {
+    // Blocks of the streaming size that are processed in place or lie between the sections of a cascade (not `stream_once`: the kernels
+    // without non-temporal tiles) gain the same way (profiles/r06_pace_inplace.log, in place): one-pole banks 303 -> 359, 6144 channels
+    // 233 - 249 -> 269 - 274, 7168 channels in the FMA mode 265 -> 293 - 304.
+    const bool big = io.stream_once || (ALZ_TUNE("ALZ_DUO_PACE_ANY", 1) != 0 && (uint64_t)io.n * (uint64_t)io.channels * 8u >= (256ull << 20));
+    if (duo && !cm && !ch && big && !sec.any_div && groups >= cus && (groups <= 2 * cus || rounds) && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0) {
       int gbps = 0, min_tiles = 2048;
       if (rounds) groups_paced = 2 * cus, gbps = kDuoPaceGBpsTwo;
       else if (groups > cus) gbps = groups <= cus + 5 * cus / 8 ? kDuoPaceGBpsShared : kDuoPaceGBpsTwo;

@@ -464,7 +464,7 @@ def wl_biquad(ctx, args, alz, C, N, c_lo, c_total, steps, warmup, check=True, ti
   bank.reset()
   shape = (N, C) if lay == "time" else (C, N)
   x = ctx.noise(shape)
-  y = torch.empty(shape, dtype=torch.float64, device=ctx.dev)
+  y = x if getattr(args, "in_place", False) else torch.empty(shape, dtype=torch.float64, device=ctx.dev)    # (--in-place: y = x, measurement runs only)
   elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout=lay, out=y), steps, warmup)
   kernel = bank.last_kernel
   exact = not args.fused and not (time_parallel and ("k_scan" in kernel or "k_look" in kernel))
@@ -694,7 +694,7 @@ def wl_envelope(ctx, args, alz, C, N, steps, warmup):
   bank = alz.FilterBank([(b, a)], n_inputs=C, device=ctx.local).set_input_map("abs")
   bank.reset()
   x = ctx.noise((N, C), 4)
-  y = torch.empty((N, C), dtype=torch.float64, device=ctx.dev)
+  y = x if getattr(args, "in_place", False) else torch.empty((N, C), dtype=torch.float64, device=ctx.dev)
   elapsed, k_ms = ctx.timed(lambda: bank.process(x, layout="time", out=y), steps, warmup)
   kernel = bank.last_kernel + " (|x| fused into the input reads)"
   parity = "skipped (--no-parity-check)"
@@ -1120,7 +1120,7 @@ def main():
                        "directory can be made, '-' to skip")
   ap.add_argument("--comb-delay", type=int, default=441, help="--workload comb: the feedback delay in samples")
   ap.add_argument("--comb-linearized", action="store_true", help="--workload comb: two adjacent feedback taps (linearize()d fractional delay)")
-  ap.add_argument("--in-place", action="store_true", help="--workload comb: y = x")
+  ap.add_argument("--in-place", action="store_true", help="--workload comb / biquad / envelope: y = x (with --no-parity-check: the block is overwritten by every step)")
   ap.add_argument("--workload", choices=["biquad", "fir", "gammatone", "lpc", "envelope", "timevar", "comb", "butter6", "maverage256"], default="biquad",
                   help="biquad = configs[1] (the contract line); fir = configs[2]; gammatone = configs[3] "
                        "(256 bands x 64 streams per GPU); lpc = configs[4] (65536 frames x 480, order 16)")

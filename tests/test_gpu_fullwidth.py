@@ -357,6 +357,36 @@ def test_time_major_streaming_blocks_on_the_tile_clock_bit_exact(alz, oracle, be
   assert same_bits(got, ref)
 
 
+@pytest.mark.parametrize("C,N,kind", [(4096, 1 << 17, "one-pole"), (6144, 1 << 17, "biquad"), (8192, 1 << 17, "biquad")])
+def test_time_major_blocks_in_place_on_the_tile_clock_bit_exact(alz, oracle, bench, C, N, kind):
+  """The same shapes processed IN PLACE (y = x: the kernels without non-temporal tiles; 8192 channels: one round of the two-wave
+  kernel instead of k_wave<16>) -- one-pole banks 303 -> 359 Gsamples/s, 6144 channels +10 ... 15 %, 8192 channels 302 -> 349.5
+  (profiles/r06_pace_inplace.log, r06_pace_inplace2.log).  Two blocks through the same buffer, bit for bit against the oracle."""
+  import torch
+  if kind == "biquad":
+    b, a = bench.resonator_coefs(C)
+    nb, na = 3, 3
+  else:
+    cut = np.geomspace(2 * np.pi * 5 / 48000., 2 * np.pi * 200 / 48000., C)
+    filts = [alz.lowpass(float(c)) for c in cut]
+    b, a = np.array([f.numlist for f in filts]), np.array([f.denlist for f in filts])
+    nb, na = 1, 2
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 24).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  bank = alz.FilterBank([(b, a)], n_inputs=C)
+  bank.reset()
+  got, xs = [], []
+  for seed in (31, 37):
+    x = _gpu_noise((N, C), seed)
+    xs.append(x.index_select(1, idx).cpu().numpy())
+    y = bank.process(x, layout="time", out=x)
+    assert y.data_ptr() == x.data_ptr() and bank.last_kernel.startswith("k_duo<16>"), bank.last_kernel
+    got.append(y.index_select(1, idx).cpu().numpy())
+    del x, y
+  ref = oracle.bank([nb], [na], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate(xs, axis=0), layout="time")
+  assert same_bits(np.concatenate(got, axis=0), ref)
+
+
 @pytest.mark.parametrize("mode", [True, "one-pass"])
 def test_narrow_bank_time_parallel_full_block_length(alz, oracle, bench, mode):
   """The time-parallel modes over a whole 2^20-sample block of the 512-channel shard (2048 chunk boundaries in the
