@@ -409,6 +409,8 @@ constexpr bool duo_fma_storer(bool cm, bool nt) { return ALZ_DUO_FMA3 || nt; }
 #endif
 static constexpr int kDuoPaceGBps = ALZ_DUO_PACE_GBPS;   // the common tile clock of the time-major FMA kernel, see launch_wave
 static constexpr int kDuoPaceGBpsOnePole = 5750;         // ... of the one-pole banks' bit-exact kernel (followed up to 6100 on four boxes, not on a fifth)
+static constexpr int kDuoPaceGBpsInPlace = 5000;         // two-pole banks bit-exact IN PLACE: 296 free-running, 4900 306, 5100 314, 5300 299 (the recurrence
+                                                         // wave's floor of that lease, 13.6 ms; past it the free-running rate again: r06_pace_inplace3.log)
 static constexpr int kDuoPaceGBpsShared = 5000;          // 257 - 416 groups: some CUs hold two workgroups
 static constexpr int kDuoPaceGBpsTwo = 5600;             // 417 - 512 groups: (nearly) all do
 #ifndef ALZ_DUO_SLOT
@@ -1033,7 +1035,8 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   //  * 256 groups, one-pole banks bit-exact (envelope: |x| -> lowpass; profiles/r06_pace3.log, r06_pace4.log): the paced pass of
   //    round 4 (aux_pace) 305 - 315; the clock INSTEAD of it 5500 343, 5700 356, 5900 366 - 368, 6100 378 - 379; 2^16 samples 328 -
   //    335 against 293 - 296, 2^17 345 against 308, 2^18 353 against 309.
-  //  * 256 groups, two-pole banks bit-exact: 327 with or without (the recurrence wave's issue rate bounds them): no clock.
+  //  * 256 groups, two-pole banks bit-exact: 327 with or without (the recurrence wave's issue rate bounds them): no clock -- except in
+  //    place (no non-temporal tiles: 14.5 ms, above that floor), where a clock just under the floor brings 296 -> 306 - 314.
   //  * 257 - 512 groups (some or all CUs hold two workgroups), 2^19 samples, bit-exact (r06_pace4.log): 4608 channels 215 - 232 ->
   //    224 - 236; 5120 211 - 229 -> 244 - 249 at 4800, 237 - 243 at 5200; 5632 224 - 245 -> 266 - 274 (4800 - 5200), 256 - 263 (5600);
   //    6144 240 - 255 -> 289 - 294 (4800 - 5200); 7168 252 - 269 -> 300 (4800), 310 - 318 (5200), 312 - 320 (5600); 7680 270 - 272 ->
@@ -1056,6 +1059,7 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
       else if (groups > cus) gbps = groups <= cus + 5 * cus / 8 ? kDuoPaceGBpsShared : kDuoPaceGBpsTwo;
       else if (duo_fma) gbps = nt_tiles ? kDuoPaceGBps : 0;
       else if (one_pole) gbps = kDuoPaceGBpsOnePole, min_tiles = 1024;
+      else if (!io.stream_once) gbps = kDuoPaceGBpsInPlace;   // two-pole, in place: 14.5 ms free-running, not at the recurrence wave's floor
       gbps = ALZ_TUNE("ALZ_DUO_PACE_GBPS", gbps);
       if (tiles >= ALZ_TUNE("ALZ_DUO_PACE_MIN_TILES", min_tiles)) p.tile_pace = tile_pace16(groups_paced * 16384ll, gbps);
     }
