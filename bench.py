@@ -1024,10 +1024,10 @@ def short_parity(p):
 # The order of the compact line's secondary entries: the BASELINE configs come LAST, so that a record that keeps only
 # the tail of the line still holds configs[2..4].
 SECONDARY_ORDER = ("downstream_collective", "strong_scaling", "narrow512_bit_exact", "narrow512_time_parallel",
-                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "biquad_fma", "biquad_8192", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
+                   "narrow512_time_parallel_three_launch", "narrow512_time_parallel_chan", "biquad_chan", "biquad_chan_fma", "biquad_8192", "envelope_abs", "comb_fb", "comb_fb_chan", "karplus_one_string", "iir_order6", "maverage_recursive_256",
                    "timevar_shared", "timevar_per_channel",
                    "gammatone_one_stream", "gammatone_one_stream_time_parallel", "gammatone_one_stream_time_parallel_tm", "lpc_1m", "lpc_1m_bit_identical",
-                   "lpc_fma", "gammatone_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
+                   "lpc_fma", "gammatone_fma", "biquad_fma", "fir256_fma", "fir256_bit_exact", "gammatone", "lpc", "lpc_bit_identical")
 
 
 def compact_line(full):
