@@ -387,6 +387,34 @@ def test_time_major_blocks_in_place_on_the_tile_clock_bit_exact(alz, oracle, ben
   assert same_bits(np.concatenate(got, axis=0), ref)
 
 
+@pytest.mark.parametrize("C", [4096, 6144])
+def test_two_section_cascade_big_block_between_the_sections_bit_exact(alz, oracle, bench, C):
+  """A bank of TWO cascaded sections (resonator, then a one-pole lowpass) on a block of streaming size: the launches between the
+  sections are not `stream_once` launches (the intermediate block is read again) and run on the tile clock all the same (round 6,
+  third session).  Strided channels over the whole block, two blocks, bit for bit against the oracle's cascade."""
+  import torch
+  N = 1 << 17
+  b1, a1 = bench.resonator_coefs(C)
+  cut = np.geomspace(2 * np.pi * 5 / 48000., 2 * np.pi * 200 / 48000., C)
+  filts = [alz.lowpass(float(c)) for c in cut]
+  b2, a2 = np.array([f.numlist for f in filts]), np.array([f.denlist for f in filts])
+  bank = alz.FilterBank([(b1, a1), (b2, a2)], n_inputs=C)
+  bank.reset()
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 16).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  got, xs = [], []
+  for seed in (41, 43):
+    x = _gpu_noise((N, C), seed)
+    y = bank.process(x, layout="time")
+    xs.append(x.index_select(1, idx).cpu().numpy())
+    got.append(y.index_select(1, idx).cpu().numpy())
+    del x, y
+  bc = np.concatenate([b1[pick], b2[pick]], axis=1)
+  ac = np.concatenate([a1[pick], a2[pick]], axis=1)
+  ref = oracle.bank([3, b2.shape[1]], [3, a2.shape[1]], np.ascontiguousarray(bc), np.ascontiguousarray(ac), np.concatenate(xs, axis=0), layout="time")
+  assert same_bits(np.concatenate(got, axis=0), ref), bank.last_kernel
+
+
 @pytest.mark.parametrize("mode", [True, "one-pass"])
 def test_narrow_bank_time_parallel_full_block_length(alz, oracle, bench, mode):
   """The time-parallel modes over a whole 2^20-sample block of the 512-channel shard (2048 chunk boundaries in the
