@@ -613,12 +613,9 @@ static int process_dev_impl(alz_bank_t *h, const double *x_dev, double *y_dev, i
   io.zero = h->zero;
   io.fused = h->fused;
   io.look_sync = h->look_check == ALZ_LOOK_CHECK_CALL ? 1 : 0;
-  // (tuning builds, ALZ_NT_INPLACE=1: blocks processed in place count as streaming blocks too -- non-temporal tiles and the rules that
-  // hang on them.  Measured, in place (profiles/r06_nt_inplace.log): 16 384 channels k_wave<64> 315 - 324 -> k_duo in rounds 348, 6144
-  // channels 275 -> 292, channel-major 4096 channels 302 -> 310 bit-exact and 305 -> 334 in the FMA mode, one-pole banks and 8192
-  // channels unchanged -- but the time-major 4096-channel two-pole bank falls from 312 (its in-place clock) to 295 - 306 in both modes:
-  // not shipped as a blanket rule; the exceptions are the next thing to sort out here.)
-  io.stream_once = (h->n_sections == 1 && (x_dev != y_dev || ALZ_TUNE("ALZ_NT_INPLACE", 0) != 0) && (uint64_t)n * (uint64_t)h->channels * 8u >= (256ull << 20)) ? 1 : 0;
+  // (blocks processed in place are not `stream_once` here; k_duo's launcher gives them non-temporal tiles itself where that pays:
+  // alz_wave.hip, nt_in_place)
+  io.stream_once = (h->n_sections == 1 && x_dev != y_dev && (uint64_t)n * (uint64_t)h->channels * 8u >= (256ull << 20)) ? 1 : 0;
   int64_t sxn = layout == ALZ_TIME_MAJOR ? ldx : 1, sxc = layout == ALZ_TIME_MAJOR ? 1 : ldx;
   const int64_t syn = layout == ALZ_TIME_MAJOR ? ldy : 1, syc = layout == ALZ_TIME_MAJOR ? 1 : ldy;
   std::string last_noted;

@@ -914,10 +914,12 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   // Gsamples/s bit-exact against k_wave<16>'s 300 - 305 at 8192 channels and k_wave<64>'s 330 / 306 / 319 at 16 384 / 24 576 / 32 768
   // (profiles/r06_pace5.log, r06_duo_rounds.log; free-running it is the slower one)
   const int64_t round_lanes = 32ll * (device_cus() > 0 ? device_cus() : 256);
-  // (a block of that size processed in place, or between the sections of a cascade: ONE round only -- 8192 channels 302 -> 349.5 in both
-  // modes; 16 384 and 32 768 channels in rounds lose there, 289 - 292 / 263 - 265 against k_wave<64>'s 323 / 305: profiles/r06_pace_inplace2.log)
+  // (a block of that size between the sections of a cascade -- temporal tiles: ONE round only -- 8192 channels 302 -> 349.5 in both
+  // modes; 16 384 and 32 768 channels in rounds lose with temporal tiles, 289 - 292 / 263 - 265 against k_wave<64>'s 323 / 305:
+  // profiles/r06_pace_inplace2.log.  In place the tiles are non-temporal, nt_in_place below, and the rounds win: 348 at 16 384)
   const bool big_block = !ch && (uint64_t)io.n * (uint64_t)io.channels * 8u >= (256ull << 20);
-  const int64_t rounds_max = io.stream_once ? ALZ_TUNE("ALZ_DUO_ROUNDS_MAX", 4) : (big_block ? 1 : 0);
+  const int64_t rounds_max = (io.stream_once || (big_block && io.x == io.y && ALZ_TUNE("ALZ_NT_INPLACE", 1) != 0))   // (in place: with non-temporal tiles, below)
+                                 ? ALZ_TUNE("ALZ_DUO_ROUNDS_MAX", 4) : (big_block ? 1 : 0);
   const bool clocked_rounds = !cm && !ch && !sec.any_div && !io.pre_op && lanes % round_lanes == 0 &&
                               lanes / round_lanes <= rounds_max && ALZ_TUNE("ALZ_DUO_PACED", 1) != 0;
   if (clocked_rounds) g = 16;
@@ -965,7 +967,14 @@ static int launch_wave_impl(const SectionDev &sec, const BlockIO &io, hipStream_
   const bool duo_clocked_wide = g == 16 && clocked_rounds;
   const bool prefer_single = g == 16 && lanes >= single_from && !ch && !duo_clocked_wide;
   // non-temporal tile traffic (its own instantiations): large blocks that this call reads once and does not read back
-  const bool nt_tiles = io.stream_once && !ch && (!fused || ALZ_DUO_FMA3 || cm || paced_tm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
+  // ... and a block of that size processed IN PLACE (alz_api.hip does not call it `stream_once`): measured in place with and without
+  // (profiles/r06_nt_inplace.log) 16 384 channels k_wave<64> 315 - 324 -> k_duo in rounds 348, 6144 channels 275 -> 292, channel-major
+  // 4096 channels 302 -> 310 bit-exact and 305 -> 334 in the FMA mode, one-pole banks and 8192 channels unchanged -- except the
+  // time-major two-pole bank that fills the chip once, which would lose its in-place clock (312 -> 295 - 306 in both modes) and
+  // keeps the tiles temporal
+  const bool nt_in_place = !io.stream_once && big_block && io.x == io.y && !(chip_wide_tm && !(sec.present_b == 1u && sec.present_a == 1u)) &&
+                           ALZ_TUNE("ALZ_NT_INPLACE", 1) != 0;
+  const bool nt_tiles = (io.stream_once || nt_in_place) && !ch && (!fused || ALZ_DUO_FMA3 || cm || paced_tm) && ALZ_TUNE("ALZ_DUO_NT", 1) != 0;
   wave_fn duo = nullptr;
   bool duo_fma = false;
   if (g == 16 && sec.any_div) {

@@ -357,7 +357,8 @@ def test_time_major_streaming_blocks_on_the_tile_clock_bit_exact(alz, oracle, be
   assert same_bits(got, ref)
 
 
-@pytest.mark.parametrize("C,N,kind", [(4096, 1 << 17, "one-pole"), (4096, 1 << 17, "biquad"), (6144, 1 << 17, "biquad"), (8192, 1 << 17, "biquad")])
+@pytest.mark.parametrize("C,N,kind", [(4096, 1 << 17, "one-pole"), (4096, 1 << 17, "biquad"), (6144, 1 << 17, "biquad"), (8192, 1 << 17, "biquad"),
+                                      (16384, 1 << 17, "biquad")])
 def test_time_major_blocks_in_place_on_the_tile_clock_bit_exact(alz, oracle, bench, C, N, kind):
   """The same shapes processed IN PLACE (y = x: the kernels without non-temporal tiles; 8192 channels: one round of the two-wave
   kernel instead of k_wave<16>) -- one-pole banks 303 -> 359 Gsamples/s, 6144 channels +10 ... 15 %, 8192 channels 302 -> 349.5
@@ -385,6 +386,34 @@ def test_time_major_blocks_in_place_on_the_tile_clock_bit_exact(alz, oracle, ben
     del x, y
   ref = oracle.bank([nb], [na], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate(xs, axis=0), layout="time")
   assert same_bits(np.concatenate(got, axis=0), ref)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_channel_major_block_in_place_non_temporal_tiles(alz, oracle, bench, fused):
+  """A channel-major block of streaming size processed in place: k_duo's instantiations with non-temporal tiles (round 6, third
+  session: 302 -> 310 Gsamples/s bit-exact, 305 -> 334 in the FMA mode).  Two blocks through the same buffer against the oracle:
+  bit for bit, or within the FMA mode's tolerance."""
+  import torch
+  C, N = 4096, 1 << 14
+  b, a = bench.resonator_coefs(C)
+  pick = np.unique(np.r_[np.linspace(0, C - 1, 24).astype(int), 0, 15, 16, C - 1])
+  idx = torch.from_numpy(pick).cuda()
+  bank = alz.FilterBank([(b, a)], n_inputs=C).set_fused(fused)
+  bank.reset()
+  got, xs = [], []
+  for seed in (47, 53):
+    x = _gpu_noise((C, N), seed)
+    xs.append(x.index_select(0, idx).cpu().numpy())
+    y = bank.process(x, layout="chan", out=x)
+    assert y.data_ptr() == x.data_ptr() and bank.last_kernel.startswith("k_duo<16"), bank.last_kernel
+    got.append(y.index_select(0, idx).cpu().numpy())
+    del x, y
+  ref = oracle.bank([3], [3], np.ascontiguousarray(b[pick]), np.ascontiguousarray(a[pick]), np.concatenate(xs, axis=1), layout="chan")
+  got = np.concatenate(got, axis=1)
+  if fused:
+    assert norm_err(got, ref, 1) <= 1e-10
+  else:
+    assert same_bits(got, ref)
 
 
 @pytest.mark.parametrize("C", [4096, 6144])
