@@ -1,5 +1,5 @@
 #!/bin/bash
-# second pass of tools/pace_probe_others.sh: where k_tvpc's and k_comb_tm's clocks stop being followed; block lengths
+# second pass of tools/clock/pace_probe_others.sh: where k_tvpc's and k_comb_tm's clocks stop being followed; block lengths
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; O=$R/gpurun_out/r06_pace2; mkdir -p $O
 export ALZ_LIBRARY=$R/tools/variants/libalzhip_tuning.so
 B="--no-cpu-baseline --no-secondary --no-parity-check --steps 10 --warmup 3 --full-json -"
